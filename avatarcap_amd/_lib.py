@@ -1,0 +1,155 @@
+"""ctypes binding of libavcap_hip.so (include/avcap.h).
+
+There is no fallback: if the library is missing or no gfx950 device is present every entry point
+raises.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libavcap_hip.so')
+
+AVC_ERR_CAPACITY = -4
+
+
+class avc_dense(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('b', C.c_void_p), ('g', C.c_void_p), ('cout', C.c_int32), ('cin', C.c_int32)]
+
+
+class avc_bn(C.Structure):
+    _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('mean', C.c_void_p), ('var', C.c_void_p), ('eps', C.c_float)]
+
+
+_SIGNATURES = {
+    'avc_last_error': (C.c_char_p, []),
+    'avc_version': (C.c_int, []),
+    'avc_ctx_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    'avc_ctx_destroy': (C.c_int, [C.c_void_p]),
+    'avc_pack_warp_weights': (C.c_int, [C.c_void_p, C.POINTER(avc_dense), C.POINTER(avc_bn), C.POINTER(avc_dense), C.c_int]),
+    'avc_pack_template_weights': (C.c_int, [C.c_void_p, C.POINTER(avc_dense), C.POINTER(avc_dense), C.POINTER(avc_dense), C.c_int]),
+    'avc_pack_recon_weights': (C.c_int, [C.c_void_p, C.POINTER(avc_dense)]),
+    'avc_set_pose_feat_map': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'avc_set_img_feat_map': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'avc_avatar_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'avc_template_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'avc_recon_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
+    'avc_scatter_volume': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'avc_recon_mesh': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+    'avc_knn': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'avc_calculate_lbs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'avc_skinning': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'avc_timing_enable': (C.c_int, [C.c_void_p, C.c_int]),
+    'avc_timing_read': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+}
+
+_lib = None
+_ctxs: dict[int, int] = {}
+
+
+class AvcapError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f'libavcap_hip: {message} (status {status})')
+        self.status = status
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """The loaded library (raises if it has not been built: run `python -m avatarcap_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -m avatarcap_amd.build` '
+                               '(there is no CPU/eager fallback for the hot path)')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(status: int):
+    if status != 0:
+        raise AvcapError(status, lib().avc_last_error().decode())
+
+
+def ctx(device=None) -> int:
+    """Context handle of a HIP device (one per device, created on first use)."""
+    if device is None:
+        device = torch.cuda.current_device()
+    elif isinstance(device, torch.device):
+        if device.type != 'cuda':
+            raise RuntimeError(f'avatarcap_amd hot path needs a HIP (cuda) device, got {device}')
+        device = device.index if device.index is not None else torch.cuda.current_device()
+    if device not in _ctxs:
+        h = C.c_void_p()
+        check(lib().avc_ctx_create(int(device), C.byref(h)))
+        _ctxs[device] = h.value
+    return _ctxs[device]
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dev_ptr(t: torch.Tensor | None, dtype=torch.float32, name='tensor') -> int | None:
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name}: expected a torch.Tensor, got {type(t).__name__}')
+    if t.device.type != 'cuda':
+        raise RuntimeError(f'{name}: must live on the HIP device, got {t.device}')
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name}: must be contiguous')
+    return t.data_ptr()
+
+
+def f3(v) -> C.Array:
+    a = np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v, np.float32).reshape(-1)
+    return (C.c_float * len(a))(*a.tolist())
+
+
+# ---- weight marshalling --------------------------------------------------------------------
+def _host(t) -> np.ndarray:
+    a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    return np.ascontiguousarray(a, np.float32)
+
+
+class DenseList:
+    """Keeps the host arrays alive while the C side reads them."""
+
+    def __init__(self, entries):
+        self.keep = []
+        arr = (avc_dense * len(entries))()
+        for i, e in enumerate(entries):
+            w = _host(e['w']); b = _host(e['b'])
+            w = w.reshape(w.shape[0], -1)
+            g = _host(e['g']).reshape(-1) if e.get('g') is not None else None
+            self.keep += [w, b, g]
+            arr[i].w = w.ctypes.data; arr[i].b = b.ctypes.data
+            arr[i].g = g.ctypes.data if g is not None else None
+            arr[i].cout, arr[i].cin = w.shape
+        self.arr = arr
+
+
+class BnList:
+    def __init__(self, entries):
+        self.keep = []
+        arr = (avc_bn * len(entries))()
+        for i, e in enumerate(entries):
+            hs = [_host(e[k]) for k in ('gamma', 'beta', 'mean', 'var')]
+            self.keep += hs
+            arr[i].gamma, arr[i].beta, arr[i].mean, arr[i].var = (h.ctypes.data for h in hs)
+            arr[i].eps = float(e['eps'])
+        self.arr = arr

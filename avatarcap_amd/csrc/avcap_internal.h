@@ -1,0 +1,86 @@
+// Internal declarations shared by the translation units of libavcap_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/avcap.h"
+
+namespace avc {
+
+void set_error(const char *fmt, ...);
+#define AVC_HIP(call)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            avc::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return AVC_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+#define AVC_REQUIRE(cond, status, ...)                                                          \
+    do {                                                                                        \
+        if (!(cond)) { avc::set_error(__VA_ARGS__); return status; }                            \
+    } while (0)
+
+// ---- fused-MLP weight stream -----------------------------------------------------------------
+// A network is packed into one contiguous byte stream of *chunks*, in exactly the order the kernel
+// consumes them.  A chunk is a sequence of 2 KiB units [hi 1 KiB | lo 1 KiB]; each 1 KiB block is
+// one MFMA A-operand fragment (64 lanes x 8 halves, lane-linear), so a wave's ds_read_b128 of it
+// is conflict-free.  See fused_mlp.hip for the layouts.
+struct ChunkDesc { uint32_t offset, bytes; };
+
+struct PackedNet {
+    std::vector<uint8_t> stream;      // host copy of the chunk stream
+    std::vector<ChunkDesc> chunks;
+    std::vector<float> bias;          // per-row bias, pre-scaled by 2^sw, padded to the tile grid
+    std::vector<float> oscale;        // 2^-sw per layer
+    void *d_stream = nullptr;
+    ChunkDesc *d_chunks = nullptr;
+    float *d_bias = nullptr;
+    bool ready = false;
+    bool has_colour = false;
+};
+
+struct Timing { bool enabled = false; double total_ms[2] = {0, 0}; int64_t launches[2] = {0, 0};
+                std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[2]; };
+
+}  // namespace avc
+
+struct avc_ctx {
+    int device = 0;
+    int num_cus = 256;
+    avc::PackedNet warp_tmpl;      // warp + template packed as ONE stream (avatar query)
+    avc::PackedNet tmpl_only;      // template alone (pts_space == 'temp')
+    avc::PackedNet recon;
+    bool warp_set = false, tmpl_set = false;
+    // staged host-side effective weights until both halves of the avatar net have arrived
+    struct Staged { std::vector<std::vector<double>> W; std::vector<std::vector<double>> b; std::vector<int> cout, cin; };
+    Staged warp_st, tmpl_st;
+    float *pose_feat_hwc = nullptr; int pose_C = 0, pose_H = 0, pose_W = 0;
+    float *img_feat_hwc = nullptr;  int img_C = 0, img_H = 0, img_W = 0;
+    // scratch for meshing
+    void *mc_scratch = nullptr; size_t mc_scratch_bytes = 0;
+    uint32_t *mc_tables_dev = nullptr;
+    avc::Timing timing;
+};
+
+namespace avc {
+// pack.cpp
+int pack_avatar(avc_ctx *ctx);   // builds warp_tmpl (and tmpl_only) from the staged weights
+int pack_recon(avc_ctx *ctx, const avc_dense fc[4]);
+int upload(PackedNet &net);
+void release(PackedNet &net);
+// fused_mlp.hip
+int launch_avatar(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], int occ_sigmoid,
+                  float *occ, float *offset, float *rgba, bool template_only, hipStream_t s);
+int launch_recon(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], float *out, hipStream_t s);
+int launch_nchw_to_hwc(const float *src, float *dst, int C, int H, int W, hipStream_t s);
+int launch_scatter(const uint8_t *valid, int64_t N, const float *values, const float *fill, float *vol, hipStream_t s);
+// mesh.hip
+int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float bounds[6], float iso,
+               float *verts, float *normals, int32_t *faces, int64_t cap_v, int64_t cap_f, int64_t counts[2], hipStream_t s);
+// knn_lbs.hip
+int knn(const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, hipStream_t s);
+int calculate_lbs(const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s);
+int skinning(const float *pts, const float *nrm, int64_t n, const float *lbs, const float *jm, float *po, float *no, float *mo, hipStream_t s);
+}  // namespace avc

@@ -1,0 +1,232 @@
+// C ABI of libavcap_hip.so (include/avcap.h): argument checking, context state, dispatch.
+#include <cstring>
+
+#include "avcap_internal.h"
+
+namespace avc {
+const char *last_error();
+int effective(const avc_dense &d, const avc_bn *bn, std::vector<double> &W, std::vector<double> &b);
+}  // namespace avc
+
+using namespace avc;
+
+extern "C" {
+
+const char *avc_last_error(void) { return avc::last_error(); }
+int avc_version(void) { return 100; }
+
+int avc_ctx_create(int device, avc_ctx **ctx_out)
+{
+    AVC_REQUIRE(ctx_out, AVC_ERR_ARG, "avc_ctx_create: ctx_out is NULL");
+    int count = 0;
+    AVC_HIP(hipGetDeviceCount(&count));
+    AVC_REQUIRE(device >= 0 && device < count, AVC_ERR_ARG, "avc_ctx_create: device %d out of range (%d visible)", device, count);
+    AVC_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    AVC_HIP(hipGetDeviceProperties(&prop, device));
+    AVC_REQUIRE(std::strncmp(prop.gcnArchName, "gfx950", 6) == 0, AVC_ERR_STATE,
+                "avc_ctx_create: this library is built for gfx950 (MI355X) only, device %d is %s", device, prop.gcnArchName);
+    avc_ctx *c = new avc_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    *ctx_out = c;
+    return AVC_OK;
+}
+
+int avc_ctx_destroy(avc_ctx *ctx)
+{
+    if (!ctx) return AVC_OK;
+    hipSetDevice(ctx->device);
+    release(ctx->warp_tmpl); release(ctx->tmpl_only); release(ctx->recon);
+    if (ctx->pose_feat_hwc) hipFree(ctx->pose_feat_hwc);
+    if (ctx->img_feat_hwc) hipFree(ctx->img_feat_hwc);
+    if (ctx->mc_scratch) hipFree(ctx->mc_scratch);
+    if (ctx->mc_tables_dev) hipFree(ctx->mc_tables_dev);
+    for (int w = 0; w < 2; ++w)
+        for (auto &pr : ctx->timing.pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    delete ctx;
+    return AVC_OK;
+}
+
+static int check_shape(const avc_dense &d, int cout, int cin, const char *what, int i)
+{
+    AVC_REQUIRE(d.cout == cout && d.cin == cin, AVC_ERR_ARG, "%s[%d]: expected weight (%d,%d), got (%d,%d)", what, i, cout, cin, d.cout, d.cin);
+    return AVC_OK;
+}
+
+int avc_pack_warp_weights(avc_ctx *ctx, const avc_dense conv[7], const avc_bn bn[7], const avc_dense *out_affine, int pos_encoding)
+{
+    AVC_REQUIRE(ctx && conv && bn && out_affine, AVC_ERR_ARG, "avc_pack_warp_weights: NULL argument");
+    AVC_REQUIRE(pos_encoding == 0, AVC_ERR_ARG, "avc_pack_warp_weights: only model.warping_field.pos_encoding == 0 is supported (got %d)", pos_encoding);
+    AVC_HIP(hipSetDevice(ctx->device));
+    auto &st = ctx->warp_st;
+    st.W.assign(8, {}); st.b.assign(8, {});
+    for (int i = 0; i < 7; ++i) {
+        const int cin = i == 0 ? 67 : (i == 4 ? 323 : 256);
+        int rc = check_shape(conv[i], 256, cin, "warp conv", i + 1);
+        if (rc) return rc;
+        AVC_REQUIRE(bn[i].gamma && bn[i].beta && bn[i].mean && bn[i].var, AVC_ERR_ARG, "warp bn%d: NULL pointer", i + 1);
+        rc = effective(conv[i], &bn[i], st.W[i], st.b[i]);
+        if (rc) return rc;
+    }
+    int rc = check_shape(*out_affine, 3, 256, "out_layer_coord_affine", 0);
+    if (rc) return rc;
+    rc = effective(*out_affine, nullptr, st.W[7], st.b[7]);
+    if (rc) return rc;
+    ctx->warp_set = true;
+    return pack_avatar(ctx);
+}
+
+int avc_pack_template_weights(avc_ctx *ctx, const avc_dense shared[7], const avc_dense geo[2], const avc_dense *clr, int pos_encoding)
+{
+    AVC_REQUIRE(ctx && shared && geo, AVC_ERR_ARG, "avc_pack_template_weights: NULL argument");
+    AVC_REQUIRE(pos_encoding == 10, AVC_ERR_ARG, "avc_pack_template_weights: only model.cano_template.pos_encoding == 10 is supported (got %d)", pos_encoding);
+    AVC_HIP(hipSetDevice(ctx->device));
+    auto &st = ctx->tmpl_st;
+    const int n = clr ? 12 : 9;
+    st.W.assign(n, {}); st.b.assign(n, {});
+    for (int i = 0; i < 7; ++i) {
+        const int cin = i == 0 ? 63 : (i == 4 ? 319 : 256);
+        int rc = check_shape(shared[i], 256, cin, "shared_mlp", i);
+        if (rc) return rc;
+        rc = effective(shared[i], nullptr, st.W[i], st.b[i]);
+        if (rc) return rc;
+    }
+    static const int gco[2] = {128, 2}, gci[2] = {256, 128}, cco[3] = {256, 128, 3}, cci[3] = {256, 256, 128};
+    for (int i = 0; i < 2; ++i) {
+        int rc = check_shape(geo[i], gco[i], gci[i], "geo_mlp", i);
+        if (rc) return rc;
+        rc = effective(geo[i], nullptr, st.W[7 + i], st.b[7 + i]);
+        if (rc) return rc;
+    }
+    if (clr)
+        for (int i = 0; i < 3; ++i) {
+            int rc = check_shape(clr[i], cco[i], cci[i], "clr_mlp", i);
+            if (rc) return rc;
+            rc = effective(clr[i], nullptr, st.W[9 + i], st.b[9 + i]);
+            if (rc) return rc;
+        }
+    ctx->tmpl_set = true;
+    return pack_avatar(ctx);
+}
+
+int avc_pack_recon_weights(avc_ctx *ctx, const avc_dense fc[4])
+{
+    AVC_REQUIRE(ctx && fc, AVC_ERR_ARG, "avc_pack_recon_weights: NULL argument");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return pack_recon(ctx, fc);
+}
+
+static int set_map(avc_ctx *ctx, float **slot, int *sc, int *sh, int *sw, const float *map, int C, int H, int W, int wantC, hipStream_t s)
+{
+    AVC_REQUIRE(ctx && map, AVC_ERR_ARG, "set feature map: NULL argument");
+    AVC_REQUIRE(C == wantC && H > 1 && W > 1, AVC_ERR_ARG, "set feature map: expected (%d,H,W) with H,W > 1, got (%d,%d,%d)", wantC, C, H, W);
+    AVC_HIP(hipSetDevice(ctx->device));
+    if (!*slot || *sc != C || *sh != H || *sw != W) {
+        if (*slot) AVC_HIP(hipFree(*slot));
+        *slot = nullptr;
+        AVC_HIP(hipMalloc((void **)slot, sizeof(float) * (size_t)C * H * W));
+        *sc = C; *sh = H; *sw = W;
+    }
+    return launch_nchw_to_hwc(map, *slot, C, H, W, s);
+}
+
+int avc_set_pose_feat_map(avc_ctx *ctx, const float *map, int C, int H, int W, avc_stream stream)
+{
+    return set_map(ctx, ctx ? &ctx->pose_feat_hwc : nullptr, &ctx->pose_C, &ctx->pose_H, &ctx->pose_W, map, C, H, W, 64, (hipStream_t)stream);
+}
+int avc_set_img_feat_map(avc_ctx *ctx, const float *map, int C, int H, int W, avc_stream stream)
+{
+    return set_map(ctx, ctx ? &ctx->img_feat_hwc : nullptr, &ctx->img_C, &ctx->img_H, &ctx->img_W, map, C, H, W, 32, (hipStream_t)stream);
+}
+
+int avc_avatar_query(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], int occupancy_sigmoid,
+                     float *occ, float *offset, float *rgba, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && center && n >= 0 && (n == 0 || (pts && occ)), AVC_ERR_ARG, "avc_avatar_query: NULL argument or negative n");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return launch_avatar(ctx, pts, n, center, occupancy_sigmoid, occ, offset, rgba, false, (hipStream_t)stream);
+}
+
+int avc_template_query(avc_ctx *ctx, const float *pts, int64_t n, int occupancy_sigmoid, float *occ, float *rgba, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && n >= 0 && (n == 0 || (pts && occ)), AVC_ERR_ARG, "avc_template_query: NULL argument or negative n");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return launch_avatar(ctx, pts, n, nullptr, occupancy_sigmoid, occ, nullptr, rgba, true, (hipStream_t)stream);
+}
+
+int avc_recon_query(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], float *out, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && center && n >= 0 && (n == 0 || (pts && out)), AVC_ERR_ARG, "avc_recon_query: NULL argument or negative n");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return launch_recon(ctx, pts, n, center, out, (hipStream_t)stream);
+}
+
+int avc_scatter_volume(avc_ctx *ctx, const uint8_t *valid, int64_t N, const float *values, const float *fill, float *vol, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && valid && vol && N > 0, AVC_ERR_ARG, "avc_scatter_volume: NULL argument or N <= 0");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return launch_scatter(valid, N, values, fill, vol, (hipStream_t)stream);
+}
+
+int avc_recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float bounds[6], float iso,
+                   float *verts, float *normals, int32_t *faces, int64_t cap_v, int64_t cap_f, int64_t counts[2], avc_stream stream)
+{
+    AVC_REQUIRE(ctx && vol && res && bounds && counts, AVC_ERR_ARG, "avc_recon_mesh: NULL argument");
+    AVC_REQUIRE(res[0] >= 2 && res[1] >= 2 && res[2] >= 2, AVC_ERR_ARG, "avc_recon_mesh: every resolution must be >= 2");
+    AVC_REQUIRE((int64_t)res[0] * res[1] * res[2] < (int64_t)1 << 31, AVC_ERR_ARG, "avc_recon_mesh: volume too large for 32-bit voxel indices");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return recon_mesh(ctx, vol, res, bounds, iso, verts, normals, faces, cap_v, cap_f, counts, (hipStream_t)stream);
+}
+
+int avc_knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && nq >= 0 && nr > 0 && (nq == 0 || (q && ref)), AVC_ERR_ARG, "avc_knn: NULL argument");
+    AVC_REQUIRE(K >= 1 && K <= 8 && K <= nr, AVC_ERR_ARG, "avc_knn: K must be in [1, min(8, nr)], got %d", K);
+    AVC_HIP(hipSetDevice(ctx->device));
+    return knn(q, nq, ref, nr, K, d2, idx, (hipStream_t)stream);
+}
+
+int avc_calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && n >= 0 && (n == 0 || (pts && lbs)), AVC_ERR_ARG, "avc_calculate_lbs: NULL argument");
+    AVC_REQUIRE(cano_v && skin_w && nv >= 4, AVC_ERR_STATE, "Canonical smpl vertices are invalid!");   // smpl_util.py:31
+    AVC_HIP(hipSetDevice(ctx->device));
+    return calculate_lbs(pts, n, cano_v, skin_w, nv, lbs, (hipStream_t)stream);
+}
+
+int avc_skinning(avc_ctx *ctx, const float *pts, const float *nrm, int64_t n, const float *lbs, const float *jm,
+                 float *po, float *no, float *mo, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && n >= 0 && lbs && jm && (pts || nrm), AVC_ERR_ARG, "avc_skinning: NULL argument");
+    AVC_REQUIRE((!pts || po) && (!nrm || no), AVC_ERR_ARG, "avc_skinning: output missing for a given input");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return skinning(pts, nrm, n, lbs, jm, po, no, mo, (hipStream_t)stream);
+}
+
+int avc_timing_enable(avc_ctx *ctx, int enable)
+{
+    AVC_REQUIRE(ctx, AVC_ERR_ARG, "avc_timing_enable: NULL ctx");
+    ctx->timing.enabled = enable != 0;
+    return AVC_OK;
+}
+
+int avc_timing_read(avc_ctx *ctx, int which, double *avg_ms, int64_t *launches, int reset)
+{
+    AVC_REQUIRE(ctx && (which == 0 || which == 1) && avg_ms && launches, AVC_ERR_ARG, "avc_timing_read: bad argument");
+    auto &t = ctx->timing;
+    for (auto &pr : t.pending[which]) {
+        AVC_HIP(hipEventSynchronize(pr.second));
+        float ms = 0;
+        AVC_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        t.total_ms[which] += ms; t.launches[which] += 1;
+        hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+    }
+    t.pending[which].clear();
+    *launches = t.launches[which];
+    *avg_ms = t.launches[which] ? t.total_ms[which] / t.launches[which] : 0.0;
+    if (reset) { t.total_ms[which] = 0; t.launches[which] = 0; }
+    return AVC_OK;
+}
+
+}  // extern "C"

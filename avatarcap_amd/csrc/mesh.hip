@@ -1,0 +1,442 @@
+// Device-resident replacement of utils/recon_util.py:51-70 (recon_mesh):
+//   marching cubes (the reference's skimage call, :64)  +  vertex offset/scale (:62,65)
+//   + Sobel-gradient normals sampled trilinearly at the vertices (:9-48, :66-68) + face flip (:69)
+// with the occupancy volume never leaving HBM (the reference copies it to the host, runs
+// single-thread Cython, and copies the vertices back).
+//
+// Algorithm = oracle/mc_oracle.c (PARITY UNPINNED against scikit-image):
+//   pass A  count   : per 1024-voxel tile, #owned cut edges (vertices) and #triangles   -> tile sums
+//   scan            : exclusive scan of the tile sums (one workgroup)
+//   pass B  vertices: recount, in-tile scan, emit position + normal; record the first vertex id
+//                     of every voxel that owns one (sparse writes into a 4 B / voxel array)
+//   pass C  faces   : recount, in-tile scan, emit triangles; a triangle corner on cube edge e is
+//                     vertex  first_id[owner voxel] + rank of e's axis among the owner's cut edges
+// Output order is canonical and deterministic: vertices by (voxel index, axis), faces by cell index.
+// HBM-bound: the volume is read once per pass (3 x 4 B/voxel; passes B/C mostly hit the 256 MiB
+// Infinity Cache at 256^3) plus 24 B/vertex + 12 B/face of output.  Case tables live in LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "avcap_internal.h"
+#include "mc_tables.h"
+
+namespace avc {
+namespace {
+
+constexpr int TILE = 1024;          // voxels per tile: 256 threads x 4 consecutive voxels
+constexpr int TABLE_WORDS = 512 + mc::N_ROWS * 4;
+
+struct McArgs {
+    const float *vol;
+    int X, Y, Z;
+    int64_t N;
+    float iso;
+    int ntiles;
+    const uint32_t *tables;         // CFG_INFO then ROWS, device copy
+};
+
+__device__ __forceinline__ void load_tables(const uint32_t *__restrict__ g, uint32_t *lds)
+{
+    for (int i = threadIdx.x; i < TABLE_WORDS; i += blockDim.x) lds[i] = g[i];
+    __syncthreads();
+}
+
+// cube-edge e -> owner voxel offset (dx,dy,dz) and axis
+__device__ __forceinline__ void edge_owner(int e, int &dx, int &dy, int &dz, int &axis)
+{
+    axis = e >> 2;
+    const int j = e & 3;
+    if (axis == 0) { dx = 0; dy = j & 1; dz = j >> 1; }
+    else if (axis == 1) { dx = j & 1; dy = 0; dz = j >> 1; }
+    else { dx = j & 1; dy = j >> 1; dz = 0; }
+}
+
+struct Voxel {
+    int x, y, z;
+    float v0;              // vol - iso at the voxel
+    float v[3];            // vol - iso at the +x, +y, +z neighbours (0 when absent)
+    unsigned cut;          // bit a: the edge towards +axis a exists and changes sign
+    int nv;
+};
+
+__device__ __forceinline__ Voxel load_voxel(const McArgs &a, int64_t li)
+{
+    Voxel q;
+    const int yz = a.Y * a.Z;
+    q.x = (int)(li / yz);
+    const int r = (int)(li - (int64_t)q.x * yz);
+    q.y = r / a.Z;
+    q.z = r - q.y * a.Z;
+    q.v0 = a.vol[li] - a.iso;
+    const bool s0 = q.v0 > 0.0f;
+    q.cut = 0;
+    q.v[0] = q.v[1] = q.v[2] = 0.0f;
+    if (q.x + 1 < a.X) { q.v[0] = a.vol[li + yz] - a.iso; if ((q.v[0] > 0.0f) != s0) q.cut |= 1u; }
+    if (q.y + 1 < a.Y) { q.v[1] = a.vol[li + a.Z] - a.iso; if ((q.v[1] > 0.0f) != s0) q.cut |= 2u; }
+    if (q.z + 1 < a.Z) { q.v[2] = a.vol[li + 1] - a.iso; if ((q.v[2] > 0.0f) != s0) q.cut |= 4u; }
+    q.nv = __popc(q.cut);
+    return q;
+}
+
+// table row of the cell whose min corner is voxel q (caller guarantees the cell exists); returns
+// the row index or -1 when the cell is not crossed.  val[] receives the 8 corner values - iso.
+__device__ __forceinline__ int cell_row(const McArgs &a, const Voxel &q, int64_t li, const uint32_t *lds, float val[8])
+{
+    const int yz = a.Y * a.Z;
+    val[0] = q.v0; val[1] = q.v[0]; val[2] = q.v[1]; val[4] = q.v[2];
+    val[3] = a.vol[li + yz + a.Z] - a.iso;
+    val[5] = a.vol[li + yz + 1] - a.iso;
+    val[6] = a.vol[li + a.Z + 1] - a.iso;
+    val[7] = a.vol[li + yz + a.Z + 1] - a.iso;
+    unsigned cfg = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cfg |= (val[c] > 0.0f ? 1u : 0u) << c;
+    if (cfg == 0u || cfg == 255u) return -1;
+    const uint32_t i0 = lds[2 * cfg], faces = lds[2 * cfg + 1];
+    const int namb = (i0 >> 16) & 7;
+    unsigned variant = 0;
+    for (int i = 0; i < namb; ++i) {
+        const int f = (faces >> (3 * i)) & 7;
+        // face corners counter-clockwise seen from outside (oracle/mc_oracle.c FACE_CORNERS), packed 3 bits each
+        const unsigned FC[6] = {0 | 4 << 3 | 6 << 6 | 2 << 9, 1 | 3 << 3 | 7 << 6 | 5 << 9, 0 | 1 << 3 | 5 << 6 | 4 << 9,
+                                2 | 6 << 3 | 7 << 6 | 3 << 9, 0 | 2 << 3 | 3 << 6 | 1 << 9, 4 | 5 << 3 | 7 << 6 | 6 << 9};
+        const unsigned pc = FC[f];
+        float fv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = (pc >> (3 * k)) & 7;
+            float t = val[0];
+#pragma unroll
+            for (int cc = 1; cc < 8; ++cc) t = (c == cc) ? val[cc] : t;
+            fv[k] = t;
+        }
+        // asymptotic decider with separately rounded products (matches the oracle's -ffp-contract=off)
+        const float pp = __fmul_rn(fv[0], fv[2]), qq = __fmul_rn(fv[1], fv[3]);
+        const bool connected = (fv[0] > 0.0f) ? (pp > qq) : (qq > pp);
+        variant |= (connected ? 1u : 0u) << i;
+    }
+    return (int)(i0 & 0xffffu) + (int)variant;
+}
+
+__device__ __forceinline__ int row_ntri(const uint32_t *lds, int row) { return (int)(lds[512 + 4 * row] & 0xffu); }
+__device__ __forceinline__ int row_edge(const uint32_t *lds, int row, int k)   // k-th nibble (0..29)
+{
+    const int byte = 1 + (k >> 1);
+    const uint32_t w = lds[512 + 4 * row + (byte >> 2)];
+    return (int)((w >> (8 * (byte & 3) + 4 * (k & 1))) & 0xfu);
+}
+
+// exclusive prefix sum of one value per thread across a 256-thread block; returns the block total in `total`
+__device__ __forceinline__ unsigned block_exclusive(unsigned v, unsigned *lds4, unsigned &total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    __syncthreads();
+    if (lane == 63) lds4[w] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int k = 0; k < w; ++k) base += lds4[k];
+    total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    return base + incl - v;
+}
+
+// ---------------- pass A ----------------
+__global__ __launch_bounds__(256) void mc_count_kernel(McArgs a, unsigned *__restrict__ tile_v, unsigned *__restrict__ tile_t)
+{
+    __shared__ uint32_t tab[TABLE_WORDS];
+    __shared__ unsigned red[8];
+    load_tables(a.tables, tab);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        unsigned nv = 0, nt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
+            if (li < a.N) {
+                const Voxel q = load_voxel(a, li);
+                nv += q.nv;
+                if (q.x + 1 < a.X && q.y + 1 < a.Y && q.z + 1 < a.Z) {
+                    float val[8];
+                    const int row = cell_row(a, q, li, tab, val);
+                    if (row >= 0) nt += row_ntri(tab, row);
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { nv += __shfl_down(nv, o, 64); nt += __shfl_down(nt, o, 64); }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = nv; red[4 + (threadIdx.x >> 6)] = nt; }
+        __syncthreads();
+        if (threadIdx.x == 0) { tile_v[tile] = red[0] + red[1] + red[2] + red[3]; tile_t[tile] = red[4] + red[5] + red[6] + red[7]; }
+    }
+}
+
+// exclusive scan of two arrays (one workgroup of 1024); totals written to totals[0..1]
+__global__ void mc_scan_kernel(unsigned *__restrict__ tv, unsigned *__restrict__ tt, int n, unsigned long long *__restrict__ totals)
+{
+    __shared__ unsigned buf[2][1024];
+    __shared__ unsigned carry[2];
+    if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < n; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const unsigned v0 = i < n ? tv[i] : 0u, v1 = i < n ? tt[i] : 0u;
+        buf[0][threadIdx.x] = v0; buf[1][threadIdx.x] = v1;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const unsigned a0 = threadIdx.x >= o ? buf[0][threadIdx.x - o] : 0u;
+            const unsigned a1 = threadIdx.x >= o ? buf[1][threadIdx.x - o] : 0u;
+            __syncthreads();
+            buf[0][threadIdx.x] += a0; buf[1][threadIdx.x] += a1;
+            __syncthreads();
+        }
+        if (i < n) { tv[i] = carry[0] + buf[0][threadIdx.x] - v0; tt[i] = carry[1] + buf[1][threadIdx.x] - v1; }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry[0] += buf[0][1023]; carry[1] += buf[1][1023]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { totals[0] = carry[0]; totals[1] = carry[1]; }
+}
+
+// ---------------- pass B: vertices + normals ----------------
+struct EmitArgs {
+    float vox[3];        // voxel_size = (b1 - b0) / res            (recon_util.py:62)
+    float b0[3];         // bounds[0]
+    float len[3];        // bounds[1] - bounds[0]
+};
+
+// per-axis 4-tap weights of (trilinear sample o 1-D Sobel factor) around base index i0 - 1
+__device__ __forceinline__ void axis_weights(float pix, int n, int &ibase, float wS[4], float wD[4])
+{
+    // pix already clamped to [0, n-1] (padding_mode='border', align_corners=True)
+    const float fl = floorf(pix);
+    const int i0 = (int)fl;
+    const int i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+    const float t = pix - fl;
+    ibase = i0 - 1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { wS[m] = 0.f; wD[m] = 0.f; }
+    const int cs[2] = {i0, i1};
+    const float cw[2] = {1.0f - t, t};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int o = cs[c] - ibase;     // 1 or 2
+        // smoothing [1,2,1] and central difference [-1,0,1] centred on cs[c]; conv3d zero padding =>
+        // taps outside [0, n-1] contribute nothing (they are skipped at read time)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int d = m - o;
+            if (d == -1) { wS[m] += cw[c]; wD[m] -= cw[c]; }
+            else if (d == 0) { wS[m] += 2.0f * cw[c]; }
+            else if (d == 1) { wS[m] += cw[c]; wD[m] += cw[c]; }
+        }
+    }
+}
+
+__device__ __forceinline__ void vertex_normal(const McArgs &a, const EmitArgs &e, const float vidx[3], float nrm[3])
+{
+    // reference arithmetic, in its order (recon_util.py:65-66, F.grid_sample unnormalise)
+    const int dim[3] = {a.X, a.Y, a.Z};
+    int ib[3];
+    float wS[3][4], wD[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = vidx[c] * e.vox[c] + e.b0[c] + 0.5f * e.vox[c];
+        const float g = 2.0f * (v - e.b0[c]) / e.len[c] - 1.0f;
+        float pix = (g + 1.0f) * 0.5f * (float)(dim[c] - 1);
+        pix = fminf(fmaxf(pix, 0.0f), (float)(dim[c] - 1));
+        axis_weights(pix, dim[c], ib[c], wS[c], wD[c]);
+    }
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    const int yz = a.Y * a.Z;
+    for (int i = 0; i < 4; ++i) {
+        const int xi = ib[0] + i;
+        if (xi < 0 || xi >= a.X) continue;
+        for (int j = 0; j < 4; ++j) {
+            const int yj = ib[1] + j;
+            if (yj < 0 || yj >= a.Y) continue;
+            float sS = 0.f, sD = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int zk = ib[2] + k;
+                if (zk < 0 || zk >= a.Z) continue;
+                const float val = a.vol[(int64_t)xi * yz + yj * a.Z + zk];
+                sS += val * wS[2][k];
+                sD += val * wD[2][k];
+            }
+            gx += wD[0][i] * wS[1][j] * sS;
+            gy += wS[0][i] * wD[1][j] * sS;
+            gz += wS[0][i] * wS[1][j] * sD;
+        }
+    }
+    gx /= 32.0f * e.vox[0]; gy /= 32.0f * e.vox[1]; gz /= 32.0f * e.vox[2];     // recon_util.py:18-20
+    const float nn = sqrtf(gx * gx + gy * gy + gz * gz);                          // :45-47 (no epsilon)
+    nrm[0] = -(gx / nn); nrm[1] = -(gy / nn); nrm[2] = -(gz / nn);                // :68
+}
+
+__global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, const unsigned *__restrict__ tile_voff,
+                                                       unsigned *__restrict__ first_id, float *__restrict__ verts, float *__restrict__ normals)
+{
+    __shared__ unsigned red[4];
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        Voxel q[4];
+        unsigned nv = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
+            if (li < a.N) { q[k] = load_voxel(a, li); nv += q[k].nv; } else { q[k].nv = 0; q[k].cut = 0; }
+        }
+        unsigned total;
+        unsigned id = tile_voff[tile] + block_exclusive(nv, red, total);
+        if (total == 0) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (q[k].nv == 0) continue;
+            const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
+            first_id[li] = id;
+            const int p[3] = {q[k].x, q[k].y, q[k].z};
+            for (int ax = 0; ax < 3; ++ax) {
+                if (!(q[k].cut & (1u << ax))) continue;
+                const float t = __fdiv_rn(__fsub_rn(0.0f, q[k].v0), __fsub_rn(q[k].v[ax], q[k].v0));   // (iso - v0)/(v1 - v0)
+                float vidx[3], out[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    vidx[c] = __fadd_rn((float)p[c], c == ax ? t : 0.0f);
+                    // vertices = mc * voxel + b0 + 0.5 * voxel   (recon_util.py:64-65)
+                    out[c] = __fadd_rn(__fadd_rn(__fmul_rn(vidx[c], e.vox[c]), e.b0[c]), __fmul_rn(0.5f, e.vox[c]));
+                }
+                verts[3 * (size_t)id + 0] = out[0]; verts[3 * (size_t)id + 1] = out[1]; verts[3 * (size_t)id + 2] = out[2];
+                if (normals) {
+                    float n[3];
+                    vertex_normal(a, e, vidx, n);
+                    normals[3 * (size_t)id + 0] = n[0]; normals[3 * (size_t)id + 1] = n[1]; normals[3 * (size_t)id + 2] = n[2];
+                }
+                ++id;
+            }
+        }
+    }
+}
+
+// ---------------- pass C: faces ----------------
+__device__ __forceinline__ unsigned owner_cut_mask(const McArgs &a, int x, int y, int z)
+{
+    const int yz = a.Y * a.Z;
+    const int64_t li = (int64_t)x * yz + y * a.Z + z;
+    const bool s0 = (a.vol[li] - a.iso) > 0.0f;
+    unsigned cut = 0;
+    if (x + 1 < a.X && ((a.vol[li + yz] - a.iso) > 0.0f) != s0) cut |= 1u;
+    if (y + 1 < a.Y && ((a.vol[li + a.Z] - a.iso) > 0.0f) != s0) cut |= 2u;
+    if (z + 1 < a.Z && ((a.vol[li + 1] - a.iso) > 0.0f) != s0) cut |= 4u;
+    return cut;
+}
+
+__global__ __launch_bounds__(256) void mc_faces_kernel(McArgs a, const unsigned *__restrict__ tile_toff,
+                                                       const unsigned *__restrict__ first_id, int32_t *__restrict__ faces)
+{
+    __shared__ uint32_t tab[TABLE_WORDS];
+    __shared__ unsigned red[4];
+    load_tables(a.tables, tab);
+    const int yz = a.Y * a.Z;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int rows[4];
+        unsigned nt = 0;
+        int cx[4], cy[4], cz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rows[k] = -1;
+            const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
+            if (li < a.N) {
+                const Voxel q = load_voxel(a, li);
+                cx[k] = q.x; cy[k] = q.y; cz[k] = q.z;
+                if (q.x + 1 < a.X && q.y + 1 < a.Y && q.z + 1 < a.Z) {
+                    float val[8];
+                    rows[k] = cell_row(a, q, li, tab, val);
+                    if (rows[k] >= 0) nt += row_ntri(tab, rows[k]);
+                }
+            }
+        }
+        unsigned total;
+        unsigned fo = tile_toff[tile] + block_exclusive(nt, red, total);
+        if (total == 0) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (rows[k] < 0) continue;
+            const int n = row_ntri(tab, rows[k]);
+            // vertex id of each of the 12 cube edges, resolved lazily
+            for (int t = 0; t < n; ++t) {
+                int32_t id[3];
+                for (int c = 0; c < 3; ++c) {
+                    const int e = row_edge(tab, rows[k], 3 * t + c);
+                    int dx, dy, dz, axis;
+                    edge_owner(e, dx, dy, dz, axis);
+                    const int ox = cx[k] + dx, oy = cy[k] + dy, oz = cz[k] + dz;
+                    const unsigned cut = owner_cut_mask(a, ox, oy, oz);
+                    const unsigned rank = __popc(cut & ((1u << axis) - 1u));
+                    id[c] = (int32_t)(first_id[(int64_t)ox * yz + oy * a.Z + oz] + rank);
+                }
+                // faces = faces[:, [2, 1, 0]]   (recon_util.py:69)
+                faces[3 * (size_t)fo + 0] = id[2]; faces[3 * (size_t)fo + 1] = id[1]; faces[3 * (size_t)fo + 2] = id[0];
+                ++fo;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float bounds[6], float iso,
+               float *verts, float *normals, int32_t *faces, int64_t cap_v, int64_t cap_f, int64_t counts[2], hipStream_t s)
+{
+    McArgs a{};
+    a.vol = vol; a.X = res[0]; a.Y = res[1]; a.Z = res[2];
+    a.N = (int64_t)a.X * a.Y * a.Z; a.iso = iso;
+    a.ntiles = (int)((a.N + TILE - 1) / TILE);
+    if (!ctx->mc_tables_dev) {
+        std::vector<uint32_t> host(TABLE_WORDS);
+        for (int i = 0; i < 256; ++i) { host[2 * i] = mc::CFG_INFO[i][0]; host[2 * i + 1] = mc::CFG_INFO[i][1]; }
+        for (int r = 0; r < mc::N_ROWS; ++r) for (int w = 0; w < 4; ++w) host[512 + 4 * r + w] = mc::ROWS[r][w];
+        AVC_HIP(hipMalloc((void **)&ctx->mc_tables_dev, sizeof(uint32_t) * TABLE_WORDS));
+        AVC_HIP(hipMemcpy(ctx->mc_tables_dev, host.data(), sizeof(uint32_t) * TABLE_WORDS, hipMemcpyHostToDevice));
+    }
+    a.tables = ctx->mc_tables_dev;
+    // scratch: tile_v[ntiles], tile_t[ntiles], totals[2] (u64), first_id[N]
+    const size_t off_tt = sizeof(unsigned) * (size_t)a.ntiles;
+    const size_t off_tot = (2 * off_tt + 15) & ~(size_t)15;
+    const size_t off_first = off_tot + 16;
+    const size_t need = off_first + sizeof(unsigned) * (size_t)a.N;
+    if (need > ctx->mc_scratch_bytes) {
+        if (ctx->mc_scratch) AVC_HIP(hipFree(ctx->mc_scratch));
+        ctx->mc_scratch = nullptr; ctx->mc_scratch_bytes = 0;
+        AVC_HIP(hipMalloc(&ctx->mc_scratch, need));
+        ctx->mc_scratch_bytes = need;
+    }
+    char *base = (char *)ctx->mc_scratch;
+    unsigned *tile_v = (unsigned *)base, *tile_t = (unsigned *)(base + off_tt);
+    unsigned long long *totals = (unsigned long long *)(base + off_tot);
+    unsigned *first_id = (unsigned *)(base + off_first);
+
+    const int grid = std::min(a.ntiles, ctx->num_cus * 8);
+    hipLaunchKernelGGL(mc_count_kernel, dim3(grid), dim3(256), 0, s, a, tile_v, tile_t);
+    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, tile_v, tile_t, a.ntiles, totals);
+    unsigned long long h_tot[2];
+    AVC_HIP(hipMemcpyAsync(h_tot, totals, sizeof h_tot, hipMemcpyDeviceToHost, s));
+    AVC_HIP(hipStreamSynchronize(s));
+    counts[0] = (int64_t)h_tot[0]; counts[1] = (int64_t)h_tot[1];
+    AVC_REQUIRE(counts[0] <= cap_v && counts[1] <= cap_f, AVC_ERR_CAPACITY,
+                "avc_recon_mesh: need capacity for %lld vertices / %lld faces, got %lld / %lld",
+                (long long)counts[0], (long long)counts[1], (long long)cap_v, (long long)cap_f);
+    if (counts[0] == 0) return AVC_OK;
+    AVC_REQUIRE(verts && faces, AVC_ERR_ARG, "avc_recon_mesh: verts/faces output is NULL");
+    EmitArgs e{};
+    for (int c = 0; c < 3; ++c) {
+        e.b0[c] = bounds[c];
+        e.len[c] = bounds[3 + c] - bounds[c];
+        e.vox[c] = e.len[c] / (float)res[c];
+    }
+    hipLaunchKernelGGL(mc_verts_kernel, dim3(grid), dim3(256), 0, s, a, e, tile_v, first_id, verts, normals);
+    hipLaunchKernelGGL(mc_faces_kernel, dim3(grid), dim3(256), 0, s, a, tile_t, first_id, faces);
+    AVC_HIP(hipGetLastError());
+    return AVC_OK;
+}
+
+}  // namespace avc

@@ -1,0 +1,222 @@
+// Host-side weight packer: folds BatchNorm1d / weight_norm, splits every fp32 weight into an
+// (fp16 hi, fp16 lo) pair, permutes the K axis into the kernels' register "slot" order and lays the
+// result out as the chunk stream the fused kernels stream through LDS (see mlp_layout.h and
+// fused_mlp.hip).  Accepts exactly the tensors of the reference checkpoints.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+
+#include "avcap_internal.h"
+#include "mlp_layout.h"
+
+namespace avc {
+
+static thread_local std::string g_err;
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const char *last_error() { return g_err.c_str(); }
+
+namespace {
+
+struct Seg { int ks; std::function<int(int)> col; };   // slot -> column of W (or -1 = zero)
+
+struct Builder {
+    PackedNet &net;
+    explicit Builder(PackedNet &n) : net(n) { net.stream.clear(); net.chunks.clear(); net.bias.clear(); net.oscale.clear(); }
+
+    // W: (cout, cin) row-major effective weights, b: (cout).  tpc = tiles per chunk (accumulators
+    // live at once in the kernel), kspc = k-steps per chunk.
+    void layer(const std::vector<double> &W, const std::vector<double> &b, int cout, int cin,
+               const std::vector<Seg> &segs, int tpc, int kspc)
+    {
+        const int nt_raw = (cout + 31) / 32;
+        const int nt = ((nt_raw + tpc - 1) / tpc) * tpc;
+        double m = 0;
+        for (double w : W) m = std::fmax(m, std::fabs(w));
+        int sw = 0;
+        if (m > 0) sw = (int)std::floor(std::log2(30000.0 / m));
+        sw = sw < -24 ? -24 : (sw > 24 ? 24 : sw);
+        const double scale = std::ldexp(1.0, sw);
+        net.oscale.push_back((float)std::ldexp(1.0, -sw));
+        for (int r = 0; r < nt * 32; ++r) net.bias.push_back(r < cout ? (float)(b[r] * scale) : 0.0f);
+        for (int g = 0; g < nt / tpc; ++g)
+            for (const Seg &sg : segs)
+                for (int k0 = 0; k0 < sg.ks; k0 += kspc) {
+                    const int kn = std::min(kspc, sg.ks - k0);
+                    ChunkDesc cd{(uint32_t)net.stream.size(), (uint32_t)(kn * tpc * layout::UNIT_BYTES)};
+                    net.stream.resize(net.stream.size() + cd.bytes);
+                    _Float16 *dst = reinterpret_cast<_Float16 *>(net.stream.data() + cd.offset);
+                    for (int k = 0; k < kn; ++k)
+                        for (int tt = 0; tt < tpc; ++tt) {
+                            _Float16 *hi = dst + (size_t)(k * tpc + tt) * (layout::UNIT_BYTES / 2);
+                            _Float16 *lo = hi + 512;
+                            const int tile = g * tpc + tt;
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int row = tile * 32 + (lane & 31);
+                                    const int slot = (k0 + k) * 16 + (lane >> 5) * 8 + e;
+                                    const int c = sg.col(slot);
+                                    float w = 0.0f;
+                                    if (row < cout && c >= 0 && c < cin) w = (float)(W[(size_t)row * cin + c] * scale);
+                                    const _Float16 h = (_Float16)w;
+                                    hi[lane * 8 + e] = h;
+                                    lo[lane * 8 + e] = (_Float16)(w - (float)h);
+                                }
+                        }
+                    net.chunks.push_back(cd);
+                }
+    }
+};
+
+Seg seg_d(int ks, int col_offset = 0)
+{
+    return Seg{ks, [col_offset](int s) { return col_offset + layout::slot_channel_d(s); }};
+}
+Seg seg_in67(int col_offset = 0)
+{
+    return Seg{layout::IN67_KS, [col_offset](int s) { int c = layout::in67_column(s); return c < 0 ? -1 : col_offset + c; }};
+}
+Seg seg_pe(int col_offset = 0)
+{
+    return Seg{layout::PE_KS, [col_offset](int s) { int c = layout::pe_column(s); return c < 0 ? -1 : col_offset + c; }};
+}
+Seg seg_in33(int col_offset = 0)
+{
+    return Seg{layout::IN33_KS, [col_offset](int s) { int c = layout::in33_column(s); return c < 0 ? -1 : col_offset + c; }};
+}
+
+}  // namespace
+
+// Effective (cout x cin) double weights + bias of one Conv1d(k=1), weight_norm / BatchNorm folded.
+int effective(const avc_dense &d, const avc_bn *bn, std::vector<double> &W, std::vector<double> &b)
+{
+    AVC_REQUIRE(d.w && d.b && d.cout > 0 && d.cin > 0, AVC_ERR_ARG, "avc_dense: null pointer or non-positive shape");
+    W.assign((size_t)d.cout * d.cin, 0.0);
+    b.assign(d.cout, 0.0);
+    for (int o = 0; o < d.cout; ++o) {
+        double s = 1.0;
+        if (d.g) {   // w = g * v / ||v||  (torch weight_norm, dim 0)
+            double n2 = 0;
+            for (int i = 0; i < d.cin; ++i) n2 += (double)d.w[(size_t)o * d.cin + i] * d.w[(size_t)o * d.cin + i];
+            s = (double)d.g[o] / std::sqrt(n2);
+        }
+        double bs = 1.0, bb = 0.0;
+        if (bn) {   // y = (x - mean) / sqrt(var + eps) * gamma + beta
+            bs = (double)bn->gamma[o] / std::sqrt((double)bn->var[o] + (double)bn->eps);
+            bb = (double)bn->beta[o] - (double)bn->mean[o] * bs;
+        }
+        for (int i = 0; i < d.cin; ++i) W[(size_t)o * d.cin + i] = (double)d.w[(size_t)o * d.cin + i] * s * bs;
+        b[o] = (double)d.b[o] * bs + bb;
+    }
+    return AVC_OK;
+}
+
+void release(PackedNet &net)
+{
+    if (net.d_stream) hipFree(net.d_stream);
+    if (net.d_chunks) hipFree(net.d_chunks);
+    if (net.d_bias) hipFree(net.d_bias);
+    net.d_stream = nullptr; net.d_chunks = nullptr; net.d_bias = nullptr; net.ready = false;
+}
+
+int upload(PackedNet &net)
+{
+    release(net);
+    AVC_HIP(hipMalloc(&net.d_stream, net.stream.size()));
+    AVC_HIP(hipMalloc((void **)&net.d_chunks, net.chunks.size() * sizeof(ChunkDesc)));
+    AVC_HIP(hipMalloc((void **)&net.d_bias, net.bias.size() * sizeof(float)));
+    AVC_HIP(hipMemcpy(net.d_stream, net.stream.data(), net.stream.size(), hipMemcpyHostToDevice));
+    AVC_HIP(hipMemcpy(net.d_chunks, net.chunks.data(), net.chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
+    AVC_HIP(hipMemcpy(net.d_bias, net.bias.data(), net.bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    net.ready = true;
+    return AVC_OK;
+}
+
+// Layer order here IS the kernel's consumption order (avatar_kernel in fused_mlp.hip).
+static void add_warp(Builder &B, const avc_ctx::Staged &w)
+{
+    B.layer(w.W[0], w.b[0], 256, 67, {seg_in67()}, 2, 16);                       // conv1
+    for (int i = 1; i <= 3; ++i) B.layer(w.W[i], w.b[i], 256, 256, {seg_d(16)}, 2, 16);   // conv2..4
+    B.layer(w.W[4], w.b[4], 256, 323, {seg_d(16, 67), seg_in67()}, 2, 16);       // conv5: cat([x0, x4]) (mlp.py:106)
+    for (int i = 5; i <= 6; ++i) B.layer(w.W[i], w.b[i], 256, 256, {seg_d(16)}, 2, 16);   // conv6..7
+    B.layer(w.W[7], w.b[7], 3, 256, {seg_d(16)}, 1, 16);                         // out_layer_coord_affine
+}
+
+static void add_template(Builder &B, const avc_ctx::Staged &t, bool colour)
+{
+    B.layer(t.W[0], t.b[0], 256, 63, {seg_pe()}, 2, 16);                         // shared 0
+    for (int i = 1; i <= 3; ++i) B.layer(t.W[i], t.b[i], 256, 256, {seg_d(16)}, 2, 16);
+    B.layer(t.W[4], t.b[4], 256, 319, {seg_d(16), seg_pe(256)}, 2, 16);          // shared 4: cat([x, x0]) (mlp.py:61)
+    B.layer(t.W[5], t.b[5], 256, 256, {seg_d(16)}, 2, 16);
+    B.layer(t.W[6], t.b[6], 256, 256, {seg_d(16)}, 2, 16);                       // shared 6 (linear)
+    B.layer(t.W[7], t.b[7], 128, 256, {seg_d(16)}, 2, 16);                       // geo 0
+    B.layer(t.W[8], t.b[8], 2, 128, {seg_d(8)}, 1, 16);                          // geo 1
+    if (colour) {
+        B.layer(t.W[9], t.b[9], 256, 256, {seg_d(16)}, 2, 16);                   // clr 0
+        B.layer(t.W[10], t.b[10], 128, 256, {seg_d(16)}, 2, 16);                 // clr 1
+        B.layer(t.W[11], t.b[11], 3, 128, {seg_d(8)}, 1, 16);                    // clr 2
+    }
+}
+
+int pack_avatar(avc_ctx *ctx)
+{
+    const bool colour = ctx->tmpl_st.W.size() == 12;
+    if (ctx->tmpl_set) {
+        Builder B(ctx->tmpl_only);
+        add_template(B, ctx->tmpl_st, colour);
+        ctx->tmpl_only.has_colour = colour;
+        int rc = upload(ctx->tmpl_only);
+        if (rc) return rc;
+    }
+    if (ctx->warp_set && ctx->tmpl_set) {
+        Builder B(ctx->warp_tmpl);
+        add_warp(B, ctx->warp_st);
+        add_template(B, ctx->tmpl_st, colour);
+        ctx->warp_tmpl.has_colour = colour;
+        int rc = upload(ctx->warp_tmpl);
+        if (rc) return rc;
+    }
+    return AVC_OK;
+}
+
+int pack_recon(avc_ctx *ctx, const avc_dense fc[4])
+{
+    static const int cout[4] = {512, 256, 128, 1}, cin[4] = {33, 545, 289, 128};
+    std::vector<double> W[4], b[4];
+    for (int i = 0; i < 4; ++i) {
+        AVC_REQUIRE(fc[i].cout == cout[i] && fc[i].cin == cin[i], AVC_ERR_ARG,
+                    "recon fc[%d]: expected (%d,%d), got (%d,%d)", i, cout[i], cin[i], fc[i].cout, fc[i].cin);
+        int rc = effective(fc[i], nullptr, W[i], b[i]);
+        if (rc) return rc;
+    }
+    // Consumption order of recon_kernel (fused_mlp.hip): fc0 is evaluated in two halves of 256
+    // channels so that fc1 (545 = [x(512) | in(33)] inputs, mlp.py:61) can accumulate over each half
+    // while only 256 hidden channels are live in registers.
+    Builder B(ctx->recon);
+    auto rows = [&](const std::vector<double> &Wf, const std::vector<double> &bf, int cinf, int r0, int n,
+                    std::vector<double> &Wo, std::vector<double> &bo) {
+        Wo.assign(Wf.begin() + (size_t)r0 * cinf, Wf.begin() + (size_t)(r0 + n) * cinf);
+        bo.assign(bf.begin() + r0, bf.begin() + r0 + n);
+    };
+    std::vector<double> Wa, ba, Wb, bb, zero256(256, 0.0);
+    rows(W[0], b[0], 33, 0, 256, Wa, ba);
+    rows(W[0], b[0], 33, 256, 256, Wb, bb);
+    B.layer(Wa, ba, 256, 33, {seg_in33()}, 2, 16);                       // fc0 rows   0..255
+    B.layer(W[1], b[1], 256, 545, {seg_d(16, 0)}, 8, 4);                 // fc1 over x[0..255]   (bias here)
+    B.layer(Wb, bb, 256, 33, {seg_in33()}, 2, 16);                       // fc0 rows 256..511
+    B.layer(W[1], zero256, 256, 545, {seg_d(16, 256), seg_in33(512)}, 8, 4);   // fc1 over x[256..511] and in(33)
+    B.layer(W[2], b[2], 128, 289, {seg_d(16), seg_in33(256)}, 2, 16);    // fc2: [x(256) | in(33)]
+    B.layer(W[3], b[3], 1, 128, {seg_d(8)}, 1, 16);                      // fc3
+    return upload(ctx->recon);
+}
+
+}  // namespace avc

@@ -1,0 +1,239 @@
+"""Host-side mirror of the reference's `network/arch_avatar.py` for the test-mode hot path.
+
+Same class names, constructor defaults, state_dict keys, call signatures and return shapes
+(SURVEY.md section 8(b)); the per-point math runs in libavcap_hip.so (csrc/fused_mlp.hip).
+
+  DoubleTNet        arch_avatar.py:26-83     weights + `forward(pts)` -> (rgb, alpha, occ)
+  WarpingField      arch_avatar.py:86-140    U-Net on PyTorch-ROCm (once per frame) + `query`
+  CanoBlendWeightVolume  :143-165            trilinear 24-ch blend weights (colour path)
+  GeoTexAvatar      arch_avatar.py:168-237   container + colour-path `forward`
+  OccupancyNet      arch_avatar.py:352-381   `query(batch)` -> {'cano_pts_ov', 'nonrigid_offset'}
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import config
+from .. import _lib
+from .mlp import MLP, OffsetDecoder
+from .unets import UnetNoCond7DS
+
+
+def _mlp_entries(m: MLP):
+    out = []
+    for l, fc in enumerate(m.fc_list):
+        conv = fc[0] if isinstance(fc, nn.Sequential) else fc
+        if hasattr(conv, 'weight_g'):
+            out.append({'w': conv.weight_v, 'b': conv.bias, 'g': conv.weight_g})
+        else:
+            out.append({'w': conv.weight, 'b': conv.bias})
+    return out
+
+
+class DoubleTNet(nn.Module):
+    """Template Geo-Tex network (occupancy + NeRF colour), reference arch_avatar.py:26-83."""
+
+    def __init__(self):
+        super().__init__()
+        self.pos_encoding_freq = config.cfg['model']['cano_template'].get('pos_encoding', 10)
+        print('# Canonical Template: Positional encoding %d' % self.pos_encoding_freq)
+        in_channels = 3 + 6 * self.pos_encoding_freq            # get_embedder (net_util.py:40-55)
+        self.shared_mlp = MLP(in_channels, 256, [256] * 6, res_layers=[4], nlactv='relu')
+        self.geo_mlp = MLP(256, 2, [128], nlactv='leaky_relu')
+        self.clr_mlp = MLP(256, 3, [256, 128], nlactv='relu')
+        with torch.no_grad():                                     # init_out_weights (arch_avatar.py:17-23,60)
+            self.geo_mlp.fc_list[-1].weight.uniform_(-1e-5, 1e-5)
+            self.geo_mlp.fc_list[-1].bias.zero_()
+
+    def pack_into(self, ctx):
+        shared = _lib.DenseList(_mlp_entries(self.shared_mlp))
+        geo = _lib.DenseList(_mlp_entries(self.geo_mlp))
+        clr = _lib.DenseList(_mlp_entries(self.clr_mlp))
+        _lib.check(_lib.lib().avc_pack_template_weights(ctx, shared.arr, geo.arr, clr.arr, int(self.pos_encoding_freq)))
+
+    def forward(self, pts):
+        """pts (B,N,3) -> rgb (B,N,3), alpha (B,N,1), occ (B,N,1)   (arch_avatar.py:65-83).
+        Needs the owning GeoTexAvatar to have packed the weights (it does so lazily)."""
+        owner = getattr(self, '_owner', None)
+        if owner is None:
+            raise RuntimeError('DoubleTNet.forward: construct it inside a GeoTexAvatar')
+        return owner()._template_forward(pts)
+
+
+class WarpingField(nn.Module):
+    """Pose-dependent warping field, reference arch_avatar.py:86-140."""
+
+    def __init__(self):
+        super().__init__()
+        self.pose_feat_dim = 64
+        self.unet = UnetNoCond7DS(input_nc=6, output_nc=self.pose_feat_dim, nf=32, up_mode='upconv', use_dropout=False)
+        self.pos_encoding_freq = config.cfg['model']['warping_field'].get('pos_encoding', 0)
+        print('# Warping Field: positional encoding %d' % self.pos_encoding_freq)
+        in_channels = 3 + 6 * self.pos_encoding_freq + self.pose_feat_dim
+        self.mlp = OffsetDecoder(in_channels)
+        self.out_layer_coord_affine = nn.Conv1d(256, 3, 1)
+        with torch.no_grad():                                     # init_out_weights (arch_avatar.py:104-105)
+            self.out_layer_coord_affine.weight.uniform_(-1e-5, 1e-5)
+            self.out_layer_coord_affine.bias.zero_()
+        self.pose_feat_map = None
+        self._map_on_device = None      # (data_ptr, batch index) of the map the context currently holds
+
+    def pack_into(self, ctx):
+        convs = _lib.DenseList([{'w': getattr(self.mlp, f'conv{i}').weight, 'b': getattr(self.mlp, f'conv{i}').bias} for i in range(1, 8)])
+        bns = _lib.BnList([{'gamma': getattr(self.mlp, f'bn{i}').weight, 'beta': getattr(self.mlp, f'bn{i}').bias,
+                            'mean': getattr(self.mlp, f'bn{i}').running_mean, 'var': getattr(self.mlp, f'bn{i}').running_var,
+                            'eps': getattr(self.mlp, f'bn{i}').eps} for i in range(1, 8)])
+        out = _lib.DenseList([{'w': self.out_layer_coord_affine.weight, 'b': self.out_layer_coord_affine.bias}])
+        _lib.check(_lib.lib().avc_pack_warp_weights(ctx, convs.arr, bns.arr, out.arr, int(self.pos_encoding_freq)))
+
+    def precompute_conv(self, batch):
+        """self.pose_feat_map = unet(smpl_pos_map)  (arch_avatar.py:109-111); MIOpen, once per frame."""
+        self.pose_feat_map = self.unet(batch['smpl_pos_map']).contiguous()
+        self._map_on_device = None
+
+    def bind_map(self, ctx, b):
+        if self.pose_feat_map is None:
+            raise AttributeError('pose_feat_map is None: call WarpingField.precompute_conv(batch) first')
+        key = (self.pose_feat_map.data_ptr(), b)
+        if self._map_on_device != key:
+            m = self.pose_feat_map[b]
+            _lib.check(_lib.lib().avc_set_pose_feat_map(ctx, _lib.dev_ptr(m, name='pose_feat_map'), m.shape[0], m.shape[1], m.shape[2],
+                                                        _lib.stream_ptr(m.device)))
+            self._map_on_device = key
+
+    def query(self, pts, batch):
+        """pts (B,N,3) -> offsets (B,N,3)  (arch_avatar.py:113-140)."""
+        owner = getattr(self, '_owner', None)
+        if owner is None:
+            raise RuntimeError('WarpingField.query: construct it inside a GeoTexAvatar')
+        return owner()._avatar_query(pts, batch, want_offset=True, want_rgba=False)[1]
+
+
+class CanoBlendWeightVolume:
+    """Trilinear fetch of the 24-channel canonical blend-weight volume (arch_avatar.py:143-165)."""
+
+    def __init__(self, base_weight_volume_path=None, base_weight_volume=None):
+        if base_weight_volume is None:
+            base_weight_volume = np.load(base_weight_volume_path)          # (X,Y,Z,24) (arch_avatar.py:145)
+        v = np.ascontiguousarray(np.asarray(base_weight_volume, np.float32).transpose((3, 0, 1, 2))[None])
+        self.base_weight_volume = torch.from_numpy(v).to(torch.float32).to(config.device)
+
+    def forward(self, pts):
+        """pts (B,N,3) scaled to [0,1] -> (B,N,24)."""
+        B, N, _ = pts.shape
+        grid = (2 * pts - 1).reshape(-1, 3)[:, [2, 1, 0]][None, :, None, None]
+        w = F.grid_sample(self.base_weight_volume, grid, padding_mode='border', align_corners=True)
+        return w[0, :, :, 0, 0].reshape(-1, B, N).permute((1, 2, 0))
+
+
+class GeoTexAvatar(nn.Module):
+    def __init__(self, base_weight_volume=None):
+        super().__init__()
+        import weakref
+        self.cano_template = DoubleTNet()
+        if base_weight_volume is not None:
+            self.cano_weight_volume = CanoBlendWeightVolume(base_weight_volume=base_weight_volume)
+        else:
+            tdir = (config.cfg.get('training') or {}).get('training_data_dir')
+            # the reference loads this file unconditionally, even in test mode (arch_avatar.py:174)
+            self.cano_weight_volume = CanoBlendWeightVolume(str(tdir) + '/cano_base_blend_weight_volume.npy')
+        self.warping_field = WarpingField()
+        ref = weakref.ref(self)
+        object.__setattr__(self.cano_template, '_owner', ref)
+        object.__setattr__(self.warping_field, '_owner', ref)
+        self._packed_version = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, '_packed_version', None))
+
+    # ---- packing (BatchNorm folded from running stats => eval-mode semantics, as in main.py:297) ----
+    def _weights_version(self):
+        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+
+    def _ctx(self, device):
+        ctx = _lib.ctx(device)
+        ver = (ctx, self._weights_version())
+        if self._packed_version != ver:
+            self.warping_field.pack_into(ctx)
+            self.cano_template.pack_into(ctx)
+            self._packed_version = ver
+        return ctx
+
+    def _avatar_query(self, pts, batch, want_offset=True, want_rgba=False):
+        B, N, _ = pts.shape
+        pts = pts.contiguous()
+        ctx = self._ctx(pts.device)
+        occ = torch.empty((B, N, 1), dtype=torch.float32, device=pts.device)
+        off = torch.empty((B, N, 3), dtype=torch.float32, device=pts.device) if want_offset else None
+        rgba = torch.empty((B, N, 4), dtype=torch.float32, device=pts.device) if want_rgba else None
+        sig = 1 if config.if_type == 'occupancy' else 0
+        if config.if_type not in ('sdf', 'occupancy'):
+            raise ValueError('Invalid config.if_type!')                   # arch_avatar.py:81-82
+        for b in range(B):
+            self.warping_field.bind_map(ctx, b if self.warping_field.pose_feat_map.shape[0] > 1 else 0)
+            _lib.check(_lib.lib().avc_avatar_query(
+                ctx, _lib.dev_ptr(pts[b], name='cano_pts'), N, _lib.f3(batch['cano_smpl_center'][b]), sig,
+                occ[b].data_ptr(), off[b].data_ptr() if want_offset else None, rgba[b].data_ptr() if want_rgba else None,
+                _lib.stream_ptr(pts.device)))
+        return occ, off, rgba
+
+    def _template_forward(self, pts):
+        B, N, _ = pts.shape
+        pts = pts.contiguous()
+        ctx = self._ctx(pts.device)
+        occ = torch.empty((B, N, 1), dtype=torch.float32, device=pts.device)
+        rgba = torch.empty((B, N, 4), dtype=torch.float32, device=pts.device)
+        sig = 1 if config.if_type == 'occupancy' else 0
+        _lib.check(_lib.lib().avc_template_query(ctx, _lib.dev_ptr(pts.view(-1, 3), name='pts'), B * N, sig,
+                                                 occ.data_ptr(), rgba.data_ptr(), _lib.stream_ptr(pts.device)))
+        return rgba[..., :3], rgba[..., 3:], occ
+
+    def forward(self, wpts, viewdirs, dists, batch, pts_space='posed'):
+        """Colour / NeRF path (arch_avatar.py:178-237): returns {'raw' (B,N,4), 'occ', 'nonrigid_offset'}."""
+        from ..utils.smpl_util import smpl_util
+        assert pts_space in ('posed', 'cano', 'temp')
+        B, N = wpts.shape[:2]
+        if pts_space == 'posed':                                           # inverse skinning (:189-205)
+            d2, idx = smpl_util.knn_points(wpts, batch['live_smpl_v'], K=1)
+            near_flag = d2[:, :, 0] < 0.08 * 0.08
+            with torch.no_grad():
+                w = smpl_util.smpl_skinning_weights[idx[:, :, 0]]
+                live2cano = torch.linalg.inv(batch['cano2live_jnt_mats'])
+                cano_ = smpl_util.skinning(wpts, w, live2cano)
+                lo, hi = batch['cano_bounds'][:, 0], batch['cano_bounds'][:, 1]
+                cano_ = (cano_ - lo[:, None]) / (hi - lo)[:, None]
+            w = self.cano_weight_volume.forward(cano_)
+            cano_pts = smpl_util.skinning(wpts, w.contiguous(), live2cano)
+        else:
+            cano_pts = wpts
+            d2, _ = smpl_util.knn_points(wpts, smpl_util.cano_smpl_vertices[None].expand(B, -1, -1), K=1)
+            near_flag = d2[:, :, 0] < 0.08 * 0.08                          # :208-209
+        if pts_space in ('posed', 'cano'):
+            occ, offsets, rgba = self._avatar_query(cano_pts, batch, want_offset=True, want_rgba=True)
+            cano_pts = cano_pts + offsets                                  # :213
+        else:
+            rgb, alpha, occ = self._template_forward(cano_pts)
+            rgba = torch.cat([rgb, alpha], -1)
+            offsets = torch.zeros_like(cano_pts)
+        rgb, alpha = rgba[..., :3], rgba[..., 3:].clone()
+        inside = (cano_pts > batch['cano_bounds'][:, :1]) & (cano_pts < batch['cano_bounds'][:, 1:])   # :222-224
+        alpha[inside.sum(2) != 3] = 0
+        alpha[~near_flag] = 0
+        alpha = 1. - torch.exp(-alpha * dists)                             # :228-230
+        return {'raw': torch.cat([rgb, alpha], -1), 'occ': occ, 'nonrigid_offset': offsets}
+
+
+class OccupancyNet:
+    """Chunk-free grid query (arch_avatar.py:352-381)."""
+
+    def __init__(self, net: GeoTexAvatar):
+        self.net = net
+
+    def query(self, batch):
+        """batch['cano_pts'] (B,N,3), ['cano_smpl_center'] (B,3); warping_field.precompute_conv(batch)
+        must have run.  -> {'cano_pts_ov': (B,N,1), 'nonrigid_offset': (B,N,3)}"""
+        occ, off, _ = self.net._avatar_query(batch['cano_pts'], batch, want_offset=True, want_rgba=False)
+        return {'cano_pts_ov': occ, 'nonrigid_offset': off}

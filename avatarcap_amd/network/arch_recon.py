@@ -1,0 +1,61 @@
+"""Host-side mirror of the reference's `network/arch_recon.py` (ReconNetwork, :9-76).
+
+`image_encoder` (HGFilter) runs once per frame on PyTorch-ROCm / MIOpen; the per-point decoder
+(bilinear 32-channel sample + z + weight-normed LeakyReLU MLP + sigmoid) runs in recon_kernel
+(csrc/fused_mlp.hip).  state_dict keys match recon_net.pt.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from . import HGFilters as hg
+from .mlp import MLP
+from .arch_avatar import _mlp_entries
+
+
+class ReconNetwork(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.image_encoder = hg.HGFilter(1, 4, 6, 32, 'group', 'no_down', False)
+        self.image_decoder = MLP(in_channels=33, out_channels=1, inter_channels=[512, 256, 128], res_layers=[1, 2],
+                                 nlactv='leaky_relu', norm='weight', last_op='sigmoid')
+        self._packed_version = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, '_packed_version', None))
+
+    def get_feat_maps(self, image):
+        feat_maps, _ = self.image_encoder(image)
+        return feat_maps
+
+    def _ctx(self, device):
+        ctx = _lib.ctx(device)
+        ver = (ctx, tuple(p._version for p in self.image_decoder.parameters()))
+        if self._packed_version != ver:
+            fc = _lib.DenseList(_mlp_entries(self.image_decoder))
+            _lib.check(_lib.lib().avc_pack_recon_weights(ctx, fc.arr))
+            self._packed_version = ver
+        return ctx
+
+    def infer(self, items):
+        """items['cano_pts'] (1,N,3), ['cano_smpl_center'] (1,3), ['front_normal'], ['back_normal'] (1,3,512,512)
+        -> (1,N) occupancy in [0,1]   (arch_recon.py:45-76)."""
+        with torch.no_grad():
+            pts = items['cano_pts'].contiguous()
+            B, N, _ = pts.shape
+            imgs = torch.cat([items['front_normal'], items['back_normal']], dim=1)
+            img_feat_map = self.get_feat_maps(imgs)[-1].contiguous()
+            return self.decode(pts, img_feat_map, items['cano_smpl_center'])
+
+    def decode(self, pts, img_feat_map, center):
+        """The per-point loop of infer (arch_recon.py:55-73) for a given feature map."""
+        B, N, _ = pts.shape
+        ctx = self._ctx(pts.device)
+        out = torch.empty((B, N), dtype=torch.float32, device=pts.device)
+        for b in range(B):
+            m = img_feat_map[b]
+            _lib.check(_lib.lib().avc_set_img_feat_map(ctx, _lib.dev_ptr(m, name='img_feat_map'), m.shape[0], m.shape[1], m.shape[2],
+                                                       _lib.stream_ptr(pts.device)))
+            _lib.check(_lib.lib().avc_recon_query(ctx, _lib.dev_ptr(pts[b], name='cano_pts'), N, _lib.f3(center[b]),
+                                                  out[b].data_ptr(), _lib.stream_ptr(pts.device)))
+        return out.squeeze(0) if B == 1 else out

@@ -1,0 +1,150 @@
+/* avcap.h -- C ABI of libavcap_hip.so, the MI355X (gfx950) hot path of AvatarCap's per-frame
+ * volumetric reconstruction.
+ *
+ * The reference (lizhe00/AvatarCap) is pure Python; it has no FFI.  Its seam for this path is a
+ * handful of Python call signatures.  Each entry point below names the
+ * reference interface it replaces (file:line under /root/reference); INTEGRATION.md shows the
+ * ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  `*_dev` pointers are device (HBM) pointers
+ *     the caller owns (e.g. tensor.data_ptr()); all other pointers are host memory.
+ *   - every call returns 0 on success, a negative avc_status otherwise; avc_last_error() returns a
+ *     thread-local description of the last failure.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls are asynchronous w.r.t. the host
+ *     unless stated otherwise.  No ownership is transferred.  One context per device; a context
+ *     is thread-compatible (use it from one thread at a time).
+ *   - all arithmetic is float32 in / float32 out; indices are int32 (faces) / int64 (KNN).
+ */
+#ifndef AVCAP_H
+#define AVCAP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct avc_ctx avc_ctx;
+typedef void *avc_stream; /* hipStream_t */
+
+enum avc_status {
+    AVC_OK = 0,
+    AVC_ERR_ARG = -1,      /* invalid argument (the reference would raise ValueError/TypeError) */
+    AVC_ERR_STATE = -2,    /* weights / feature map not set (reference: AttributeError / ValueError) */
+    AVC_ERR_HIP = -3,      /* a HIP runtime call failed */
+    AVC_ERR_CAPACITY = -4  /* caller-provided output capacity too small; required sizes are reported */
+};
+
+const char *avc_last_error(void);
+int avc_version(void);
+
+int avc_ctx_create(int device, avc_ctx **ctx_out);
+int avc_ctx_destroy(avc_ctx *ctx);
+
+/* ---- weights -------------------------------------------------------------------------------
+ * A Conv1d(k=1) layer exactly as the reference stores it in net.pt / recon_net.pt:
+ * w is (cout, cin) row-major (state_dict `...weight` squeezed); b is (cout).  When g != NULL the
+ * layer is weight-normed: w holds `weight_v`, g holds `weight_g` (cout) and the effective weight
+ * is g * v / ||v||_2 per output channel (network/mlp.py:24,36).  Host pointers; copied. */
+typedef struct { const float *w, *b, *g; int32_t cout, cin; } avc_dense;
+/* BatchNorm1d in eval mode (running statistics), network/mlp.py:88-96 */
+typedef struct { const float *gamma, *beta, *mean, *var; float eps; } avc_bn;
+
+/* WarpingField.mlp (OffsetDecoder conv1..7 + bn1..7) and out_layer_coord_affine
+ * (network/arch_avatar.py:100-105; network/mlp.py:75-112).  BatchNorm is folded at pack time.
+ * pos_encoding is cfg['model']['warping_field']['pos_encoding'] (only 0 is supported: that is
+ * the value configs/example.yaml ships and the only one the 67-wide checkpoints fit). */
+int avc_pack_warp_weights(avc_ctx *ctx, const avc_dense conv[7], const avc_bn bn[7],
+                          const avc_dense *out_affine, int pos_encoding);
+
+/* DoubleTNet shared_mlp (7 layers, res @4), geo_mlp (2), clr_mlp (3, may be NULL)
+ * (network/arch_avatar.py:37-58).  pos_encoding must be 10 (63-wide checkpoints). */
+int avc_pack_template_weights(avc_ctx *ctx, const avc_dense shared[7], const avc_dense geo[2],
+                              const avc_dense *clr /* [3] or NULL */, int pos_encoding);
+
+/* ReconNetwork.image_decoder: MLP [33,512,256,128,1], res @ [1,2], weight_norm, LeakyReLU(0.02),
+ * sigmoid (network/arch_recon.py:19-39).  weight_norm is folded at pack time. */
+int avc_pack_recon_weights(avc_ctx *ctx, const avc_dense fc[4]);
+
+/* ---- per-frame feature maps ----------------------------------------------------------------
+ * WarpingField.precompute_conv caches self.pose_feat_map = unet(smpl_pos_map)
+ * (network/arch_avatar.py:109-111).  The U-Net itself stays on PyTorch-ROCm; this call hands its
+ * (1,C=64,H,W) NCHW output to the context, which re-lays it out channel-last for the gather. */
+int avc_set_pose_feat_map(avc_ctx *ctx, const float *map_nchw_dev, int C, int H, int W, avc_stream stream);
+/* img_feat_map = HGFilter(cat(front,back))[-1], (1,C=32,H,W) (network/arch_recon.py:51-52) */
+int avc_set_img_feat_map(avc_ctx *ctx, const float *map_nchw_dev, int C, int H, int W, avc_stream stream);
+
+/* ---- queries -------------------------------------------------------------------------------
+ * OccupancyNet.query (network/arch_avatar.py:356-381) = WarpingField.query (:113-140) +
+ * DoubleTNet.forward (:65-83) on cano_pts + offset, for n points (any n >= 0; the reference's
+ * 262,144-point chunking is an activation-memory device it no longer needs).
+ *   pts_dev     (n,3)  cano_pts
+ *   center      (3)    batch['cano_smpl_center']
+ *   occ_out_dev (n)    'cano_pts_ov'   raw geo[0] when occupancy_sigmoid == 0 (config.if_type=='sdf'),
+ *                                      sigmoid(geo[0]) otherwise (arch_avatar.py:77-80)
+ *   offset_out_dev (n,3) or NULL   'nonrigid_offset'
+ *   rgba_out_dev (n,4) or NULL     sigmoid(clr_mlp) and relu(geo[1]) -- the `rgb, alpha` of
+ *                                  DoubleTNet.forward (:75-76); needs clr weights. */
+int avc_avatar_query(avc_ctx *ctx, const float *pts_dev, int64_t n, const float center[3],
+                     int occupancy_sigmoid, float *occ_out_dev, float *offset_out_dev,
+                     float *rgba_out_dev, avc_stream stream);
+
+/* DoubleTNet.forward alone on given points (pts_space == 'temp', arch_avatar.py:216-219) */
+int avc_template_query(avc_ctx *ctx, const float *pts_dev, int64_t n, int occupancy_sigmoid,
+                       float *occ_out_dev, float *rgba_out_dev, avc_stream stream);
+
+/* ReconNetwork.infer's per-point part (network/arch_recon.py:55-73): bilinear 32-ch sample at
+ * (x-cx, -(y-cy)), z = p.z-cz, decoder, sigmoid.  out_dev (n). */
+int avc_recon_query(avc_ctx *ctx, const float *pts_dev, int64_t n, const float center[3],
+                    float *out_dev, avc_stream stream);
+
+/* occ_volume[valid] = values; occ_volume[~valid] = fill  (main.py:362-363, 442-443).
+ * valid_dev (N) uint8/bool; values_dev (n_valid) in flat order; fill_dev (N - n_valid). */
+int avc_scatter_volume(avc_ctx *ctx, const uint8_t *valid_dev, int64_t N, const float *values_dev,
+                       const float *fill_dev, float *volume_out_dev, avc_stream stream);
+
+/* ---- meshing -------------------------------------------------------------------------------
+ * recon_util.recon_mesh (utils/recon_util.py:51-70) with the volume kept on the device:
+ * marching cubes at iso (replaces skimage.measure.marching_cubes, :64 -- parity UNPINNED, see
+ * DESIGN.md), vertices = index*voxel + b0 + voxel/2 (:62,65), normals = -normalize(trilinear
+ * sample of the Sobel gradient volume) (:9-48,66-68), faces flipped [2,1,0] (:69).
+ *   vol_dev (X,Y,Z) float32, res = {X,Y,Z}, bounds = {b0x,b0y,b0z,b1x,b1y,b1z}
+ *   verts_out_dev (cap_v,3) f32, normals_out_dev (cap_v,3) f32 or NULL, faces_out_dev (cap_f,3) i32
+ *   counts_out[2] (HOST) = {V, F}.  Synchronises the stream once (the counts decide the emit
+ *   launch sizes).  Returns AVC_ERR_CAPACITY (with counts filled) if V > cap_v or F > cap_f.
+ * Output order is canonical (see oracle/mc_oracle.c): vertices by owning grid edge, faces by cell. */
+int avc_recon_mesh(avc_ctx *ctx, const float *vol_dev, const int32_t res[3], const float bounds[6],
+                   float iso, float *verts_out_dev, float *normals_out_dev, int32_t *faces_out_dev,
+                   int64_t cap_v, int64_t cap_f, int64_t counts_out[2], avc_stream stream);
+
+/* ---- SMPL utilities ------------------------------------------------------------------------
+ * K nearest of nr reference points per query, squared L2 ascending, ties -> lower index
+ * (pytorch3d.ops.knn_points as used at utils/smpl_util.py:33, dataset/avatarcap_dataset.py:114,
+ * network/arch_avatar.py:190,208).  K <= 8.  d2_out_dev (nq,K) f32, idx_out_dev (nq,K) i64. */
+int avc_knn(avc_ctx *ctx, const float *query_dev, int64_t nq, const float *ref_dev, int32_t nr, int K,
+            float *d2_out_dev, int64_t *idx_out_dev, avc_stream stream);
+
+/* SmplUtil.calculate_lbs (utils/smpl_util.py:24-39): KNN-4 to the canonical SMPL vertices,
+ * w = exp(-d2 / (2*0.05^2)), normalised (+1e-16), blended 24-wide skin weights.
+ * cano_v_dev (nv,3), skin_w_dev (nv,24) -> lbs_out_dev (n,24) */
+int avc_calculate_lbs(avc_ctx *ctx, const float *pts_dev, int64_t n, const float *cano_v_dev,
+                      const float *skin_w_dev, int32_t nv, float *lbs_out_dev, avc_stream stream);
+
+/* SmplUtil.skinning / skinning_normal (utils/smpl_util.py:58-81): M = sum_j lbs_j * J_j;
+ * p' = M[:3,:3] p + M[:3,3]; n' = M[:3,:3] n (no renormalisation).
+ * jnt_mats_dev (24,4,4).  nrm_dev/nrm_out_dev/mats_out_dev may be NULL.  mats_out_dev (n,4,4). */
+int avc_skinning(avc_ctx *ctx, const float *pts_dev, const float *nrm_dev, int64_t n,
+                 const float *lbs_dev, const float *jnt_mats_dev, float *pts_out_dev,
+                 float *nrm_out_dev, float *mats_out_dev, avc_stream stream);
+
+/* ---- measurement hook ------------------------------------------------------------------------
+ * Average device time (ms, HIP events on the launch stream) of the fused query kernel over the
+ * launches since the last reset; used by bench.py for roofline.achieved.  which: 0 avatar, 1 recon. */
+int avc_timing_enable(avc_ctx *ctx, int enable);
+int avc_timing_read(avc_ctx *ctx, int which, double *avg_ms_out, int64_t *launches_out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVCAP_H */

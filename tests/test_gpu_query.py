@@ -1,0 +1,110 @@
+"""GPU parity of the fused MLP queries (csrc/fused_mlp.hip) through the C-ABI, against
+(a) the golden vectors produced by the reference itself and (b) the CPU oracle on fresh inputs.
+Tolerance: 1e-4 absolute on occupancy / offsets (BASELINE.json north_star), fp32 in/out."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from avatarcap_amd import config, synthetic as syn
+from common import geotex_sd, recon_sd, maxabs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _t(x, dev='cuda'):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+@pytest.fixture(scope='module')
+def net():
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar
+    config.cfg = config.default_cfg()
+    n = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume()).to('cuda').eval()
+    n.load_state_dict({k: torch.from_numpy(v) for k, v in geotex_sd().items()})
+    return n
+
+
+def _batch(pts):
+    return {'cano_pts': _t(pts[None]), 'cano_smpl_center': _t(gi.center()[None])}
+
+
+def test_avatar_query_matches_reference_golden(net, golden):
+    from avatarcap_amd.network.arch_avatar import OccupancyNet
+    net.warping_field.pose_feat_map = _t(gi.pose_feat_map()[None])
+    net.warping_field._map_on_device = None
+    pts = gi.query_points(104, 2048)
+    for if_type in ('sdf', 'occupancy'):
+        config.if_type = if_type
+        out = OccupancyNet(net).query(_batch(pts))
+        assert out['cano_pts_ov'].shape == (1, 2048, 1) and out['nonrigid_offset'].shape == (1, 2048, 3)
+        assert maxabs(out['cano_pts_ov'][0].cpu().numpy(), golden[f'G5_occ_{if_type}']) < TOL
+        assert maxabs(out['nonrigid_offset'][0].cpu().numpy(), golden['G5_offset']) < TOL
+    config.if_type = 'sdf'
+    assert maxabs(net.warping_field.query(_t(pts[None]), _batch(pts))[0].cpu().numpy(), golden['G4_offset']) < TOL
+    rgb, alpha, occ = net.cano_template.forward(_t(pts[None]))
+    assert maxabs(rgb[0].cpu().numpy(), golden['G5_tmpl_rgb']) < TOL
+    assert maxabs(alpha[0].cpu().numpy(), golden['G5_tmpl_alpha']) < TOL
+    assert maxabs(occ[0].cpu().numpy(), golden['G5_tmpl_occ']) < TOL
+
+
+@pytest.mark.parametrize('n', [1, 31, 128, 129, 5000, 70001])
+def test_avatar_query_vs_oracle_ragged(net, n):
+    """ragged sizes around the 32-point wave / 128-point tile boundaries"""
+    from avatarcap_amd.network.arch_avatar import OccupancyNet
+    from oracle import avatarcap_oracle as orc
+    config.if_type = 'sdf'
+    fmap = gi.pose_feat_map(seed=300 + n % 7)
+    net.warping_field.pose_feat_map = _t(fmap[None])
+    net.warping_field._map_on_device = None
+    pts = gi.query_points(500 + n, n)
+    out = OccupancyNet(net).query(_batch(pts))
+    sel = np.arange(n) if n <= 6000 else np.sort(np.random.RandomState(n).choice(n, 6000, replace=False))
+    ref = orc.occupancy_query(pts[sel], fmap, gi.center(), geotex_sd())
+    assert maxabs(out['cano_pts_ov'][0].cpu().numpy()[sel], ref['cano_pts_ov']) < TOL
+    assert maxabs(out['nonrigid_offset'][0].cpu().numpy()[sel], ref['nonrigid_offset']) < TOL
+
+
+def test_avatar_query_empty_and_errors(net):
+    from avatarcap_amd.network.arch_avatar import OccupancyNet
+    from avatarcap_amd import _lib
+    net.warping_field.pose_feat_map = _t(gi.pose_feat_map()[None])
+    net.warping_field._map_on_device = None
+    out = OccupancyNet(net).query(_batch(np.zeros((0, 3), np.float32)))
+    assert out['cano_pts_ov'].shape == (1, 0, 1)
+    net.warping_field.pose_feat_map = None
+    with pytest.raises(AttributeError):
+        OccupancyNet(net).query(_batch(gi.query_points(1, 8)))
+    with pytest.raises((TypeError, RuntimeError)):
+        net.warping_field.pose_feat_map = _t(gi.pose_feat_map()[None])
+        OccupancyNet(net).query({'cano_pts': torch.zeros(1, 8, 3, dtype=torch.float64, device='cuda'),
+                                 'cano_smpl_center': _t(gi.center()[None])})
+
+
+def test_recon_decoder_matches_reference_golden(golden):
+    from avatarcap_amd.network.arch_recon import ReconNetwork
+    rn = ReconNetwork().to('cuda').eval()
+    rn.load_state_dict({k: torch.from_numpy(v) for k, v in recon_sd().items()})
+    pts = gi.query_points(104, 2048)
+    y = rn.decode(_t(pts[None]), _t(gi.img_feat_map()[None]), _t(gi.center()[None]))
+    assert y.shape == (2048,)
+    assert maxabs(y.cpu().numpy(), golden['G6_decoder']) < TOL
+    # whole infer(): HGFilter on MIOpen + fused decoder
+    nm = gi.normal_maps(64)
+    items = {'cano_pts': _t(pts[None]), 'cano_smpl_center': _t(gi.center()[None]),
+             'front_normal': _t(nm[None, :3]), 'back_normal': _t(nm[None, 3:])}
+    y2 = rn.infer(items)
+    assert maxabs(y2.cpu().numpy(), golden['G6_recon'].reshape(-1)) < 5e-4   # includes fp32 conv-stack differences (MIOpen vs CPU)
+
+
+@pytest.mark.parametrize('n', [1, 33, 4097])
+def test_recon_decoder_vs_oracle(n):
+    from avatarcap_amd.network.arch_recon import ReconNetwork
+    from oracle import avatarcap_oracle as orc
+    rn = ReconNetwork().to('cuda').eval()
+    rn.load_state_dict({k: torch.from_numpy(v) for k, v in recon_sd().items()})
+    pts = gi.query_points(700 + n, n)
+    imap = gi.img_feat_map(seed=210)
+    y = rn.decode(_t(pts[None]), _t(imap[None]), _t(gi.center()[None]))
+    assert maxabs(y.cpu().numpy().reshape(-1), orc.recon_infer(pts, imap, gi.center(), recon_sd())) < TOL

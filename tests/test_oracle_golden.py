@@ -1,0 +1,113 @@
+"""Pins the CPU oracle (oracle/avatarcap_oracle.py) to outputs of the reference itself
+(tests/golden/reference_golden.npz, produced by tests/golden/make_golden.py from /root/reference).
+CPU only.  Tolerances: the reference runs fp32, the oracle fp64 => a few 1e-6 relative."""
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+from avatarcap_amd import synthetic as syn
+from avatarcap_amd.grid import generate_volume_points_np, linspace01_f32
+from oracle import avatarcap_oracle as orc
+from common import geotex_sd, recon_sd, mlp_sd, offset_decoder_sd, maxabs
+
+
+def rel(a, b):
+    return maxabs(a, b) / max(1e-12, float(np.max(np.abs(b))))
+
+
+def test_G0_grid(golden):
+    assert np.array_equal(linspace01_f32(17), golden['G0_lin17'])
+    assert np.array_equal(linspace01_f32(256), golden['G0_lin256'])
+    for name, res in (('toy', (4, 3, 2)), ('odd', (5, 7, 6))):
+        assert np.array_equal(generate_volume_points_np(syn.CANO_BOUNDS, res), golden[f'G0_{name}_pts'])
+
+
+def test_G1_embedder(golden):
+    x = gi.points(101, 256)
+    assert maxabs(orc.embed(x.astype(np.float64), 10), golden['G1_embed10']) < 5e-5   # sin(512 x) in fp32 vs fp64
+    assert np.array_equal(orc.embed(x, 0), golden['G1_embed0'])
+    # same arithmetic type as the reference => tight
+    assert maxabs(orc.embed(x, 10), golden['G1_embed10']) < 5e-7
+
+
+@pytest.mark.parametrize('name', list(gi.MLP_CONFIGS))
+def test_G2_mlp(golden, name):
+    c = gi.MLP_CONFIGS[name]
+    k = c['kwargs']
+    x = gi.features(102, 300, k['in_channels'])
+    y = orc.mlp_forward(x, mlp_sd(name), '', c['n_layers'], tuple(k['res_layers']), k['nlactv'], k['last_op'])
+    assert y.shape == golden[f'G2_{name}'].shape
+    assert rel(y, golden[f'G2_{name}']) < 2e-5
+
+
+def test_G3_offset_decoder(golden):
+    y = orc.offset_decoder(gi.features(103, 300, 67), offset_decoder_sd(), '')
+    assert rel(y, golden['G3_offset_decoder']) < 2e-5
+
+
+def test_G4_G5_avatar_query(golden):
+    sd, fmap, pts, c = geotex_sd(), gi.pose_feat_map(), gi.query_points(104, 2048), gi.center()
+    off = orc.warping_query(pts, fmap, c, sd)
+    assert maxabs(off, golden['G4_offset']) < 2e-5 * max(1.0, float(np.abs(golden['G4_offset']).max()))
+    for if_type in ('sdf', 'occupancy'):
+        o = orc.occupancy_query(pts, fmap, c, sd, if_type)
+        g = golden[f'G5_occ_{if_type}']
+        assert np.abs(g).max() > 0.05, 'vacuous fixture'
+        assert maxabs(o['cano_pts_ov'], g) < 1e-4
+        assert maxabs(o['nonrigid_offset'], golden['G5_offset']) < 1e-4
+    rgb, alpha, occ = orc.double_tnet(pts, sd)
+    assert maxabs(rgb, golden['G5_tmpl_rgb']) < 1e-4
+    assert maxabs(alpha, golden['G5_tmpl_alpha']) < 1e-4
+    assert maxabs(occ, golden['G5_tmpl_occ']) < 1e-4
+    gpts = generate_volume_points_np(syn.CANO_BOUNDS, (64, 64, 64))[gi.grid_subset(64 ** 3, 1500)]
+    assert maxabs(orc.occupancy_query(gpts, fmap, c, sd)['cano_pts_ov'], golden['G5_grid64_sel_occ']) < 1e-4
+
+
+def test_G6_recon_decoder(golden):
+    y = orc.recon_infer(gi.query_points(104, 2048), gi.img_feat_map(), gi.center(), recon_sd())
+    assert maxabs(y, golden['G6_decoder']) < 2e-5
+    # full infer with the reference's own HGFilter output as the feature map
+    y2 = orc.recon_infer(gi.query_points(104, 2048), golden['G6_img_feat'], gi.center(), recon_sd())
+    assert maxabs(y2, golden['G6_recon'][0] if golden['G6_recon'].ndim == 2 else golden['G6_recon']) < 2e-5
+
+
+def test_G8_lbs(golden, body):
+    vp = gi.surface_points(105, 700, body)
+    lbs = orc.calculate_lbs(vp, body['cano_smpl_v'], body['skin_weights'])
+    assert maxabs(lbs, golden['G8_lbs']) < 2e-6
+    jm = syn.random_pose_jnt_mats(gi.SEED_POSE)
+    live, mats = orc.skinning(vp, golden['G8_lbs'], jm)
+    assert maxabs(live, golden['G8_live']) < 2e-6
+    assert maxabs(mats, golden['G8_mats']) < 2e-6
+    nrm = gi.unit_vectors(106, 700)
+    assert maxabs(orc.skinning_normal(nrm, golden['G8_lbs'], jm), golden['G8_live_normals']) < 2e-6
+
+
+def test_G9_normals(golden):
+    vol, voxel = gi.sdf_volume(32)
+    nv = orc.extract_normal_volume(vol, voxel)
+    assert rel(nv[::5, ::5, ::5], golden['G9_normal_volume_slice']) < 1e-5
+    n = orc.extract_normal_from_volume(vol, voxel, gi.grid_points_m11(107, 400))
+    assert maxabs(n, golden['G9_normals']) < 2e-5
+
+
+def test_G10_blend_weights(golden):
+    w = orc.cano_blend_weight_volume(gi.blend_weight_volume(), gi.points01(108, 300))
+    assert maxabs(w, golden['G10_blend_w']) < 2e-6
+
+
+def test_G11_raw2outputs(golden):
+    raw, zv = gi.raw_and_z(109, 50, 64)
+    r = orc.raw2outputs(raw, zv)
+    for k, v in zip(('rgb_map', 'disp_map', 'acc_map', 'weights', 'depth_map'), r):
+        assert rel(v, golden[f'G11_{k}']) < 1e-5, k
+
+
+def test_G12_geotex_forward_cano(golden, body):
+    wp = gi.surface_points(110, 600, body) + 0.01 * gi.unit_vectors(111, 600)
+    dists = np.full((600, 1), 0.0016, np.float32)
+    raw, occ, off = orc.geotex_forward_cano(wp, dists, gi.pose_feat_map(), gi.center(), syn.CANO_BOUNDS,
+                                            body['cano_smpl_v'], geotex_sd())
+    assert maxabs(raw, golden['G12_raw']) < 1e-4
+    assert maxabs(occ, golden['G12_occ']) < 1e-4
+    assert maxabs(off, golden['G12_off']) < 1e-4
