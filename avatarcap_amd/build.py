@@ -18,6 +18,9 @@ SOURCES = ['fused_mlp.hip', 'mesh.hip', 'knn_lbs.hip', 'pack.cpp', 'capi.cpp']
 HEADERS = ['avcap_internal.h', 'mlp_layout.h', 'mc_tables.h', os.path.join('..', '..', 'include', 'avcap.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
+# mesh / KNN kernels promise bit-exact agreement with the C oracle (built with -ffp-contract=off):
+# HIP's __fmul_rn/__fadd_rn are plain operators, so contraction has to be disabled per file.
+EXTRA = {'mesh.hip': ['-ffp-contract=off'], 'knn_lbs.hip': ['-ffp-contract=off']}
 
 
 def _stale(target, deps):
@@ -35,7 +38,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, src + '.o')
         if force or _stale(op, [sp] + hdrs):
-            cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', sp, '-o', op]
+            cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', sp, '-o', op]
             jobs.append((src, cmd))
 
     def run(job):

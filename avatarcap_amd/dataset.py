@@ -1,0 +1,91 @@
+"""Test-mode data harness.
+
+`SyntheticTestDataset` mirrors what `AvatarCapDataset.__init__/__getitem__` prepare in test mode
+(dataset/avatarcap_dataset.py:27-125, 181-308) -- the canonical grid, the valid-band flag, the
+inside/outside fill of the skipped points and the per-frame item dict -- from the synthetic body of
+`avatarcap_amd.synthetic` instead of the licensed SMPL model and a captured sequence.
+
+One-time work runs on the device: the KNN-1 band test is the HIP KNN kernel
+(1.16e11 pair tests at 256^3, avatarcap_dataset.py:114); the reference's trimesh/embree
+`contains` (:121-125) is replaced by the sign of the analytic capsule SDF of the synthetic body.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import config
+from . import synthetic as syn
+from .grid import generate_volume_points
+
+
+class SyntheticTestDataset:
+    def __init__(self, vol_res=None, valid='band', n_frames=8, seed=syn.SEED, device=None, bounds=None):
+        self.device = torch.device(device) if device is not None else config.device
+        self.vol_res = [int(r) for r in (vol_res or config.cfg['testing']['vol_res'])]
+        self.body = syn.synthetic_body(seed)
+        self.cano_smpl_v = torch.from_numpy(self.body['cano_smpl_v'])
+        self.cano_bounds = np.asarray(bounds if bounds is not None else syn.CANO_BOUNDS, np.float32)
+        v = self.body['cano_smpl_v']
+        self.cano_smpl_center = (0.5 * (v.max(0) + v.min(0))).astype(np.float32)        # avatarcap_dataset.py:65-66
+        self.n_frames = n_frames
+        self.seed = seed
+        self.valid_mode = valid
+
+        vol_pts = generate_volume_points(self.cano_bounds, self.vol_res, self.device)     # :111
+        N = vol_pts.shape[0]
+        if valid == 'dense':
+            self.infer_pts_flag = torch.ones(N, dtype=torch.bool, device=self.device)
+            self.infer_pts = vol_pts
+            self.invalid_pts_ov = torch.empty(0, dtype=torch.float32, device=self.device)
+        elif valid == 'band':
+            from .utils.smpl_util import SmplUtil
+            su = SmplUtil()
+            d2 = torch.empty(N, dtype=torch.float32, device=self.device)
+            cv = self.cano_smpl_v.to(self.device)
+            step = 1 << 22
+            for s in range(0, N, step):                                                    # :114
+                d, _ = su.knn_points(vol_pts[None, s:s + step], cv[None], K=1)
+                d2[s:s + step] = d[0, :, 0]
+            self.infer_pts_flag = d2 < 0.1 ** 2                                            # :116
+            self.infer_pts = vol_pts[self.infer_pts_flag].contiguous()                     # :118
+            inv = vol_pts[~self.infer_pts_flag].cpu().numpy()
+            sign = np.empty(inv.shape[0], np.float32)
+            for s in range(0, inv.shape[0], 1 << 20):                                      # :121-125 (contains -> [-1, 1])
+                sign[s:s + (1 << 20)] = np.where(syn.body_sdf(inv[s:s + (1 << 20)]) < 0, 1.0, -1.0)
+            self.invalid_pts_ov = torch.from_numpy(sign).to(self.device)
+        else:
+            raise ValueError("valid must be 'dense' or 'band'")
+        self.valid_u8 = self.infer_pts_flag.to(torch.uint8).contiguous()
+
+    def __len__(self):
+        return self.n_frames
+
+    def __getitem__(self, idx):
+        """Item dict with the keys the hot path reads (Appendix B), tensors on the host like the
+        reference's dataset; `to_cuda(item, add_batch=True)` moves them."""
+        rs = np.random.RandomState(self.seed * 7919 + idx)
+        return {
+            'data_idx': idx,
+            'cano_pts': self.infer_pts,                                                   # already on device (:118,305)
+            'valid_pts_flag': self.infer_pts_flag,
+            'smpl_pos_map': rs.uniform(-1, 1, (6, 256, 256)).astype(np.float32),          # :207-213
+            'cano_smpl_center': self.cano_smpl_center,
+            'cano_bounds': self.cano_bounds,
+            'cano2live_jnt_mats': syn.random_pose_jnt_mats(self.seed * 31 + idx),         # :193-201
+        }
+
+
+def to_cuda(items: dict, add_batch=False):
+    """dataset/avatarcap_dataset.py:329-346"""
+    out = {}
+    for key, data in items.items():
+        if isinstance(data, torch.Tensor):
+            out[key] = data.to(config.device)
+        elif isinstance(data, np.ndarray):
+            out[key] = torch.from_numpy(data).to(config.device)
+        else:
+            out[key] = data
+        if add_batch and isinstance(out[key], torch.Tensor):
+            out[key] = out[key].unsqueeze(0)
+    return out

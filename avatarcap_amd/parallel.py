@@ -1,0 +1,63 @@
+"""Frame-sharded data parallelism.
+
+The reference has no multi-GPU code; its frame loop (main.py:348) carries no state between frames, so
+frames shard embarrassingly: frame f runs on rank f mod world_size, one process per GPU, weights /
+grid / SMPL tables replicated.  The only exchange is an all-gather(v) of the finished meshes
+(torch.distributed; backend 'nccl' = RCCL over xGMI on the GPU box, 'gloo' in the CPU tests):
+  1. all_gather of the per-frame (V, F) counts,
+  2. one all_gather of the [verts | normals] float buffers and one of the int32 faces, padded to the
+     largest rank (xGMI moves the ~1 GB of a 64-frame batch in well under one frame time, so a single
+     large collective per batch beats per-frame ones).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_frames(n_frames: int, rank: int, world_size: int) -> list[int]:
+    """Frames owned by `rank`: f with f % world_size == rank, ascending."""
+    return list(range(rank, n_frames, world_size))
+
+
+def _pack(meshes, device):
+    counts = torch.tensor([[m['v'].shape[0], m['f'].shape[0]] for m in meshes], dtype=torch.int64, device=device).reshape(-1, 2)
+    vn = [torch.cat([m['v'].reshape(-1, 3), m['vn'].reshape(-1, 3)], 1).reshape(-1) for m in meshes]
+    fs = [m['f'].reshape(-1).to(torch.int32) for m in meshes]
+    vbuf = torch.cat(vn) if vn else torch.empty(0, dtype=torch.float32, device=device)
+    fbuf = torch.cat(fs) if fs else torch.empty(0, dtype=torch.int32, device=device)
+    return counts, vbuf.to(torch.float32), fbuf
+
+
+def all_gather_meshes(meshes: list[dict], n_frames: int, group=None) -> list[dict]:
+    """meshes: this rank's frames in ascending frame order, each {'v' (V,3) f32, 'vn' (V,3) f32,
+    'f' (F,3) i32}.  Returns, on every rank, all n_frames meshes in frame order."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        return list(meshes)
+    device = meshes[0]['v'].device if meshes else torch.device('cpu')
+    kmax = (n_frames + world - 1) // world
+    counts, vbuf, fbuf = _pack(meshes, device)
+    cpad = torch.zeros((kmax, 2), dtype=torch.int64, device=device)
+    cpad[:counts.shape[0]] = counts
+    all_counts = [torch.empty_like(cpad) for _ in range(world)]
+    dist.all_gather(all_counts, cpad, group=group)
+    all_counts = torch.stack(all_counts).cpu()                       # (world, kmax, 2)
+    vmax = int(all_counts[:, :, 0].sum(1).max()) * 6
+    fmax = int(all_counts[:, :, 1].sum(1).max()) * 3
+    vpad = torch.zeros(max(vmax, 1), dtype=torch.float32, device=device); vpad[:vbuf.numel()] = vbuf
+    fpad = torch.zeros(max(fmax, 1), dtype=torch.int32, device=device); fpad[:fbuf.numel()] = fbuf
+    all_v = [torch.empty_like(vpad) for _ in range(world)]
+    all_f = [torch.empty_like(fpad) for _ in range(world)]
+    dist.all_gather(all_v, vpad, group=group)
+    dist.all_gather(all_f, fpad, group=group)
+    out = [None] * n_frames
+    for r in range(world):
+        vo = fo = 0
+        for k, f in enumerate(shard_frames(n_frames, r, world)):
+            V, Fn = int(all_counts[r, k, 0]), int(all_counts[r, k, 1])
+            vn = all_v[r][vo:vo + 6 * V].reshape(V, 6)
+            out[f] = {'v': vn[:, :3], 'vn': vn[:, 3:], 'f': all_f[r][fo:fo + 3 * Fn].reshape(Fn, 3)}
+            vo += 6 * V; fo += 3 * Fn
+    return out

@@ -1,0 +1,69 @@
+"""The per-frame driver segment of `main.run_avatarcap` (main.py:357-367, 383-389, 438-453) with every
+tensor kept on the device: no `.cpu()` of the volume for marching cubes, no host round trip of the
+vertices for normals / LBS.  Rendering (OpenGL), image I/O and normal fusion are outside this path
+(SURVEY.md section 8(f)).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import config
+from . import _lib
+from .utils import recon_util
+from .utils.smpl_util import smpl_util
+
+
+def fill_volume(values: torch.Tensor, valid_u8: torch.Tensor, invalid_ov: torch.Tensor, out: torch.Tensor | None = None):
+    """occ_volume[valid] = values; occ_volume[~valid] = invalid_pts_ov   (main.py:362-363)."""
+    N = valid_u8.numel()
+    vol = out if out is not None else torch.empty(N, dtype=torch.float32, device=values.device)
+    values = values.reshape(-1).contiguous()
+    if values.numel() == N:
+        return values if out is None else out.copy_(values)
+    _lib.check(_lib.lib().avc_scatter_volume(_lib.ctx(values.device), valid_u8.data_ptr(), N, values.data_ptr(),
+                                             invalid_ov.contiguous().data_ptr(), vol.data_ptr(), _lib.stream_ptr(values.device)))
+    return vol
+
+
+class FramePipeline:
+    """Holds the networks and the per-sequence constants; `avatar_frame` / `recon_frame` are steps
+    1 and 3 of main.py's loop body."""
+
+    def __init__(self, network, dataset, recon_net=None):
+        from .network.arch_avatar import OccupancyNet
+        self.network = network
+        self.occ_net = OccupancyNet(network)
+        self.recon_net = recon_net
+        self.ds = dataset
+        self.vol_res = list(dataset.vol_res)
+        smpl_util.set_smpl_skinning_weights(dataset.body['skin_weights'])
+        smpl_util.set_cano_smpl_vertices(dataset.cano_smpl_v)                 # main.py:335
+
+    @torch.no_grad()
+    def avatar_frame(self, items: dict, skin=True):
+        """1. geometric avatar in canonical space (main.py:357-367) + skinning to live space (:383-389)."""
+        self.network.warping_field.precompute_conv(items)                    # :359
+        out = self.occ_net.query(items)                                      # :360
+        vol = fill_volume(out['cano_pts_ov'][0, :, 0], self.ds.valid_u8, self.ds.invalid_pts_ov)   # :362-364
+        v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds, iso_value=config.iso_value)   # :367
+        res = {'cano_v': v, 'cano_vn': n, 'f': f, 'occ_volume': vol}
+        if skin and v.shape[0] > 0:
+            lbs = smpl_util.calculate_lbs(v[None])                           # :385
+            live_v, mats = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'], True)     # :386
+            live_n = smpl_util.skinning_normal(n[None], lbs, items['cano2live_jnt_mats'])          # :389 (einsum with vert_mats[:, :3, :3])
+            res.update({'live_v': live_v[0], 'live_vn': live_n[0], 'vert_mats': mats[0]})
+        return res
+
+    @torch.no_grad()
+    def recon_frame(self, items: dict):
+        """3. reconstruction network (main.py:438-453); items must hold front_normal / back_normal."""
+        out = self.recon_net.infer(items)                                    # :440
+        vol = fill_volume(out.reshape(-1), self.ds.valid_u8, self.ds.invalid_pts_ov)               # :442-443
+        v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds)             # :444 (iso 0.5)
+        res = {'cano_v': v, 'cano_vn': n, 'f': f, 'occ_volume': vol}
+        if v.shape[0] > 0:
+            lbs = smpl_util.calculate_lbs(v[None])                           # :451
+            res['live_v'] = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'])[0]       # :452
+            res['live_vn'] = smpl_util.skinning_normal(n[None], lbs, items['cano2live_jnt_mats'])[0]   # :453
+        return res

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- reconstructed-mesh frames/sec at 256^3 (BASELINE.json metric), 1..8 MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one frame of BASELINE.json configs[1] ("AvatarNet occupancy-only, 256^3 grid, random SMPL
+pose") on every rank: UNet7DS pose-feature map (MIOpen) -> fused warp+template occupancy query over
+ALL 256^3 grid points (dense: nothing is masked out) -> marching cubes + normals -> KNN-4 LBS ->
+skinned live mesh, all on the device (avatarcap_amd.pipeline.FramePipeline.avatar_frame, i.e.
+main.py:357-367,383-389).  Frames are independent, so ranks process different frames (weak scaling,
+no data-path collective); for N > 1 the batch's meshes are all-gathered once over RCCL inside the
+timed region (avatarcap_amd.parallel).  Inputs (weights, grid, per-frame pose maps / joint
+matrices) are resident in HBM before the timed region.
+
+The JSON line also carries:
+  roofline     -- the dominant kernel (avatar_kernel): algorithmic FLOP/launch (1,773,568 per point,
+                  SURVEY.md 8(d)) / mean launch time measured with HIP events on the launch stream,
+                  against the dense fp16 MFMA peak (the kernel issues 3 fp16 MFMA passes per fp32
+                  product, so `mfma_util` = 3.06 x frac is the matrix-pipe utilisation).
+  cpu_baseline -- the CPU oracle (NumPy float32 port of the reference path + C marching cubes) timed
+                  on this host on a bounded sample and scaled to one 256^3 frame.
+  masked       -- the same frame with the reference's own valid-band masking (only points within 0.1 m
+                  of the body are evaluated, dataset/avatarcap_dataset.py:114-118), for information.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_POINT = 1_773_568          # warp 428,288 + shared 425,472 + geo 33,024 MAC
+MFMA_ISSUED_PER_POINT = 5304 * 32 * 32 * 16 * 2 / 32   # 5304 v_mfma_f32_32x32x16_f16 per 32 points
+PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def build_pipeline(res, valid, n_frames, device):
+    from avatarcap_amd import config, synthetic as syn
+    from avatarcap_amd.dataset import SyntheticTestDataset
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar
+    from avatarcap_amd.pipeline import FramePipeline
+    config.device = device
+    config.cfg = config.default_cfg()
+    config.cfg['testing']['vol_res'] = [res, res, res]
+    ds = SyntheticTestDataset([res, res, res], valid=valid, n_frames=n_frames, device=device)
+    net = GeoTexAvatar(base_weight_volume=np.zeros((2, 2, 2, 24), np.float32)).to(device).eval()
+    sd = syn.synth_state_dict(syn.module_shapes(net), syn.SEED)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return FramePipeline(net, ds), sd
+
+
+def cpu_baseline(pipe, sd, frame_out, res, budget_s=20.0):
+    """Oracle ('port') on the host cores, bounded sample, scaled to one dense frame."""
+    from oracle import avatarcap_oracle as orc, mc as omc
+    from avatarcap_amd import synthetic as syn
+    ds = pipe.ds
+    N = res ** 3
+    fmap = pipe.network.warping_field.pose_feat_map[0].cpu().numpy()
+    pts = ds.infer_pts[:: max(1, ds.infer_pts.shape[0] // 262144)].cpu().numpy()
+    n0 = 8192
+    t = time.perf_counter(); orc.occupancy_query(pts[:n0], fmap, ds.cano_smpl_center, sd, dt=np.float32); t0 = time.perf_counter() - t
+    n1 = int(min(len(pts) - n0, max(n0, (budget_s * 0.5) / (t0 / n0))))
+    t = time.perf_counter(); orc.occupancy_query(pts[n0:n0 + n1], fmap, ds.cano_smpl_center, sd, dt=np.float32); t1 = time.perf_counter() - t
+    per_pt = t1 / n1
+    vol = frame_out['occ_volume'].reshape(res, res, res).cpu().numpy()
+    voxel = ((ds.cano_bounds[1] - ds.cano_bounds[0]) / res).astype(np.float32)
+    t = time.perf_counter(); v, f = omc.marching_cubes(vol, 0.0, voxel); t_mc = time.perf_counter() - t
+    V = max(1, v.shape[0])
+    nv = min(V, 4000)
+    vv = (v[:: max(1, V // nv)][:nv] + ds.cano_bounds[0] + 0.5 * voxel).astype(np.float32)
+    t = time.perf_counter()
+    lbs = orc.calculate_lbs(vv, ds.body['cano_smpl_v'], ds.body['skin_weights'])
+    orc.skinning(vv, lbs, syn.random_pose_jnt_mats(1))
+    t_lbs = (time.perf_counter() - t) / len(vv)
+    frame_s = per_pt * N + t_mc + t_lbs * V
+    return {'value': 1.0 / frame_s, 'unit': 'frames/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'NumPy-f32 oracle: query {n1} of {N} grid points ({t1:.1f} s, {per_pt*1e6:.2f} us/pt) scaled to {N}; '
+                      f'C marching cubes on the full {res}^3 volume ({t_mc:.2f} s, 1 thread); KNN-4 LBS on {len(vv)} of {V} vertices scaled; '
+                      f'Sobel normals and the 10 GFLOP U-Net not included',
+            'seconds_per_frame': frame_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--res', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-masked', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the hot path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from avatarcap_amd import _lib
+    from avatarcap_amd.dataset import to_cuda
+    from avatarcap_amd.parallel import all_gather_meshes
+    K, W, res = args.steps, args.warmup, args.res
+    n_frames = world * (K + W)
+    pipe, sd = build_pipeline(res, 'dense', n_frames, device)
+    ctx = _lib.ctx(device)
+    # inputs of this rank's frames, resident in HBM before timing
+    my = [to_cuda(pipe.ds[(s * world) + rank], add_batch=True) for s in range(K + W)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for s in range(W):
+        out = pipe.avatar_frame(my[s])
+    if world > 1:   # warm the collective too
+        all_gather_meshes([{'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']}], world)
+    barrier()
+    _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
+    t0 = time.perf_counter()
+    meshes = []
+    for s in range(W, W + K):
+        out = pipe.avatar_frame(my[s])
+        meshes.append({'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']})
+    if world > 1:
+        gathered = all_gather_meshes(meshes, world * K)
+        assert len(gathered) == world * K
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    import ctypes as C
+    avg_ms, launches = C.c_double(), C.c_int64()
+    _lib.check(_lib.lib().avc_timing_read(ctx, 0, C.byref(avg_ms), C.byref(launches), 1))
+    N = res ** 3
+    achieved = N * FLOP_PER_POINT / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
+
+    if rank == 0:
+        line = {
+            'metric': 'reconstructed-mesh frames/sec at 256^3 grid (avatar occupancy-only, dense query + marching cubes + LBS)',
+            'value': world * K / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (products as 3 split-fp16 MFMA passes, fp32 accumulate)', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[1]: AvatarNet occupancy-only, {res}^3 grid dense ({N} points/frame), random SMPL pose, '
+                                   f'UNet7DS + fused query + marching cubes + normals + KNN-4 LBS per frame',
+                       'grid': [res] * 3, 'points_per_frame': N, 'vertices_last_frame': int(out['cano_v'].shape[0]),
+                       'faces_last_frame': int(out['f'].shape[0]), 'parallelism': f'frame-sharded x{world}'},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F16_TFLOPS, 'traffic': None,
+                         'kernel': 'avc::avatar_kernel<true,false>', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
+                         'algorithmic_flop_per_launch': N * FLOP_PER_POINT,
+                         'mfma_issued_tflops': N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0,
+                         'mfma_util': (N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 / PEAK_F16_TFLOPS) if avg_ms.value > 0 else 0.0,
+                         'fp32_mfma_peak_equiv': achieved / 157.3},
+        }
+        if world == 1 and not args.no_masked:
+            try:
+                line['masked'] = masked_run(res, device, K, W)
+            except Exception as e:       # informational leg only
+                line['masked'] = {'error': repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(pipe, sd, out, res)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def masked_run(res, device, K, W):
+    """Same frame with the reference's valid-band masking (informational)."""
+    from avatarcap_amd.dataset import to_cuda
+    pipe, _ = build_pipeline(res, 'band', K + W, device)
+    items = [to_cuda(pipe.ds[s], add_batch=True) for s in range(K + W)]
+    for s in range(W):
+        out = pipe.avatar_frame(items[s])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(W, W + K):
+        out = pipe.avatar_frame(items[s])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'value': K / dt, 'unit': 'frames/s', 'valid_points': int(pipe.ds.infer_pts.shape[0]),
+            'valid_fraction': float(pipe.ds.infer_pts.shape[0]) / res ** 3, 'vertices_last_frame': int(out['cano_v'].shape[0])}
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,22 @@
+"""Scratch timing of the fused avatar query (not the bench contract)."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from avatarcap_amd import config, synthetic as syn
+config.cfg = config.default_cfg()
+import golden_inputs as gi
+from common import geotex_sd
+from avatarcap_amd.network.arch_avatar import GeoTexAvatar, OccupancyNet
+net = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume()).to('cuda').eval()
+net.load_state_dict({k: torch.from_numpy(v) for k, v in geotex_sd().items()})
+net.warping_field.pose_feat_map = torch.from_numpy(gi.pose_feat_map()[None]).cuda()
+from avatarcap_amd.grid import generate_volume_points
+for res in (128, 256):
+    pts = generate_volume_points(syn.CANO_BOUNDS, (res, res, res), 'cuda')[None]
+    batch = {'cano_pts': pts, 'cano_smpl_center': torch.from_numpy(gi.center()[None]).cuda()}
+    o = OccupancyNet(net).query(batch); torch.cuda.synchronize()
+    t0 = time.time(); reps = 3
+    for _ in range(reps): o = OccupancyNet(net).query(batch)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / reps
+    n = res ** 3
+    print(f'res {res}: {dt*1e3:.2f} ms  {n/dt/1e6:.1f} Mpts/s  {n*1773568/dt/1e12:.1f} TFLOP/s algorithmic  ({n*1773568*3/dt/1e12:.0f} issued)', flush=True)
