@@ -1,0 +1,124 @@
+"""Host-side logic and the C-ABI surface.  CPU only (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from avatarcap_amd import config, synthetic as syn
+from common import geotex_shapes, maxabs
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def test_library_exports_every_declared_symbol():
+    from avatarcap_amd import _lib
+    lib = _lib.lib()
+    hdr = open(os.path.join(ROOT, 'include', 'avcap.h')).read()
+    declared = set(re.findall(r'\b(avc_[a-z_0-9]+)\s*\(', hdr))
+    assert len(declared) >= 18
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert declared == set(_lib.exported_symbols())
+    assert lib.avc_version() == 100
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_product_path_fails_loudly_without_gpu():
+    from avatarcap_amd import _lib
+    h = ctypes.c_void_p()
+    rc = _lib.lib().avc_ctx_create(0, ctypes.byref(h))
+    assert rc != 0 and len(_lib.lib().avc_last_error()) > 0
+    with pytest.raises(Exception):
+        _lib.ctx(torch.device('cpu'))
+    config.cfg = config.default_cfg()
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar, OccupancyNet
+    net = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume())
+    net.warping_field.pose_feat_map = torch.zeros(1, 64, 256, 256)
+    with pytest.raises(Exception):     # no eager fallback exists
+        OccupancyNet(net).query({'cano_pts': torch.zeros(1, 8, 3), 'cano_smpl_center': torch.zeros(1, 3)})
+    from avatarcap_amd.network.mlp import MLP
+    with pytest.raises(RuntimeError):
+        MLP(3, 1, [4])(torch.zeros(1, 3, 2))
+
+
+def test_state_dict_surface_matches_reference_checkpoints():
+    """125 keys for net.pt, 214 for recon_net.pt, exact shapes of the hot-path tensors."""
+    sh = geotex_shapes()
+    assert len(sh) == 125
+    assert sh['cano_template.shared_mlp.fc_list.4.0.weight'] == (256, 319, 1)
+    assert sh['cano_template.shared_mlp.fc_list.6.weight'] == (256, 256, 1)
+    assert sh['cano_template.geo_mlp.fc_list.1.weight'] == (2, 128, 1)
+    assert sh['cano_template.clr_mlp.fc_list.2.weight'] == (3, 128, 1)
+    assert sh['warping_field.mlp.conv1.weight'] == (256, 67, 1)
+    assert sh['warping_field.mlp.conv5.weight'] == (256, 323, 1)
+    assert sh['warping_field.mlp.bn7.running_var'] == (256,)
+    assert sh['warping_field.out_layer_coord_affine.weight'] == (3, 256, 1)
+    assert 'warping_field.unet.upconv4.up.weight' in sh            # dead weights stay loadable (unets.py:188)
+    assert sum(k.startswith('warping_field.unet.') for k in sh) == 50
+    from avatarcap_amd.network.arch_recon import ReconNetwork
+    rs = syn.module_shapes(ReconNetwork())
+    assert len(rs) == 214
+    assert rs['image_decoder.fc_list.1.0.weight_v'] == (256, 545, 1) and rs['image_decoder.fc_list.1.0.weight_g'] == (256, 1, 1)
+    assert rs['image_decoder.fc_list.3.weight'] == (1, 128, 1)
+    assert sum(k.startswith('image_encoder.') for k in rs) == 203
+
+
+def test_config_surface(tmp_path):
+    cfg = config.load_config(os.path.join(ROOT, 'configs', 'example.yaml'))
+    assert cfg['testing']['vol_res'] == [384, 384, 128]
+    assert cfg['model']['cano_template']['pos_encoding'] == 10 and cfg['model']['warping_field']['pos_encoding'] == 0
+    assert config.if_type == 'sdf' and config.iso_value == 0. and config.sdf_thres == 0.1 and config.N_samples == 64
+    with pytest.raises(ValueError):
+        config._iso_for('bogus')
+
+
+def test_producers_match_reference_golden(golden):
+    """UNet7DS (incl. the upconv3-twice quirk) and HGFilter definitions vs the reference, on CPU."""
+    from avatarcap_amd.network.unets import UnetNoCond7DS
+    from avatarcap_amd.network.HGFilters import HGFilter
+    torch.set_grad_enabled(False)
+    un = UnetNoCond7DS(input_nc=6, output_nc=64, nf=32).eval()
+    syn.load_synth(un, gi.SEED_NET)
+    y = un(torch.from_numpy(gi.pos_map(128)[None])).numpy()[0]
+    g = golden['G7_unet_samples']
+    assert maxabs(y[:, gi.PIX[:, 0] % 128, gi.PIX[:, 1] % 128], g) < 1e-4 * max(1.0, np.abs(g).max())
+    hg = HGFilter(1, 4, 6, 32, 'group', 'no_down', False).eval()
+    syn.load_synth(hg, gi.SEED_NET)
+    y = hg(torch.from_numpy(gi.normal_maps(64)[None]))[0][-1].numpy()[0]
+    g = golden['G7_hg_samples']
+    assert maxabs(y[:, gi.PIX[:, 0] % 32, gi.PIX[:, 1] % 32], g) < 1e-4 * max(1.0, np.abs(g).max())
+    with pytest.raises(NotImplementedError):
+        HGFilter(2, 4, 6, 32, 'group', 'conv64', False)
+
+
+def test_synthetic_body_and_pose():
+    b = syn.synthetic_body()
+    assert b['cano_smpl_v'].shape == (6890, 3) and b['skin_weights'].shape == (6890, 24)
+    assert np.allclose(b['skin_weights'].sum(1), 1, atol=1e-5)
+    lo, hi = syn.CANO_BOUNDS
+    assert np.all(b['cano_smpl_v'] >= lo) and np.all(b['cano_smpl_v'] <= hi)
+    d = np.abs(syn.body_sdf(b['cano_smpl_v']))
+    assert np.percentile(d, 99) < 0.01 and d.max() < 0.06      # a few extremities are clipped into the bounds
+    jm = syn.random_pose_jnt_mats(3)
+    assert jm.shape == (24, 4, 4) and np.allclose(jm[:, 3], [0, 0, 0, 1])
+    R = jm[:, :3, :3]
+    assert np.allclose(np.einsum('jab,jcb->jac', R, R), np.eye(3), atol=1e-5)
+    ident = syn.random_pose_jnt_mats(3, sigma=0.0)
+    assert np.allclose(ident, np.eye(4), atol=1e-6)
+
+
+def test_dense_dataset_item_keys_cpu():
+    from avatarcap_amd.dataset import SyntheticTestDataset
+    config.cfg = config.default_cfg()
+    ds = SyntheticTestDataset([6, 5, 4], valid='dense', n_frames=2, device='cpu')
+    it = ds[1]
+    for k in ('cano_pts', 'valid_pts_flag', 'smpl_pos_map', 'cano_smpl_center', 'cano_bounds', 'cano2live_jnt_mats'):
+        assert k in it
+    assert it['cano_pts'].shape == (120, 3) and it['smpl_pos_map'].shape == (6, 256, 256)
+    assert it['cano2live_jnt_mats'].shape == (24, 4, 4)
+    with pytest.raises(ValueError):
+        SyntheticTestDataset([4, 4, 4], valid='nope', device='cpu')

@@ -1,0 +1,66 @@
+"""Frame sharding + mesh all-gather over torch.distributed with the gloo backend, world_size 2,
+on CPU (the N > 1 path of bench.py; RCCL on the GPU box).  CPU only."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from avatarcap_amd.parallel import all_gather_meshes, shard_frames
+
+
+def _mesh(frame):
+    rs = np.random.RandomState(100 + frame)
+    V, F = 5 + 3 * frame, 2 + frame * (frame % 3)
+    return {'v': torch.from_numpy(rs.randn(V, 3).astype(np.float32)), 'vn': torch.from_numpy(rs.randn(V, 3).astype(np.float32)),
+            'f': torch.from_numpy(rs.randint(0, V, (F, 3)).astype(np.int32))}
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        mine = [_mesh(f) for f in shard_frames(n_frames, rank, world)]
+        out = all_gather_meshes(mine, n_frames)
+        ok = len(out) == n_frames
+        for f, m in enumerate(out):
+            ref = _mesh(f)
+            ok = ok and all(torch.equal(m[k], ref[k]) for k in ('v', 'vn', 'f'))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_shard_frames():
+    assert shard_frames(7, 0, 2) == [0, 2, 4, 6] and shard_frames(7, 1, 2) == [1, 3, 5]
+    assert sorted(sum((shard_frames(64, r, 8) for r in range(8)), [])) == list(range(64))
+    assert shard_frames(1, 3, 8) == []
+
+
+@pytest.mark.parametrize('n_frames', [5, 2])
+def test_all_gather_meshes_world2(n_frames):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_all_gather_single_process_is_identity():
+    m = [_mesh(0), _mesh(1)]
+    assert all_gather_meshes(m, 2) is not m and len(all_gather_meshes(m, 2)) == 2
