@@ -3,22 +3,28 @@
 //                   (reference network/arch_avatar.py:356-381, :113-140, :65-83)
 //   recon_kernel  : ReconNetwork.infer's decoder loop (network/arch_recon.py:55-73)
 //
-// Design (DESIGN.md section "fused MLP"):
-//   * one workgroup = 4 waves (one per SIMD, ~400 VGPRs each), persistent over 128-point tiles;
+// Design:
+//   * one workgroup = 4 waves (one per SIMD, ~450 VGPRs each), persistent over 128-point tiles;
 //     a wave owns 32 points and ALL hidden channels of them, so the whole 17-layer chain runs
 //     out of registers: the D tile of one layer is, register for register, the B operand of the
 //     next (mlp_layout.h).  No activation ever touches LDS or HBM.
 //   * arithmetic: every fp32 product a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with
 //     (hi, lo) fp16 pairs on v_mfma_f32_32x32x16_f16, fp32 accumulation (22+ significant bits,
 //     ~1e-6 relative; the parity bar is 1e-4 absolute).  3 MFMA passes at 16x the fp32-MFMA rate.
-//   * weights (3.5 MB, pre-split and pre-permuted by pack.cpp) stream L2 -> LDS with
+//   * weights (3.6 MB, pre-split and pre-permuted by pack.cpp) stream L2 -> LDS with
 //     global_load_lds_dwordx4 into a 2 x 64 KiB ring, one chunk ahead of the MFMAs that read it
 //     (ds_read_b128, lane-linear => conflict-free); one barrier per chunk.
-//   * prologue/epilogue work is fused: bilinear gather of the channel-last feature map,
-//     positional encoding (accurate sincosf), bias (accumulator init), Softplus / ReLU /
-//     LeakyReLU(0.02) / Sigmoid, the fp16 re-split, and the p + offset hand-off in fp32.
+//   * everything is a compile-time unrolled sequence of CHUNK STEPS.  Inside a chunk every k-step
+//     issues, in the shadow of its 3*TPC MFMAs: the LDS reads of the next k-step's A fragments, a
+//     slice of the next chunk's global->LDS prefetch, and a slice of the PREVIOUS tile pair's
+//     epilogue (bias is the accumulator init; scale, activation, fp16 re-split), so VALU / LDS /
+//     VMEM work hides behind the matrix pipe instead of serialising with it.
+//   * fused prologue: bilinear gather of the channel-last feature map, positional encoding
+//     (accurate sincosf), the p + offset hand-off in fp32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <utility>
 
 #include "avcap_internal.h"
 #include "mlp_layout.h"
@@ -35,7 +41,12 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SOFTPLUS = 3 };
 
 constexpr int WAVES = 4;
 constexpr int TILE_PTS = 32 * WAVES;
-constexpr int LDS_BYTES = 2 * layout::SLOT_BYTES;
+constexpr int PARK_BASE = 2 * layout::SLOT_BYTES;     // per-wave 8 KiB: 4 input k-steps parked in LDS (see ParkIn)
+constexpr int PARK_PER_WAVE = 4 * layout::UNIT_BYTES;
+constexpr int LDS_BYTES = PARK_BASE + WAVES * PARK_PER_WAVE;   // 128 KiB weight ring + 32 KiB = the whole 160 KiB
+constexpr int PIECE = WAVES * 1024;          // bytes one round of 4 wave-wide glds instructions moves
+
+constexpr int chunk_bytes(int ks, int tpc) { return ks * tpc * layout::UNIT_BYTES; }
 
 struct QueryParams {
     const float *pts;        // (n,3)
@@ -44,8 +55,7 @@ struct QueryParams {
     int H, W;
     float cx, cy, cz;
     const char *wstream;
-    const ChunkDesc *chunks;
-    int nchunks;
+    unsigned stream_bytes;   // bytes of one pass over the network (the prefetcher wraps here)
     const float *bias;
     float oscale[24];
     float *out0;             // occ / recon value (n)
@@ -55,102 +65,129 @@ struct QueryParams {
     int64_t ntiles;
 };
 
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+struct NoSide { template <class K> __device__ __forceinline__ void operator()(K) const {} };
+
+// B-operand providers of a chunk: k-step K -> fragment.
+struct RegIn {                       // activations living in registers
+    const Frag *f;
+    template <int K> __device__ __forceinline__ Frag get() const { return f[K]; }
+};
+// The network inputs (sampled features / positional encoding) are needed twice, several layers
+// apart (conv1 & conv5, shared.0 & shared.4).  Keeping them in VGPRs across the layers in between
+// pushes the kernel over the 512-register budget, so their first 4 k-steps are parked in the
+// wave's private 8 KiB of LDS (lane-linear 1 KiB blocks, conflict-free) and re-read just in time;
+// an optional 5th k-step (raw xyz, mostly zeros) stays in registers.
+struct ParkIn {
+    unsigned base;                   // PARK_BASE + wave * PARK_PER_WAVE + lane * 16
+    const Frag *extra;               // k-step 4 (may be null when KS == 4)
+    template <int K> __device__ __forceinline__ Frag get() const
+    {
+        extern __shared__ __attribute__((aligned(16))) char smem[];
+        if constexpr (K < 4) {
+            Frag r;
+            r.hi = *reinterpret_cast<const half8 *>(smem + base + K * layout::UNIT_BYTES);
+            r.lo = *reinterpret_cast<const half8 *>(smem + base + K * layout::UNIT_BYTES + 1024);
+            return r;
+        } else {
+            return *extra;
+        }
+    }
+};
+__device__ __forceinline__ void park_store(unsigned base, int k, const Frag &f)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    *reinterpret_cast<half8 *>(smem + base + k * layout::UNIT_BYTES) = f.hi;
+    *reinterpret_cast<half8 *>(smem + base + k * layout::UNIT_BYTES + 1024) = f.lo;
+}
+
 // ------------------------------------------------------------------------------------------
-// weight stream: 2-slot LDS ring, one chunk of prefetch
+// weight stream: 2-slot LDS ring, one chunk of prefetch, sizes known at compile time
 // ------------------------------------------------------------------------------------------
 struct Stream {
-    const char *g;
-    const ChunkDesc *tab;
-    int nch, c;          // c = chunk about to be consumed
-    unsigned parity;     // ring slot of chunk c
-    int wave, lane;
+    const char *gs;          // weight stream (wave-uniform: stays in SGPRs, glds uses the saddr form)
+    unsigned voff;           // per-lane source offset: wave*1024 + lane*16
+    unsigned total;          // bytes per pass
+    unsigned pf_off;         // offset of the next chunk to prefetch
+    unsigned parity;         // ring slot of the chunk about to be consumed
+    unsigned wave_off;       // wave * 1024
+    unsigned lane_off;       // lane * 16
 };
 
-__device__ __forceinline__ void stream_issue(const Stream &s, int chunk, unsigned slot)
+__device__ __forceinline__ void glds16(const char *sbase, unsigned voff, unsigned lds_byte)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const ChunkDesc d = s.tab[chunk];
-    const char *src = s.g + d.offset + s.lane * 16;
-    char *dst = smem + slot * layout::SLOT_BYTES;
-    for (unsigned o = s.wave * 1024u; o < d.bytes; o += WAVES * 1024u)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + o),
-                                         (__attribute__((address_space(3))) void *)(dst + o), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sbase + voff),
+                                     (__attribute__((address_space(3))) void *)(smem + lds_byte), 16, 0, 0);
 }
 
-// Make chunk c readable (its loads were issued one chunk earlier), start loading chunk c+1 into
-// the slot every wave has just finished reading, and return the LDS byte offset of chunk c.
-__device__ __forceinline__ unsigned stream_acquire(Stream &s)
+// One chunk step: KS k-steps x TPC output tiles (units k-major in LDS).  While it computes, it
+// prefetches the next chunk (NEXT_BYTES, compile-time) and runs `side(k)` once per k-step.
+template <int KS, int TPC, int NEXT_BYTES, class In, class Side>
+__device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restrict__ acc, Side &&side)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(NEXT_BYTES % PIECE == 0, "chunk sizes are multiples of 4 KiB");
+    // acquire: this chunk's loads (issued during the previous chunk) have landed for every wave, and
+    // every wave has finished reading the other slot
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int nc = s.c + 1;
-    if (nc == s.nch) nc = 0;
-    stream_issue(s, nc, s.parity ^ 1u);
-    const unsigned base = s.parity * layout::SLOT_BYTES + s.lane * 16;
-    s.c = nc;
-    s.parity ^= 1u;
-    return base;
-}
+    // Values every address of this chunk derives from are made opaque HERE, after the barrier: with
+    // everything unrolled and compile-time, the compiler otherwise hoists the address arithmetic of all
+    // ~60 chunks of a tile (hundreds of 64-bit values) to the top of the tile loop and spills them.
+    unsigned base = s.parity * layout::SLOT_BYTES + s.lane_off;
+    unsigned so = s.pf_off;
+    unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES + s.wave_off;
+    asm volatile("" : "+v"(base), "+s"(so), "+s"(dst));
+    const char *src = s.gs + so;
+    constexpr int NP = NEXT_BYTES / PIECE;                       // glds instructions per wave
+    constexpr int WIN = KS > 1 ? KS - 1 : 1;                     // issue them over the first KS-1 k-steps
+    constexpr int PPK = (NP + WIN - 1) / WIN;
 
-// ------------------------------------------------------------------------------------------
-// MFMA over one chunk: KS k-steps x TPC output tiles, units ordered k-major
-// ------------------------------------------------------------------------------------------
-template <int KS, int TPC>
-__device__ __forceinline__ void mma_chunk(unsigned base, const Frag *__restrict__ in, f32x16 *__restrict__ acc)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // software pipeline: the A fragments of k-step k+1 are fetched from LDS while the 3*TPC MFMAs of
-    // k-step k issue; sched_barrier keeps the compiler from hoisting a whole chunk of ds_reads
-    // (64 fragments = 256 VGPRs) above the first MFMA.
     half8 ah[2][TPC], al[2][TPC];
+    Frag b[2];
+    b[0] = in.template get<0>();
 #pragma unroll
     for (int t = 0; t < TPC; ++t) {
         ah[0][t] = *reinterpret_cast<const half8 *>(smem + base + t * layout::UNIT_BYTES);
         al[0][t] = *reinterpret_cast<const half8 *>(smem + base + t * layout::UNIT_BYTES + 1024);
     }
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        const int cur = k & 1, nxt = cur ^ 1;
-        if (k + 1 < KS) {
+    static_for<KS>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int cur = k & 1, nxt = cur ^ 1;
+        if constexpr (k + 1 < KS) {
+            b[nxt] = in.template get<k + 1>();
 #pragma unroll
             for (int t = 0; t < TPC; ++t) {
                 ah[nxt][t] = *reinterpret_cast<const half8 *>(smem + base + ((k + 1) * TPC + t) * layout::UNIT_BYTES);
                 al[nxt][t] = *reinterpret_cast<const half8 *>(smem + base + ((k + 1) * TPC + t) * layout::UNIT_BYTES + 1024);
             }
         }
+        static_for<PPK>([&](auto pc) {
+            constexpr int piece = k * PPK + decltype(pc)::value;
+            if constexpr (piece < NP) glds16(src + piece * PIECE, s.voff, dst + piece * PIECE);
+        });
 #pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], in[k].hi, acc[t], 0, 0, 0);
+        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], b[cur].hi, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], in[k].lo, acc[t], 0, 0, 0);
+        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], b[cur].lo, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], in[k].hi, acc[t], 0, 0, 0);
+        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], b[cur].hi, acc[t], 0, 0, 0);
+        side(kc);
         __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// single output tile: two accumulators over even / odd k-steps break the dependent MFMA chain
-template <int KS>
-__device__ __forceinline__ f32x16 mma_head(unsigned base, const Frag *__restrict__ in, f32x16 init)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x16 a0 = init, a1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a1[r] = 0.f;
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        const half8 ah = *reinterpret_cast<const half8 *>(smem + base + k * layout::UNIT_BYTES);
-        const half8 al = *reinterpret_cast<const half8 *>(smem + base + k * layout::UNIT_BYTES + 1024);
-        if (k & 1) {
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].hi, a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].lo, a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[k].hi, a1, 0, 0, 0);
-        } else {
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].hi, a0, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].lo, a0, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[k].hi, a0, 0, 0, 0);
-        }
-    }
-    return a0 + a1;
+    });
+    const unsigned no = s.pf_off + NEXT_BYTES;
+    s.pf_off = no >= s.total ? 0u : no;
+    s.parity ^= 1u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -198,49 +235,123 @@ __device__ __forceinline__ void split8(const float *v, half8 &hi, half8 &lo)
     }
 }
 
-// accumulator tile -> activation -> the two B fragments it becomes for the next layer
-template <int ACT>
-__device__ __forceinline__ void tile_to_frags(const f32x16 &acc, float oscale, Frag &f0, Frag &f1)
+// Slice K of NS of the epilogue of a tile pair: accumulators -> scale -> activation -> split fp16,
+// written into the 4 B fragments (k-steps) the pair becomes for the next layer.  32 values per lane.
+template <int ACT, int NS, int K>
+__device__ __forceinline__ void epi_slice(const f32x16 *__restrict__ acc, float oscale, Frag *__restrict__ out4)
 {
-    float v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = act_f<ACT>(acc[r] * oscale);
-    split8(v, f0.hi, f0.lo);
-    split8(v + 8, f1.hi, f1.lo);
+    constexpr int VPS = (32 + NS - 1) / NS;
+    static_for<VPS>([&](auto ic) {
+        constexpr int v = K * VPS + decltype(ic)::value;
+        if constexpr (K < NS && v < 32) {
+            constexpr int t = v >> 4, r = v & 15;
+            const float x = act_f<ACT>(acc[t][r] * oscale);
+            const _Float16 hh = (_Float16)x;
+            out4[2 * t + (r >> 3)].hi[r & 7] = hh;
+            out4[2 * t + (r >> 3)].lo[r & 7] = (_Float16)(x - (float)hh);
+        }
+    });
 }
+
+// deferred epilogue of a layer's LAST tile pair, to be run inside the first chunk of the next layer
+template <int ACT, int NS>
+struct Pending {
+    const f32x16 *acc;
+    float oscale;
+    Frag *out4;
+    template <class KC>
+    __device__ __forceinline__ void operator()(KC) const { epi_slice<ACT, NS, KC::value>(acc, oscale, out4); }
+};
 
 // ------------------------------------------------------------------------------------------
 // dense layers
 // ------------------------------------------------------------------------------------------
 // NT output tiles (even), evaluated two at a time; up to two input segments accumulate into the
-// same tiles (the reference's torch.cat on the channel axis).
-template <int NT, int KS0, int KS1, int ACT>
-__device__ __forceinline__ void dense(Stream &s, const Frag *__restrict__ in0, const Frag *__restrict__ in1,
-                                      Frag *__restrict__ out, const float *bias, float oscale, int h)
+// same tiles (the reference's torch.cat on the channel axis).  The epilogue of pair p runs inside
+// the first chunk of pair p+1; the last pair's accumulators are handed back in `pend` and the caller
+// schedules their epilogue (Pending) into whatever chunk comes next.  `pre` is such deferred work
+// from the previous layer.  NEXT_BYTES = size of the chunk that follows this layer in the stream.
+template <int NT, int KS0, int KS1, int ACT, int NEXT_BYTES, class In0, class In1, class Pre>
+__device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
+                                      Frag *__restrict__ out, const float *bias, float oscale, int h,
+                                      Pre &&pre, f32x16 *__restrict__ pend)
 {
-#pragma unroll
-    for (int p = 0; p < NT / 2; ++p) {
+    constexpr int NPAIR = NT / 2;
+    constexpr int B0 = chunk_bytes(KS0, 2), B1 = chunk_bytes(KS1, 2);
+    constexpr int NS = KS0 < 16 ? KS0 : 16;
+    f32x16 prev[2];
+    static_for<NPAIR>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
         f32x16 acc[2];
         acc[0] = bias_tile(bias + (2 * p) * 32, h);
         acc[1] = bias_tile(bias + (2 * p + 1) * 32, h);
-        unsigned base = stream_acquire(s);
-        mma_chunk<KS0, 2>(base, in0, acc);
-        if constexpr (KS1 > 0) {
-            base = stream_acquire(s);
-            mma_chunk<KS1, 2>(base, in1, acc);
+        constexpr int after0 = KS1 > 0 ? B1 : (p + 1 < NPAIR ? B0 : NEXT_BYTES);
+        if constexpr (p == 0) {
+            chunk<KS0, 2, after0>(s, in0, acc, pre);
+        } else {
+            chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc) { epi_slice<ACT, NS, decltype(kc)::value>(prev, oscale, out + 4 * (p - 1)); });
         }
-        tile_to_frags<ACT>(acc[0], oscale, out[4 * p + 0], out[4 * p + 1]);
-        tile_to_frags<ACT>(acc[1], oscale, out[4 * p + 2], out[4 * p + 3]);
-    }
+        if constexpr (KS1 > 0) {
+            constexpr int after1 = p + 1 < NPAIR ? B0 : NEXT_BYTES;
+            chunk<KS1, 2, after1>(s, in1, acc, NoSide{});
+        }
+        prev[0] = acc[0]; prev[1] = acc[1];
+    });
+    pend[0] = prev[0]; pend[1] = prev[1];
 }
 
-// one-tile linear head (rows 0..31 of which only the first few are real); returns scaled outputs
-template <int KS>
-__device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, const float *bias, float oscale, int h)
+// run a deferred epilogue right away (no chunk to hide it in)
+template <int ACT>
+__device__ __forceinline__ void flush(const f32x16 *__restrict__ pend, float oscale, Frag *__restrict__ out4)
 {
-    const f32x16 init = bias_tile(bias, h);
-    const unsigned base = stream_acquire(s);
-    f32x16 a = mma_head<KS>(base, in, init);
+    static_for<4>([&](auto kc) { epi_slice<ACT, 4, decltype(kc)::value>(pend, oscale, out4); });
+}
+
+// one-tile linear head (rows 0..31 of which only the first few are real); two accumulators over
+// even / odd k-steps break the dependent MFMA chain.  Returns scaled outputs.
+template <int KS, int NEXT_BYTES, class Pre>
+__device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, const float *bias, float oscale, int h, Pre &&pre)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x16 a0 = bias_tile(bias, h), a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // Values every address of this chunk derives from are made opaque HERE, after the barrier: with
+    // everything unrolled and compile-time, the compiler otherwise hoists the address arithmetic of all
+    // ~60 chunks of a tile (hundreds of 64-bit values) to the top of the tile loop and spills them.
+    unsigned base = s.parity * layout::SLOT_BYTES + s.lane_off;
+    unsigned so = s.pf_off;
+    unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES + s.wave_off;
+    asm volatile("" : "+v"(base), "+s"(so), "+s"(dst));
+    const char *src = s.gs + so;
+    constexpr int NP = NEXT_BYTES / PIECE;
+    constexpr int PPK = (NP + KS - 2) / (KS - 1);
+    static_for<KS>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const half8 ah = *reinterpret_cast<const half8 *>(smem + base + k * layout::UNIT_BYTES);
+        const half8 al = *reinterpret_cast<const half8 *>(smem + base + k * layout::UNIT_BYTES + 1024);
+        static_for<PPK>([&](auto pc) {
+            constexpr int piece = k * PPK + decltype(pc)::value;
+            if constexpr (piece < NP) glds16(src + piece * PIECE, s.voff, dst + piece * PIECE);
+        });
+        pre(kc);
+        if constexpr (k & 1) {
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].hi, a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].lo, a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[k].hi, a1, 0, 0, 0);
+        } else {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].hi, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].lo, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[k].hi, a0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    const unsigned no = s.pf_off + NEXT_BYTES;
+    s.pf_off = no >= s.total ? 0u : no;
+    s.parity ^= 1u;
+    f32x16 a = a0 + a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] *= oscale;
     return a;
@@ -295,7 +406,7 @@ __device__ __forceinline__ void bilinear_frag(const Bilinear &b, int c, Frag &f)
 // NeRF positional encoding of q (3 floats) into the 4 k-steps of the PE layout (mlp_layout.h):
 // lane-half h evaluates arguments 15h .. 15h+14: coordinate i%3, frequency 2^(5h + i/3) -- exact
 // power-of-two scaling like the reference's x * freq (net_util.py:27-33), accurate sincosf.
-__device__ __forceinline__ void posenc(const float q[3], int h, Frag *__restrict__ P)
+__device__ __forceinline__ void posenc(const float q[3], int h, unsigned park)
 {
     float v[32];
     const float hs = h ? 32.0f : 1.0f;
@@ -310,22 +421,41 @@ __device__ __forceinline__ void posenc(const float q[3], int h, Frag *__restrict
     v[30] = h ? q[2] : q[0];
     v[31] = h ? 0.0f : q[1];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) split8(v + 8 * k, P[k].hi, P[k].lo);
+    for (int k = 0; k < 4; ++k) {
+        Frag f;
+        split8(v + 8 * k, f.hi, f.lo);
+        park_store(park, k, f);
+    }
+}
+
+__device__ __forceinline__ Stream stream_init(const QueryParams &p, int wave, int lane, int first_bytes)
+{
+    Stream s;
+    s.wave_off = wave * 1024u; s.lane_off = lane * 16u;
+    s.gs = p.wstream; s.voff = s.wave_off + s.lane_off;
+    s.total = p.stream_bytes; s.parity = 0;
+    for (int o = 0; o < first_bytes; o += PIECE) glds16(s.gs + o, s.voff, s.wave_off + o);     // chunk 0 -> slot 0
+    s.pf_off = first_bytes;
+    return s;
 }
 
 // ------------------------------------------------------------------------------------------
 // avatar query kernel
 // ------------------------------------------------------------------------------------------
+constexpr int B_MAIN = chunk_bytes(16, 2);       // 64 KiB: two tiles x 16 k-steps
+constexpr int B_IN67 = chunk_bytes(layout::IN67_KS, 2);
+constexpr int B_PE = chunk_bytes(layout::PE_KS, 2);
+constexpr int B_HEAD16 = chunk_bytes(16, 1), B_HEAD8 = chunk_bytes(8, 1);
+
 template <bool WARP, bool COLOUR>
 __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
+    constexpr int B_FIRST = WARP ? B_IN67 : B_PE;       // first chunk of a pass (the prefetcher wraps to it)
 
-    Stream s;
-    s.g = p.wstream; s.tab = p.chunks; s.nch = p.nchunks; s.c = 0; s.parity = 0; s.wave = wave; s.lane = lane;
-    stream_issue(s, 0, 0);
+    Stream s = stream_init(p, wave, lane, B_FIRST);
 
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int64_t pidx_raw = tile * TILE_PTS + wave * 32 + j;
@@ -334,48 +464,60 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         pt[0] = p.pts[pidx * 3 + 0]; pt[1] = p.pts[pidx * 3 + 1]; pt[2] = p.pts[pidx * 3 + 2];
 
         Frag X[16], Y[16];
+        unsigned park = PARK_BASE + wave * PARK_PER_WAVE + lane * 16;
+        asm volatile("" : "+v"(park));   // opaque per tile: otherwise every park address is hoisted out of the loop as its own VGPR
+        f32x16 pa[2], pb[2];             // deferred accumulators of a layer's last tile pair (ping/pong)
         const float *bias = p.bias;
         asm volatile("" : "+s"(bias));   // opaque per tile: stops LICM from hoisting ~60 tiles of bias loads out of the loop
-        int li = 0;                      // layer counter (oscale index); compile-time after unrolling
+        constexpr int LI = WARP ? 8 : 0; // oscale index of the first template layer
         float q[3] = {pt[0], pt[1], pt[2]};
         float off[3] = {0.f, 0.f, 0.f};
 
         if constexpr (WARP) {
             // ---- WarpingField.query (arch_avatar.py:113-140) ----
-            Frag S[layout::IN67_KS];
+            Frag S4;                         // k-step 4: raw xyz (pos_encoding 0); k-steps 0..3 are parked in LDS
             {
                 const Bilinear bl = bilinear_setup<64>(p.feat, p.H, p.W, pt[0] - p.cx, -(pt[1] - p.cy), 32 * h);   // :125-133
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { bilinear_frag(bl, 8 * k, S[k]); __builtin_amdgcn_sched_barrier(0); }
+                for (int k = 0; k < 4; ++k) { Frag f; bilinear_frag(bl, 8 * k, f); park_store(park, k, f); __builtin_amdgcn_sched_barrier(0); }
                 float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (h == 0) { z[0] = pt[0]; z[1] = pt[1]; z[2] = pt[2]; }                             // pos_encoding 0 => raw xyz
-                split8(z, S[4].hi, S[4].lo);
+                if (h == 0) { z[0] = pt[0]; z[1] = pt[1]; z[2] = pt[2]; }
+                split8(z, S4.hi, S4.lo);
             }
-            dense<8, layout::IN67_KS, 0, ACT_SOFTPLUS>(s, S, nullptr, X, bias, p.oscale[li], h); bias += 256; ++li;   // conv1+bn1
-            dense<8, 16, 0, ACT_SOFTPLUS>(s, X, nullptr, Y, bias, p.oscale[li], h); bias += 256; ++li;                 // conv2
-            dense<8, 16, 0, ACT_SOFTPLUS>(s, Y, nullptr, X, bias, p.oscale[li], h); bias += 256; ++li;                 // conv3
-            dense<8, 16, 0, ACT_SOFTPLUS>(s, X, nullptr, Y, bias, p.oscale[li], h); bias += 256; ++li;                 // conv4
-            dense<8, 16, layout::IN67_KS, ACT_SOFTPLUS>(s, Y, S, X, bias, p.oscale[li], h); bias += 256; ++li;         // conv5 on [x0|x4]
-            dense<8, 16, 0, ACT_SOFTPLUS>(s, X, nullptr, Y, bias, p.oscale[li], h); bias += 256; ++li;                 // conv6
-            dense<8, 16, 0, ACT_SOFTPLUS>(s, Y, nullptr, X, bias, p.oscale[li], h); bias += 256; ++li;                 // conv7
-            const f32x16 o = head<16>(s, X, bias, p.oscale[li], h); bias += 32; ++li;                                  // out_layer_coord_affine
+            const ParkIn S{park, &S4};
+            const RegIn RX{X}, RY{Y};
+            using SP = Pending<ACT_SOFTPLUS, 8>;
+            const float o0 = p.oscale[0], o1 = p.oscale[1], o2 = p.oscale[2], o3 = p.oscale[3], o4 = p.oscale[4], o5 = p.oscale[5], o6 = p.oscale[6];
+            dense<8, layout::IN67_KS, 0, ACT_SOFTPLUS, B_MAIN>(s, S, S, X, bias, o0, h, NoSide{}, pa); bias += 256;                       // conv1+bn1
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, o1, h, SP{pa, o0, X + 12}, pb); bias += 256;                        // conv2
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RY, RY, X, bias, o2, h, SP{pb, o1, Y + 12}, pa); bias += 256;                        // conv3
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, o3, h, SP{pa, o2, X + 12}, pb); bias += 256;                        // conv4
+            dense<8, 16, layout::IN67_KS, ACT_SOFTPLUS, B_MAIN>(s, RY, S, X, bias, o4, h, SP{pb, o3, Y + 12}, pa); bias += 256;           // conv5 on [x0|x4]
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, o5, h, SP{pa, o4, X + 12}, pb); bias += 256;                        // conv6
+            dense<8, 16, 0, ACT_SOFTPLUS, B_HEAD16>(s, RY, RY, X, bias, o6, h, SP{pb, o5, Y + 12}, pa); bias += 256;                      // conv7
+            const f32x16 o = head<16, B_PE>(s, X, bias, p.oscale[7], h, SP{pa, o6, X + 12}); bias += 32;                                  // out_layer_coord_affine
             // rows 0..2 live in lanes h == 0, regs 0..2: broadcast to the other half
             off[0] = __shfl(o[0], j, 64); off[1] = __shfl(o[1], j, 64); off[2] = __shfl(o[2], j, 64);
             q[0] = pt[0] + off[0]; q[1] = pt[1] + off[1]; q[2] = pt[2] + off[2];                                       // arch_avatar.py:372 (fp32 add)
         }
 
         // ---- DoubleTNet.forward (arch_avatar.py:65-83) ----
-        Frag P[layout::PE_KS];
-        posenc(q, h, P);                                                                                               // :70
-        dense<8, layout::PE_KS, 0, ACT_RELU>(s, P, nullptr, X, bias, p.oscale[li], h); bias += 256; ++li;             // shared 0
-        dense<8, 16, 0, ACT_RELU>(s, X, nullptr, Y, bias, p.oscale[li], h); bias += 256; ++li;
-        dense<8, 16, 0, ACT_RELU>(s, Y, nullptr, X, bias, p.oscale[li], h); bias += 256; ++li;
-        dense<8, 16, 0, ACT_RELU>(s, X, nullptr, Y, bias, p.oscale[li], h); bias += 256; ++li;
-        dense<8, 16, layout::PE_KS, ACT_RELU>(s, Y, P, X, bias, p.oscale[li], h); bias += 256; ++li;                  // shared 4 on [x|x0]
-        dense<8, 16, 0, ACT_RELU>(s, X, nullptr, Y, bias, p.oscale[li], h); bias += 256; ++li;
-        dense<8, 16, 0, ACT_NONE>(s, Y, nullptr, X, bias, p.oscale[li], h); bias += 256; ++li;                        // shared 6: no activation (mlp.py:46,64)
-        dense<4, 16, 0, ACT_LEAKY>(s, X, nullptr, Y, bias, p.oscale[li], h); bias += 128; ++li;                       // geo 0
-        const f32x16 g = head<8>(s, Y, bias, p.oscale[li], h); bias += 32; ++li;                                       // geo 1: row 0 = occ/sdf, row 1 = sigma
+        posenc(q, h, park);                                                                                            // :70 (parked in LDS)
+        const ParkIn P{park, nullptr};
+        const RegIn TX{X}, TY{Y};
+        using RP = Pending<ACT_RELU, 8>;
+        const float t0 = p.oscale[LI], t1 = p.oscale[LI + 1], t2 = p.oscale[LI + 2], t3 = p.oscale[LI + 3], t4 = p.oscale[LI + 4],
+                    t5 = p.oscale[LI + 5], t6 = p.oscale[LI + 6], g0 = p.oscale[LI + 7], g1 = p.oscale[LI + 8];
+        dense<8, layout::PE_KS, 0, ACT_RELU, B_MAIN>(s, P, P, X, bias, t0, h, NoSide{}, pa); bias += 256;                                 // shared 0
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, t1, h, RP{pa, t0, X + 12}, pb); bias += 256;
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TY, TY, X, bias, t2, h, RP{pb, t1, Y + 12}, pa); bias += 256;
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, t3, h, RP{pa, t2, X + 12}, pb); bias += 256;
+        dense<8, 16, layout::PE_KS, ACT_RELU, B_MAIN>(s, TY, P, X, bias, t4, h, RP{pb, t3, Y + 12}, pa); bias += 256;                     // shared 4 on [x|x0]
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, t5, h, RP{pa, t4, X + 12}, pb); bias += 256;
+        dense<8, 16, 0, ACT_NONE, B_MAIN>(s, TY, TY, X, bias, t6, h, RP{pb, t5, Y + 12}, pa); bias += 256;                                // shared 6: no activation (mlp.py:46,64)
+        dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TX, TX, Y, bias, g0, h, Pending<ACT_NONE, 8>{pa, t6, X + 12}, pb); bias += 128;           // geo 0
+        constexpr int AFTER_GEO = COLOUR ? B_MAIN : B_FIRST;
+        const f32x16 g = head<8, AFTER_GEO>(s, Y, bias, g1, h, Pending<ACT_LEAKY, 4>{pb, g0, Y + 4}); bias += 32;                         // geo 1: row 0 = occ/sdf, row 1 = sigma
 
         const bool writer = (h == 0) && (pidx_raw < p.n);
         if (writer) {
@@ -383,9 +525,11 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             if (WARP && p.out1) { p.out1[pidx_raw * 3 + 0] = off[0]; p.out1[pidx_raw * 3 + 1] = off[1]; p.out1[pidx_raw * 3 + 2] = off[2]; }
         }
         if constexpr (COLOUR) {
-            dense<8, 16, 0, ACT_RELU>(s, X, nullptr, Y, bias, p.oscale[li], h); bias += 256; ++li;                    // clr 0
-            dense<4, 16, 0, ACT_RELU>(s, Y, nullptr, X, bias, p.oscale[li], h); bias += 128; ++li;                    // clr 1
-            const f32x16 c = head<8>(s, X, bias, p.oscale[li], h); bias += 32; ++li;                                   // clr 2
+            const float c0 = p.oscale[LI + 9], c1 = p.oscale[LI + 10], c2 = p.oscale[LI + 11];
+            // X (the shared feature) is complete: its last pair was finished inside geo 0's first chunk
+            dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, c0, h, NoSide{}, pa); bias += 256;                                      // clr 0
+            dense<4, 16, 0, ACT_RELU, B_HEAD8>(s, TY, TY, X, bias, c1, h, RP{pa, c0, Y + 12}, pb); bias += 128;                           // clr 1
+            const f32x16 c = head<8, B_FIRST>(s, X, bias, c2, h, Pending<ACT_RELU, 4>{pb, c1, X + 4}); bias += 32;                        // clr 2
             if (writer && p.out2) {
                 f32x4 rgba = {sigmoid_f(c[0]), sigmoid_f(c[1]), sigmoid_f(c[2]), __builtin_fmaxf(g[1], 0.0f)};         // :75-76
                 *reinterpret_cast<f32x4 *>(p.out2 + pidx_raw * 4) = rgba;
@@ -401,15 +545,16 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
 // res @ 1,2, sigmoid.  fc0 is produced in two 256-channel halves so that fc1 can consume each half
 // while it is the only hidden state alive (see pack.cpp::pack_recon for the matching stream order).
 // ------------------------------------------------------------------------------------------
+constexpr int B_IN33 = chunk_bytes(layout::IN33_KS, 2);
+constexpr int B_WIDE4 = chunk_bytes(4, 8), B_WIDE_IN33 = chunk_bytes(layout::IN33_KS, 8);
+
 __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
 
-    Stream s;
-    s.g = p.wstream; s.tab = p.chunks; s.nch = p.nchunks; s.c = 0; s.parity = 0; s.wave = wave; s.lane = lane;
-    stream_issue(s, 0, 0);
+    Stream s = stream_init(p, wave, lane, B_IN33);
 
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int64_t pidx_raw = tile * TILE_PTS + wave * 32 + j;
@@ -426,144 +571,41 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
             split8(z, I[2].hi, I[2].lo);
         }
         Frag X[16], Y[16];
+        const RegIn RI{I}, RX{X}, RY{Y};
+        f32x16 pend[2];
         const float *bias = p.bias;
         asm volatile("" : "+s"(bias));   // see avatar_kernel
         f32x16 acc[8];
+        const float s0 = p.oscale[0], s1 = p.oscale[1], s2 = p.oscale[2], s4 = p.oscale[4], s5 = p.oscale[5];
         // fc0 rows 0..255
-        dense<8, layout::IN33_KS, 0, ACT_LEAKY>(s, I, nullptr, X, bias, p.oscale[0], h); bias += 256;
+        dense<8, layout::IN33_KS, 0, ACT_LEAKY, B_WIDE4>(s, RI, RI, X, bias, s0, h, NoSide{}, pend); bias += 256;
+        flush<ACT_LEAKY>(pend, s0, X + 12);
         // fc1 partial over x[0..255]: 8 tiles live, 4 k-steps per chunk
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] = bias_tile(bias + 32 * t, h);
         bias += 256;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { const unsigned base = stream_acquire(s); mma_chunk<4, 8>(base, X + 4 * c, acc); }
+        chunk<4, 8, B_WIDE4>(s, RegIn{X}, acc, NoSide{});
+        chunk<4, 8, B_WIDE4>(s, RegIn{X + 4}, acc, NoSide{});
+        chunk<4, 8, B_WIDE4>(s, RegIn{X + 8}, acc, NoSide{});
+        chunk<4, 8, B_IN33>(s, RegIn{X + 12}, acc, NoSide{});
         // fc0 rows 256..511
-        dense<8, layout::IN33_KS, 0, ACT_LEAKY>(s, I, nullptr, X, bias, p.oscale[2], h); bias += 256;
+        dense<8, layout::IN33_KS, 0, ACT_LEAKY, B_WIDE4>(s, RI, RI, X, bias, s2, h, NoSide{}, pend); bias += 256;
+        flush<ACT_LEAKY>(pend, s2, X + 12);
         bias += 256;   // (zero bias block of the second fc1 pack call)
+        chunk<4, 8, B_WIDE4>(s, RegIn{X}, acc, NoSide{});
+        chunk<4, 8, B_WIDE4>(s, RegIn{X + 4}, acc, NoSide{});
+        chunk<4, 8, B_WIDE4>(s, RegIn{X + 8}, acc, NoSide{});
+        chunk<4, 8, B_WIDE_IN33>(s, RegIn{X + 12}, acc, NoSide{});
+        chunk<layout::IN33_KS, 8, B_MAIN>(s, RI, acc, NoSide{});
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const unsigned base = stream_acquire(s); mma_chunk<4, 8>(base, X + 4 * c, acc); }
-        { const unsigned base = stream_acquire(s); mma_chunk<layout::IN33_KS, 8>(base, I, acc); }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) tile_to_frags<ACT_LEAKY>(acc[t], p.oscale[1], Y[2 * t], Y[2 * t + 1]);
+        for (int t = 0; t < 8; t += 2) flush<ACT_LEAKY>(acc + t, s1, Y + 2 * t);
         // fc2 on [x(256) | in(33)] -> 128
-        dense<4, 16, layout::IN33_KS, ACT_LEAKY>(s, Y, I, X, bias, p.oscale[4], h); bias += 128;
-        const f32x16 o = head<8>(s, X, bias, p.oscale[5], h);
+        dense<4, 16, layout::IN33_KS, ACT_LEAKY, B_HEAD8>(s, RY, RI, X, bias, s4, h, NoSide{}, pend); bias += 128;
+        const f32x16 o = head<8, B_IN33>(s, X, bias, s5, h, Pending<ACT_LEAKY, 4>{pend, s4, X + 4});
         if (h == 0 && pidx_raw < p.n) p.out0[pidx_raw] = sigmoid_f(o[0]);                         // last_op sigmoid
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------
-// small helpers: NCHW -> HWC relayout, volume scatter
-// ------------------------------------------------------------------------------------------
-__global__ void nchw_to_hwc_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int HW)
-{
-    __shared__ float tile[64][65];
-    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 64 x 4
-    for (int r = ty; r < 64; r += 4) {
-        const int c = c0 + r, pp = p0 + tx;
-        tile[r][tx] = (c < C && pp < HW) ? src[(size_t)c * HW + pp] : 0.f;
-    }
-    __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        const int pp = p0 + r, c = c0 + tx;
-        if (c < C && pp < HW) dst[(size_t)pp * C + c] = tile[tx][r];
-    }
-}
-
-int launch_nchw_to_hwc(const float *src, float *dst, int C, int H, int W, hipStream_t s)
-{
-    const int HW = H * W;
-    dim3 grid((HW + 63) / 64, (C + 63) / 64);
-    hipLaunchKernelGGL(nchw_to_hwc_kernel, grid, dim3(256), 0, s, src, dst, C, HW);
-    AVC_HIP(hipGetLastError());
-    return AVC_OK;
-}
-
-// occ_volume[valid] = values (compacted order); occ_volume[~valid] = fill  (main.py:362-363).
-// Ranks come from a block-level prefix over the flags; three tiny kernels.
-__global__ void scatter_count_kernel(const uint8_t *__restrict__ valid, int64_t N, unsigned *__restrict__ block_counts)
-{
-    __shared__ unsigned wsum[4];
-    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
-    unsigned c = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) c += (i + k < N && valid[i + k]) ? 1u : 0u;
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-__global__ void scan_blocks_kernel(unsigned *__restrict__ counts, int nblocks)
-{
-    // single workgroup exclusive scan (nblocks up to a few hundred thousand): serial over chunks of 1024
-    __shared__ unsigned buf[1024];
-    __shared__ unsigned carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
-        const int i = b0 + threadIdx.x;
-        const unsigned v = i < nblocks ? counts[i] : 0u;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            unsigned t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0u;
-            __syncthreads();
-            buf[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nblocks) counts[i] = carry + buf[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += buf[1023];
-        __syncthreads();
-    }
-}
-
-__global__ void scatter_write_kernel(const uint8_t *__restrict__ valid, int64_t N, const unsigned *__restrict__ block_off,
-                                     const float *__restrict__ values, const float *__restrict__ fill, float *__restrict__ vol)
-{
-    __shared__ unsigned wsum[4];
-    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
-    unsigned f[4], c = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { f[k] = (i + k < N && valid[i + k]) ? 1u : 0u; c += f[k]; }
-    // exclusive prefix of c within the block
-    unsigned incl = c;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    unsigned wbase = 0;
-    for (int k = 0; k < w; ++k) wbase += wsum[k];
-    unsigned rank = block_off[blockIdx.x] + wbase + incl - c;      // # valid before element i
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (i + k < N) {
-            if (f[k]) { vol[i + k] = values[rank]; ++rank; }
-            else vol[i + k] = fill[(i + k) - rank];
-        }
-    }
-}
-
-static unsigned *g_scatter_scratch = nullptr;
-static size_t g_scatter_cap = 0;
-
-int launch_scatter(const uint8_t *valid, int64_t N, const float *values, const float *fill, float *vol, hipStream_t s)
-{
-    const int nblocks = (int)((N + 1023) / 1024);
-    if ((size_t)nblocks > g_scatter_cap) {
-        if (g_scatter_scratch) hipFree(g_scatter_scratch);
-        AVC_HIP(hipMalloc((void **)&g_scatter_scratch, sizeof(unsigned) * nblocks));
-        g_scatter_cap = nblocks;
-    }
-    hipLaunchKernelGGL(scatter_count_kernel, dim3(nblocks), dim3(256), 0, s, valid, N, g_scatter_scratch);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, g_scatter_scratch, nblocks);
-    hipLaunchKernelGGL(scatter_write_kernel, dim3(nblocks), dim3(256), 0, s, valid, N, g_scatter_scratch, values, fill, vol);
-    AVC_HIP(hipGetLastError());
-    return AVC_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -590,6 +632,13 @@ static int set_lds(K kernel)
     return AVC_OK;
 }
 
+static unsigned bytes_until(const PackedNet &net, size_t nchunks)
+{
+    unsigned b = 0;
+    for (size_t i = 0; i < nchunks && i < net.chunks.size(); ++i) b += net.chunks[i].bytes;
+    return b;
+}
+
 int launch_avatar(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], int occ_sigmoid,
                   float *occ, float *offset, float *rgba, bool template_only, hipStream_t s)
 {
@@ -601,17 +650,17 @@ int launch_avatar(avc_ctx *ctx, const float *pts, int64_t n, const float center[
     QueryParams p{};
     p.pts = pts; p.n = n; p.feat = ctx->pose_feat_hwc; p.H = ctx->pose_H; p.W = ctx->pose_W;
     p.cx = center ? center[0] : 0.f; p.cy = center ? center[1] : 0.f; p.cz = center ? center[2] : 0.f;
-    p.wstream = (const char *)net.d_stream; p.chunks = net.d_chunks; p.bias = net.d_bias;
+    p.wstream = (const char *)net.d_stream; p.bias = net.d_bias;
     AVC_REQUIRE(net.oscale.size() <= 24, AVC_ERR_STATE, "internal: too many layers");
     for (size_t i = 0; i < net.oscale.size(); ++i) p.oscale[i] = net.oscale[i];
     p.out0 = occ; p.out1 = offset; p.out2 = rgba; p.sigmoid_occ = occ_sigmoid;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;
     const bool colour = rgba != nullptr;
-    // the chunk table of a colour-capable stream ends with the clr chunks; a geometry-only launch
-    // simply wraps around before them (their count is fixed by pack.cpp: 2 + 2 + 1 chunks... see below)
-    int nch = (int)net.chunks.size();
-    if (net.has_colour && !colour) nch -= 4 + 2 + 1;   // clr0: 4 pair chunks, clr1: 2, clr2: 1
-    p.nchunks = nch;
+    // a colour-capable stream ends with the clr chunks (clr0: 4 pair chunks, clr1: 2, clr2: 1); a
+    // geometry-only launch wraps around before them
+    size_t nch = net.chunks.size();
+    if (net.has_colour && !colour) nch -= 4 + 2 + 1;
+    p.stream_bytes = bytes_until(net, nch);
     const int grid = (int)std::min<int64_t>(p.ntiles, ctx->num_cus);
     hipEvent_t e0, e1;
     timing_begin(ctx, 0, s, e0, e1);
@@ -639,9 +688,9 @@ int launch_recon(avc_ctx *ctx, const float *pts, int64_t n, const float center[3
     QueryParams p{};
     p.pts = pts; p.n = n; p.feat = ctx->img_feat_hwc; p.H = ctx->img_H; p.W = ctx->img_W;
     p.cx = center[0]; p.cy = center[1]; p.cz = center[2];
-    p.wstream = (const char *)net.d_stream; p.chunks = net.d_chunks; p.bias = net.d_bias;
+    p.wstream = (const char *)net.d_stream; p.bias = net.d_bias;
     for (size_t i = 0; i < net.oscale.size(); ++i) p.oscale[i] = net.oscale[i];
-    p.nchunks = (int)net.chunks.size();
+    p.stream_bytes = bytes_until(net, net.chunks.size());
     p.out0 = out;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;
     const int grid = (int)std::min<int64_t>(p.ntiles, ctx->num_cus);
