@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libavcap_hip.so')
+LIB_PATH = os.environ.get('AVCAP_LIB', os.path.join(_HERE, 'libavcap_hip.so'))   # override only for kernel A/B experiments
 
 AVC_ERR_CAPACITY = -4
 

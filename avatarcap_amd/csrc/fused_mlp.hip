@@ -29,13 +29,32 @@
 #include "avcap_internal.h"
 #include "mlp_layout.h"
 
+// Compile-time ablation knobs for kernel A/B timing (tools/ablate.sh).  All default to 0; any other
+// setting produces WRONG results and exists only to attribute time.
+#ifndef AVC_DBG_NO_PREFETCH
+#define AVC_DBG_NO_PREFETCH 0
+#endif
+#ifndef AVC_DBG_NO_BARRIER
+#define AVC_DBG_NO_BARRIER 0
+#endif
+#ifndef AVC_DBG_NO_SIDE
+#define AVC_DBG_NO_SIDE 0
+#endif
+#ifndef AVC_DBG_NO_MFMA
+#define AVC_DBG_NO_MFMA 0
+#endif
+
 namespace avc {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct Frag { half8 hi, lo; };   // B operand of one k-step: 16 K-slots x 32 points, split fp16
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// B operand of one k-step: 16 K-slots x 32 points as split fp16; each dword packs two halves
+struct Frag { u32x4 hi, lo; };
+__device__ __forceinline__ half8 as_half8(u32x4 v) { return __builtin_bit_cast(half8, v); }
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SOFTPLUS = 3 };
 
@@ -57,7 +76,6 @@ struct QueryParams {
     const char *wstream;
     unsigned stream_bytes;   // bytes of one pass over the network (the prefetcher wraps here)
     const float *bias;
-    float oscale[24];
     float *out0;             // occ / recon value (n)
     float *out1;             // offsets (n,3) or null
     float *out2;             // rgba (n,4) or null
@@ -95,8 +113,8 @@ struct ParkIn {
         extern __shared__ __attribute__((aligned(16))) char smem[];
         if constexpr (K < 4) {
             Frag r;
-            r.hi = *reinterpret_cast<const half8 *>(smem + base + K * layout::UNIT_BYTES);
-            r.lo = *reinterpret_cast<const half8 *>(smem + base + K * layout::UNIT_BYTES + 1024);
+            r.hi = *reinterpret_cast<const u32x4 *>(smem + base + K * layout::UNIT_BYTES);
+            r.lo = *reinterpret_cast<const u32x4 *>(smem + base + K * layout::UNIT_BYTES + 1024);
             return r;
         } else {
             return *extra;
@@ -106,8 +124,8 @@ struct ParkIn {
 __device__ __forceinline__ void park_store(unsigned base, int k, const Frag &f)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    *reinterpret_cast<half8 *>(smem + base + k * layout::UNIT_BYTES) = f.hi;
-    *reinterpret_cast<half8 *>(smem + base + k * layout::UNIT_BYTES + 1024) = f.lo;
+    *reinterpret_cast<u32x4 *>(smem + base + k * layout::UNIT_BYTES) = f.hi;
+    *reinterpret_cast<u32x4 *>(smem + base + k * layout::UNIT_BYTES + 1024) = f.lo;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -123,11 +141,32 @@ struct Stream {
     unsigned lane_off;       // lane * 16
 };
 
-__device__ __forceinline__ void glds16(const char *sbase, unsigned voff, unsigned lds_byte)
+// One prefetch instruction = 1 KiB per wave (64 lanes x 16 B).  A chunk is covered in GROUPS of 16 KiB
+// (a shorter last group for sizes that are not a multiple of 16 KiB): inside a group wave w owns a
+// contiguous quarter and walks it with the instruction's immediate offset (added to the global AND
+// the LDS address), so a group costs one address and one M0 set-up per wave, not one per instruction.
+template <int IMM>
+__device__ __forceinline__ void glds16(const char *src_lane, unsigned lds_wave_base)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sbase + voff),
-                                     (__attribute__((address_space(3))) void *)(smem + lds_byte), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
+                                     (__attribute__((address_space(3))) void *)(smem + lds_wave_base), 16, IMM, 0);
+}
+constexpr int GROUP = 16384;
+// instruction index i (0 .. bytes/4096-1) of a chunk of `bytes` -> group, position in group
+constexpr int pf_group(int i) { return i / 4; }
+constexpr int pf_group_bytes(int bytes, int g) { return bytes - g * GROUP >= GROUP ? GROUP : bytes - g * GROUP; }
+template <int BYTES, int I>
+__device__ __forceinline__ void prefetch_piece(const char *src, unsigned lane16, unsigned wave, unsigned dst_slot)
+{
+    // pieces are numbered group-major; a full group has 4 per wave, the last may have 1..3
+    constexpr int g = I / 4, j = I % 4;
+    constexpr int gb = pf_group_bytes(BYTES, g);
+    constexpr int per_wave = gb / WAVES;                 // bytes of this group owned by one wave
+    if constexpr (j * 1024 < per_wave) {
+        const unsigned woff = g * GROUP + wave * per_wave;
+        glds16<j * 1024>(src + woff + lane16, dst_slot + woff);
+    }
 }
 
 // One chunk step: KS k-steps x TPC output tiles (units k-major in LDS).  While it computes, it
@@ -139,19 +178,22 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
     static_assert(NEXT_BYTES % PIECE == 0, "chunk sizes are multiples of 4 KiB");
     // acquire: this chunk's loads (issued during the previous chunk) have landed for every wave, and
     // every wave has finished reading the other slot
+#if !AVC_DBG_NO_BARRIER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
     // Values every address of this chunk derives from are made opaque HERE, after the barrier: with
     // everything unrolled and compile-time, the compiler otherwise hoists the address arithmetic of all
     // ~60 chunks of a tile (hundreds of 64-bit values) to the top of the tile loop and spills them.
     unsigned base = s.parity * layout::SLOT_BYTES + s.lane_off;
     unsigned so = s.pf_off;
-    unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES + s.wave_off;
+    unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES;
     asm volatile("" : "+v"(base), "+s"(so), "+s"(dst));
     const char *src = s.gs + so;
-    constexpr int NP = NEXT_BYTES / PIECE;                       // glds instructions per wave
+    constexpr int NP = 4 * ((NEXT_BYTES + GROUP - 1) / GROUP);   // prefetch slots per wave (4 per 16 KiB group)
     constexpr int WIN = KS > 1 ? KS - 1 : 1;                     // issue them over the first KS-1 k-steps
     constexpr int PPK = (NP + WIN - 1) / WIN;
+    const unsigned wave = s.wave_off >> 10;
 
     half8 ah[2][TPC], al[2][TPC];
     Frag b[2];
@@ -174,15 +216,19 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
         }
         static_for<PPK>([&](auto pc) {
             constexpr int piece = k * PPK + decltype(pc)::value;
-            if constexpr (piece < NP) glds16(src + piece * PIECE, s.voff, dst + piece * PIECE);
+            if constexpr (piece < NP && !AVC_DBG_NO_PREFETCH) prefetch_piece<NEXT_BYTES, piece>(src, s.lane_off, wave, dst);
         });
 #pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], b[cur].hi, acc[t], 0, 0, 0);
+        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], b[cur].lo, acc[t], 0, 0, 0);
+        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].lo), acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], b[cur].hi, acc[t], 0, 0, 0);
+        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
+#if AVC_DBG_NO_SIDE
+        if constexpr (k == 0) side(kc);
+#else
         side(kc);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     });
     const unsigned no = s.pf_off + NEXT_BYTES;
@@ -199,19 +245,54 @@ __device__ __forceinline__ f32x16 bias_tile(const float *bias_rows, int h)
     f32x16 a;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(bias_rows + 8 * m + 4 * h);
+        const f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(
+            (const __attribute__((address_space(1))) float *)bias_rows + 8 * m + 4 * h);
         a[4 * m + 0] = v[0]; a[4 * m + 1] = v[1]; a[4 * m + 2] = v[2]; a[4 * m + 3] = v[3];
     }
     return a;
 }
 
-__device__ __forceinline__ float softplus_f(float x)
+// Bias sources for the accumulator init of a tile pair.
+//   BiasDirect : load when needed.  The loads sit right in front of the chunk's `vmcnt(0)` + barrier,
+//                so their full L2 latency is exposed once per pair (recon kernel: not the headline).
+//   BiasQueue  : the 64 floats of the NEXT pair are fetched right after the barrier of the CURRENT
+//                chunk and sit in 32 registers until needed; the table is in consumption order (pack.cpp)
+//                so "next" is simply the following block.  `rewind` restarts at the table head for the
+//                next point tile.  Removes a ~1-2 k cycle stall in front of every chunk.
+struct BiasDirect {
+    const float *p;
+    __device__ __forceinline__ void take(f32x16 *acc, int ntiles, int h)
+    {
+        acc[0] = bias_tile(p, h);
+        if (ntiles > 1) acc[1] = bias_tile(p + 32, h);
+        p += 32 * ntiles;
+    }
+    __device__ __forceinline__ void after_barrier(int) {}
+    __device__ __forceinline__ void rewind(const float *) {}
+};
+struct BiasQueue {
+    const float *next;       // block the registers were loaded from
+    f32x16 nb[2];
+    __device__ __forceinline__ void fetch(int h) { nb[0] = bias_tile(next, h); nb[1] = bias_tile(next + 32, h); }
+    __device__ __forceinline__ void take(f32x16 *acc, int ntiles, int)
+    {
+        acc[0] = nb[0];
+        if (ntiles > 1) acc[1] = nb[1];
+        next += 32 * ntiles;
+    }
+    __device__ __forceinline__ void after_barrier(int h) { fetch(h); }
+    __device__ __forceinline__ void rewind(const float *head) { next = head; }
+};
+
+__device__ __forceinline__ float softplus_f(float m)
 {
-    // torch.nn.Softplus(beta=1, threshold=20): x > 20 ? x : log1p(exp(x))   (network/mlp.py:99)
-    // = max(x,0) + ln2 * log2(1 + 2^(-|x| log2 e)); absolute error ~1e-7, see DESIGN.md
-    const float t = __builtin_amdgcn_exp2f(-1.44269504088896341f * __builtin_fabsf(x));
-    const float l = __builtin_amdgcn_logf(1.0f + t) * 0.69314718055994531f;
-    return __builtin_fmaxf(x, 0.0f) + l;
+    // torch.nn.Softplus(beta=1, threshold=20)   (network/mlp.py:99).  pack.cpp folds log2(e) into the
+    // weights/bias of every Softplus layer and ln(2) into its consumers, so the accumulator already is
+    // m = x*log2(e) and the activation carried between layers is y/ln2 = log2(1 + 2^m): v_exp_f32,
+    // v_add, v_log_f32.  m is clamped at 64, where 1 + 2^m == 2^m in fp32, so large x returns x (the
+    // reference's threshold branch) and nothing overflows; for very negative x the result underflows
+    // to 0 with absolute error < 1e-7.
+    return __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(__builtin_fminf(m, 64.0f)));
 }
 
 template <int ACT>
@@ -225,30 +306,46 @@ __device__ __forceinline__ float act_f(float x)
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-__device__ __forceinline__ void split8(const float *v, half8 &hi, half8 &lo)
+// (x0, x1) -> packed fp16 pair `hi` = RN(x) and packed `lo` = RN(x - hi): 3 VALU for two values
+// (v_cvt_pk_f16_f32 + two v_fma_mix*_f16 that take hi as an fp16 operand and write one half each).
+// The conversion is left to the compiler on purpose: x may come straight out of v_log_f32, and the
+// transcendental -> VALU wait state is inserted by hipcc for its own instructions only (an asm
+// statement that consumed x first would read a stale register -- seen as NaN offsets).
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo)
+{
+    const half2_t hv = {(_Float16)x0, (_Float16)x1};
+    hi = __builtin_bit_cast(unsigned, hv);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo)
+        : "v"(hi), "v"(x0), "v"(x1));
+}
+
+__device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo)
 {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 h = (_Float16)v[e];
-        hi[e] = h;
-        lo[e] = (_Float16)(v[e] - (float)h);
+    for (int e = 0; e < 4; ++e) {
+        unsigned h, l;
+        split2(v[2 * e], v[2 * e + 1], h, l);
+        hi[e] = h; lo[e] = l;
     }
 }
 
 // Slice K of NS of the epilogue of a tile pair: accumulators -> scale -> activation -> split fp16,
 // written into the 4 B fragments (k-steps) the pair becomes for the next layer.  32 values per lane.
 template <int ACT, int NS, int K>
-__device__ __forceinline__ void epi_slice(const f32x16 *__restrict__ acc, float oscale, Frag *__restrict__ out4)
+__device__ __forceinline__ void epi_slice(const f32x16 *__restrict__ acc, Frag *__restrict__ out4)
 {
-    constexpr int VPS = (32 + NS - 1) / NS;
-    static_for<VPS>([&](auto ic) {
-        constexpr int v = K * VPS + decltype(ic)::value;
-        if constexpr (K < NS && v < 32) {
-            constexpr int t = v >> 4, r = v & 15;
-            const float x = act_f<ACT>(acc[t][r] * oscale);
-            const _Float16 hh = (_Float16)x;
-            out4[2 * t + (r >> 3)].hi[r & 7] = hh;
-            out4[2 * t + (r >> 3)].lo[r & 7] = (_Float16)(x - (float)hh);
+    constexpr int PPS = (16 + NS - 1) / NS;          // value PAIRS per slice (16 pairs per lane)
+    static_for<PPS>([&](auto ic) {
+        constexpr int pr = K * PPS + decltype(ic)::value;
+        if constexpr (K < NS && pr < 16) {
+            constexpr int v = 2 * pr, t = v >> 4, r = v & 15;
+            unsigned h, l;
+            split2(act_f<ACT>(acc[t][r]), act_f<ACT>(acc[t][r + 1]), h, l);
+            out4[2 * t + (r >> 3)].hi[(r & 7) >> 1] = h;
+            out4[2 * t + (r >> 3)].lo[(r & 7) >> 1] = l;
         }
     });
 }
@@ -257,10 +354,9 @@ __device__ __forceinline__ void epi_slice(const f32x16 *__restrict__ acc, float 
 template <int ACT, int NS>
 struct Pending {
     const f32x16 *acc;
-    float oscale;
     Frag *out4;
     template <class KC>
-    __device__ __forceinline__ void operator()(KC) const { epi_slice<ACT, NS, KC::value>(acc, oscale, out4); }
+    __device__ __forceinline__ void operator()(KC) const { epi_slice<ACT, NS, KC::value>(acc, out4); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -271,9 +367,9 @@ struct Pending {
 // the first chunk of pair p+1; the last pair's accumulators are handed back in `pend` and the caller
 // schedules their epilogue (Pending) into whatever chunk comes next.  `pre` is such deferred work
 // from the previous layer.  NEXT_BYTES = size of the chunk that follows this layer in the stream.
-template <int NT, int KS0, int KS1, int ACT, int NEXT_BYTES, class In0, class In1, class Pre>
+template <int NT, int KS0, int KS1, int ACT, int NEXT_BYTES, class In0, class In1, class Bias, class Pre>
 __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
-                                      Frag *__restrict__ out, const float *bias, float oscale, int h,
+                                      Frag *__restrict__ out, Bias &bias, int h,
                                       Pre &&pre, f32x16 *__restrict__ pend)
 {
     constexpr int NPAIR = NT / 2;
@@ -283,13 +379,15 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
     static_for<NPAIR>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
         f32x16 acc[2];
-        acc[0] = bias_tile(bias + (2 * p) * 32, h);
-        acc[1] = bias_tile(bias + (2 * p + 1) * 32, h);
+        bias.take(acc, 2, h);
         constexpr int after0 = KS1 > 0 ? B1 : (p + 1 < NPAIR ? B0 : NEXT_BYTES);
         if constexpr (p == 0) {
-            chunk<KS0, 2, after0>(s, in0, acc, pre);
+            chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc) { if constexpr (decltype(kc)::value == 0) bias.after_barrier(h); pre(kc); });
         } else {
-            chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc) { epi_slice<ACT, NS, decltype(kc)::value>(prev, oscale, out + 4 * (p - 1)); });
+            chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc) {
+                if constexpr (decltype(kc)::value == 0) bias.after_barrier(h);
+                epi_slice<ACT, NS, decltype(kc)::value>(prev, out + 4 * (p - 1));
+            });
         }
         if constexpr (KS1 > 0) {
             constexpr int after1 = p + 1 < NPAIR ? B0 : NEXT_BYTES;
@@ -302,59 +400,62 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
 
 // run a deferred epilogue right away (no chunk to hide it in)
 template <int ACT>
-__device__ __forceinline__ void flush(const f32x16 *__restrict__ pend, float oscale, Frag *__restrict__ out4)
+__device__ __forceinline__ void flush(const f32x16 *__restrict__ pend, Frag *__restrict__ out4)
 {
-    static_for<4>([&](auto kc) { epi_slice<ACT, 4, decltype(kc)::value>(pend, oscale, out4); });
+    static_for<4>([&](auto kc) { epi_slice<ACT, 4, decltype(kc)::value>(pend, out4); });
 }
 
 // one-tile linear head (rows 0..31 of which only the first few are real); two accumulators over
 // even / odd k-steps break the dependent MFMA chain.  Returns scaled outputs.
-template <int KS, int NEXT_BYTES, class Pre>
-__device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, const float *bias, float oscale, int h, Pre &&pre)
+template <int KS, int NEXT_BYTES, bool LAST, class Bias, class Pre>
+__device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, Bias &bias, const float *bias_head, int h, Pre &&pre)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x16 a0 = bias_tile(bias, h), a1;
+    f32x16 a0, a1;
+    bias.take(&a0, 1, h);
+    if constexpr (LAST) bias.rewind(bias_head);      // the next block is the first one of the next point tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+#if !AVC_DBG_NO_BARRIER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
     // Values every address of this chunk derives from are made opaque HERE, after the barrier: with
     // everything unrolled and compile-time, the compiler otherwise hoists the address arithmetic of all
     // ~60 chunks of a tile (hundreds of 64-bit values) to the top of the tile loop and spills them.
     unsigned base = s.parity * layout::SLOT_BYTES + s.lane_off;
     unsigned so = s.pf_off;
-    unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES + s.wave_off;
+    unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES;
     asm volatile("" : "+v"(base), "+s"(so), "+s"(dst));
     const char *src = s.gs + so;
-    constexpr int NP = NEXT_BYTES / PIECE;
+    constexpr int NP = 4 * ((NEXT_BYTES + GROUP - 1) / GROUP);
     constexpr int PPK = (NP + KS - 2) / (KS - 1);
+    const unsigned wave = s.wave_off >> 10;
     static_for<KS>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const half8 ah = *reinterpret_cast<const half8 *>(smem + base + k * layout::UNIT_BYTES);
         const half8 al = *reinterpret_cast<const half8 *>(smem + base + k * layout::UNIT_BYTES + 1024);
         static_for<PPK>([&](auto pc) {
             constexpr int piece = k * PPK + decltype(pc)::value;
-            if constexpr (piece < NP) glds16(src + piece * PIECE, s.voff, dst + piece * PIECE);
+            if constexpr (piece < NP && !AVC_DBG_NO_PREFETCH) prefetch_piece<NEXT_BYTES, piece>(src, s.lane_off, wave, dst);
         });
+        if constexpr (k == 0) bias.after_barrier(h);
         pre(kc);
         if constexpr (k & 1) {
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].hi, a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].lo, a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[k].hi, a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].hi), a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].lo), a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_half8(in[k].hi), a1, 0, 0, 0);
         } else {
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].hi, a0, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[k].lo, a0, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[k].hi, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].hi), a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].lo), a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_half8(in[k].hi), a0, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     });
     const unsigned no = s.pf_off + NEXT_BYTES;
     s.pf_off = no >= s.total ? 0u : no;
     s.parity ^= 1u;
-    f32x16 a = a0 + a1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] *= oscale;
-    return a;
+    return a0 + a1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -434,7 +535,11 @@ __device__ __forceinline__ Stream stream_init(const QueryParams &p, int wave, in
     s.wave_off = wave * 1024u; s.lane_off = lane * 16u;
     s.gs = p.wstream; s.voff = s.wave_off + s.lane_off;
     s.total = p.stream_bytes; s.parity = 0;
-    for (int o = 0; o < first_bytes; o += PIECE) glds16(s.gs + o, s.voff, s.wave_off + o);     // chunk 0 -> slot 0
+    // chunk 0 -> slot 0 (same group layout as prefetch_piece, run-time sizes)
+    for (int g0 = 0; g0 < first_bytes; g0 += GROUP) {
+        const int gb = first_bytes - g0 >= GROUP ? GROUP : first_bytes - g0, per_wave = gb / WAVES;
+        for (int o = 0; o < per_wave; o += 1024) glds16<0>(s.gs + g0 + wave * per_wave + o + s.lane_off, g0 + wave * per_wave + o);
+    }
     s.pf_off = first_bytes;
     return s;
 }
@@ -456,6 +561,9 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
     constexpr int B_FIRST = WARP ? B_IN67 : B_PE;       // first chunk of a pass (the prefetcher wraps to it)
 
     Stream s = stream_init(p, wave, lane, B_FIRST);
+    BiasQueue bias;
+    bias.next = p.bias;
+    bias.fetch(h);                       // first block; afterwards every chunk fetches its successor's
 
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int64_t pidx_raw = tile * TILE_PTS + wave * 32 + j;
@@ -467,9 +575,8 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         unsigned park = PARK_BASE + wave * PARK_PER_WAVE + lane * 16;
         asm volatile("" : "+v"(park));   // opaque per tile: otherwise every park address is hoisted out of the loop as its own VGPR
         f32x16 pa[2], pb[2];             // deferred accumulators of a layer's last tile pair (ping/pong)
-        const float *bias = p.bias;
-        asm volatile("" : "+s"(bias));   // opaque per tile: stops LICM from hoisting ~60 tiles of bias loads out of the loop
-        constexpr int LI = WARP ? 8 : 0; // oscale index of the first template layer
+        const float *bias_head = p.bias;
+        asm volatile("" : "+s"(bias_head));   // opaque per tile: keeps bias addresses from being hoisted out of the loop
         float q[3] = {pt[0], pt[1], pt[2]};
         float off[3] = {0.f, 0.f, 0.f};
 
@@ -487,15 +594,14 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             const ParkIn S{park, &S4};
             const RegIn RX{X}, RY{Y};
             using SP = Pending<ACT_SOFTPLUS, 8>;
-            const float o0 = p.oscale[0], o1 = p.oscale[1], o2 = p.oscale[2], o3 = p.oscale[3], o4 = p.oscale[4], o5 = p.oscale[5], o6 = p.oscale[6];
-            dense<8, layout::IN67_KS, 0, ACT_SOFTPLUS, B_MAIN>(s, S, S, X, bias, o0, h, NoSide{}, pa); bias += 256;                       // conv1+bn1
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, o1, h, SP{pa, o0, X + 12}, pb); bias += 256;                        // conv2
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RY, RY, X, bias, o2, h, SP{pb, o1, Y + 12}, pa); bias += 256;                        // conv3
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, o3, h, SP{pa, o2, X + 12}, pb); bias += 256;                        // conv4
-            dense<8, 16, layout::IN67_KS, ACT_SOFTPLUS, B_MAIN>(s, RY, S, X, bias, o4, h, SP{pb, o3, Y + 12}, pa); bias += 256;           // conv5 on [x0|x4]
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, o5, h, SP{pa, o4, X + 12}, pb); bias += 256;                        // conv6
-            dense<8, 16, 0, ACT_SOFTPLUS, B_HEAD16>(s, RY, RY, X, bias, o6, h, SP{pb, o5, Y + 12}, pa); bias += 256;                      // conv7
-            const f32x16 o = head<16, B_PE>(s, X, bias, p.oscale[7], h, SP{pa, o6, X + 12}); bias += 32;                                  // out_layer_coord_affine
+            dense<8, layout::IN67_KS, 0, ACT_SOFTPLUS, B_MAIN>(s, S, S, X, bias, h, NoSide{}, pa);                       // conv1+bn1
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12}, pb);                        // conv2
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RY, RY, X, bias, h, SP{pb, Y + 12}, pa);                        // conv3
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12}, pb);                        // conv4
+            dense<8, 16, layout::IN67_KS, ACT_SOFTPLUS, B_MAIN>(s, RY, S, X, bias, h, SP{pb, Y + 12}, pa);           // conv5 on [x0|x4]
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12}, pb);                        // conv6
+            dense<8, 16, 0, ACT_SOFTPLUS, B_HEAD16>(s, RY, RY, X, bias, h, SP{pb, Y + 12}, pa);                      // conv7
+            const f32x16 o = head<16, B_PE, false>(s, X, bias, bias_head, h, SP{pa, X + 12});                                  // out_layer_coord_affine
             // rows 0..2 live in lanes h == 0, regs 0..2: broadcast to the other half
             off[0] = __shfl(o[0], j, 64); off[1] = __shfl(o[1], j, 64); off[2] = __shfl(o[2], j, 64);
             q[0] = pt[0] + off[0]; q[1] = pt[1] + off[1]; q[2] = pt[2] + off[2];                                       // arch_avatar.py:372 (fp32 add)
@@ -506,18 +612,16 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         const ParkIn P{park, nullptr};
         const RegIn TX{X}, TY{Y};
         using RP = Pending<ACT_RELU, 8>;
-        const float t0 = p.oscale[LI], t1 = p.oscale[LI + 1], t2 = p.oscale[LI + 2], t3 = p.oscale[LI + 3], t4 = p.oscale[LI + 4],
-                    t5 = p.oscale[LI + 5], t6 = p.oscale[LI + 6], g0 = p.oscale[LI + 7], g1 = p.oscale[LI + 8];
-        dense<8, layout::PE_KS, 0, ACT_RELU, B_MAIN>(s, P, P, X, bias, t0, h, NoSide{}, pa); bias += 256;                                 // shared 0
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, t1, h, RP{pa, t0, X + 12}, pb); bias += 256;
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TY, TY, X, bias, t2, h, RP{pb, t1, Y + 12}, pa); bias += 256;
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, t3, h, RP{pa, t2, X + 12}, pb); bias += 256;
-        dense<8, 16, layout::PE_KS, ACT_RELU, B_MAIN>(s, TY, P, X, bias, t4, h, RP{pb, t3, Y + 12}, pa); bias += 256;                     // shared 4 on [x|x0]
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, t5, h, RP{pa, t4, X + 12}, pb); bias += 256;
-        dense<8, 16, 0, ACT_NONE, B_MAIN>(s, TY, TY, X, bias, t6, h, RP{pb, t5, Y + 12}, pa); bias += 256;                                // shared 6: no activation (mlp.py:46,64)
-        dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TX, TX, Y, bias, g0, h, Pending<ACT_NONE, 8>{pa, t6, X + 12}, pb); bias += 128;           // geo 0
+        dense<8, layout::PE_KS, 0, ACT_RELU, B_MAIN>(s, P, P, X, bias, h, NoSide{}, pa);                                 // shared 0
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12}, pb);
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TY, TY, X, bias, h, RP{pb, Y + 12}, pa);
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12}, pb);
+        dense<8, 16, layout::PE_KS, ACT_RELU, B_MAIN>(s, TY, P, X, bias, h, RP{pb, Y + 12}, pa);                     // shared 4 on [x|x0]
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12}, pb);
+        dense<8, 16, 0, ACT_NONE, B_MAIN>(s, TY, TY, X, bias, h, RP{pb, Y + 12}, pa);                                // shared 6: no activation (mlp.py:46,64)
+        dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TX, TX, Y, bias, h, Pending<ACT_NONE, 8>{pa, X + 12}, pb);           // geo 0
         constexpr int AFTER_GEO = COLOUR ? B_MAIN : B_FIRST;
-        const f32x16 g = head<8, AFTER_GEO>(s, Y, bias, g1, h, Pending<ACT_LEAKY, 4>{pb, g0, Y + 4}); bias += 32;                         // geo 1: row 0 = occ/sdf, row 1 = sigma
+        const f32x16 g = head<8, AFTER_GEO, !COLOUR>(s, Y, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pb, Y + 4});                         // geo 1: row 0 = occ/sdf, row 1 = sigma
 
         const bool writer = (h == 0) && (pidx_raw < p.n);
         if (writer) {
@@ -525,11 +629,10 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             if (WARP && p.out1) { p.out1[pidx_raw * 3 + 0] = off[0]; p.out1[pidx_raw * 3 + 1] = off[1]; p.out1[pidx_raw * 3 + 2] = off[2]; }
         }
         if constexpr (COLOUR) {
-            const float c0 = p.oscale[LI + 9], c1 = p.oscale[LI + 10], c2 = p.oscale[LI + 11];
             // X (the shared feature) is complete: its last pair was finished inside geo 0's first chunk
-            dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, c0, h, NoSide{}, pa); bias += 256;                                      // clr 0
-            dense<4, 16, 0, ACT_RELU, B_HEAD8>(s, TY, TY, X, bias, c1, h, RP{pa, c0, Y + 12}, pb); bias += 128;                           // clr 1
-            const f32x16 c = head<8, B_FIRST>(s, X, bias, c2, h, Pending<ACT_RELU, 4>{pb, c1, X + 4}); bias += 32;                        // clr 2
+            dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, NoSide{}, pa);                                      // clr 0
+            dense<4, 16, 0, ACT_RELU, B_HEAD8>(s, TY, TY, X, bias, h, RP{pa, Y + 12}, pb);                           // clr 1
+            const f32x16 c = head<8, B_FIRST, true>(s, X, bias, bias_head, h, Pending<ACT_RELU, 4>{pb, X + 4});                        // clr 2
             if (writer && p.out2) {
                 f32x4 rgba = {sigmoid_f(c[0]), sigmoid_f(c[1]), sigmoid_f(c[2]), __builtin_fmaxf(g[1], 0.0f)};         // :75-76
                 *reinterpret_cast<f32x4 *>(p.out2 + pidx_raw * 4) = rgba;
@@ -573,35 +676,34 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
         Frag X[16], Y[16];
         const RegIn RI{I}, RX{X}, RY{Y};
         f32x16 pend[2];
-        const float *bias = p.bias;
-        asm volatile("" : "+s"(bias));   // see avatar_kernel
+        BiasDirect bias{p.bias};
+        asm volatile("" : "+s"(bias.p));   // see avatar_kernel
         f32x16 acc[8];
-        const float s0 = p.oscale[0], s1 = p.oscale[1], s2 = p.oscale[2], s4 = p.oscale[4], s5 = p.oscale[5];
         // fc0 rows 0..255
-        dense<8, layout::IN33_KS, 0, ACT_LEAKY, B_WIDE4>(s, RI, RI, X, bias, s0, h, NoSide{}, pend); bias += 256;
-        flush<ACT_LEAKY>(pend, s0, X + 12);
+        dense<8, layout::IN33_KS, 0, ACT_LEAKY, B_WIDE4>(s, RI, RI, X, bias, h, NoSide{}, pend);
+        flush<ACT_LEAKY>(pend, X + 12);
         // fc1 partial over x[0..255]: 8 tiles live, 4 k-steps per chunk
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = bias_tile(bias + 32 * t, h);
-        bias += 256;
+        for (int t = 0; t < 8; ++t) acc[t] = bias_tile(bias.p + 32 * t, h);
+        bias.p += 256;
         chunk<4, 8, B_WIDE4>(s, RegIn{X}, acc, NoSide{});
         chunk<4, 8, B_WIDE4>(s, RegIn{X + 4}, acc, NoSide{});
         chunk<4, 8, B_WIDE4>(s, RegIn{X + 8}, acc, NoSide{});
         chunk<4, 8, B_IN33>(s, RegIn{X + 12}, acc, NoSide{});
         // fc0 rows 256..511
-        dense<8, layout::IN33_KS, 0, ACT_LEAKY, B_WIDE4>(s, RI, RI, X, bias, s2, h, NoSide{}, pend); bias += 256;
-        flush<ACT_LEAKY>(pend, s2, X + 12);
-        bias += 256;   // (zero bias block of the second fc1 pack call)
+        dense<8, layout::IN33_KS, 0, ACT_LEAKY, B_WIDE4>(s, RI, RI, X, bias, h, NoSide{}, pend);
+        flush<ACT_LEAKY>(pend, X + 12);
+        bias.p += 256;   // (zero bias block of the second fc1 pack call)
         chunk<4, 8, B_WIDE4>(s, RegIn{X}, acc, NoSide{});
         chunk<4, 8, B_WIDE4>(s, RegIn{X + 4}, acc, NoSide{});
         chunk<4, 8, B_WIDE4>(s, RegIn{X + 8}, acc, NoSide{});
         chunk<4, 8, B_WIDE_IN33>(s, RegIn{X + 12}, acc, NoSide{});
         chunk<layout::IN33_KS, 8, B_MAIN>(s, RI, acc, NoSide{});
 #pragma unroll
-        for (int t = 0; t < 8; t += 2) flush<ACT_LEAKY>(acc + t, s1, Y + 2 * t);
+        for (int t = 0; t < 8; t += 2) flush<ACT_LEAKY>(acc + t, Y + 2 * t);
         // fc2 on [x(256) | in(33)] -> 128
-        dense<4, 16, layout::IN33_KS, ACT_LEAKY, B_HEAD8>(s, RY, RI, X, bias, s4, h, NoSide{}, pend); bias += 128;
-        const f32x16 o = head<8, B_IN33>(s, X, bias, s5, h, Pending<ACT_LEAKY, 4>{pend, s4, X + 4});
+        dense<4, 16, layout::IN33_KS, ACT_LEAKY, B_HEAD8>(s, RY, RI, X, bias, h, NoSide{}, pend);
+        const f32x16 o = head<8, B_IN33, true>(s, X, bias, p.bias, h, Pending<ACT_LEAKY, 4>{pend, X + 4});
         if (h == 0 && pidx_raw < p.n) p.out0[pidx_raw] = sigmoid_f(o[0]);                         // last_op sigmoid
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -651,8 +753,6 @@ int launch_avatar(avc_ctx *ctx, const float *pts, int64_t n, const float center[
     p.pts = pts; p.n = n; p.feat = ctx->pose_feat_hwc; p.H = ctx->pose_H; p.W = ctx->pose_W;
     p.cx = center ? center[0] : 0.f; p.cy = center ? center[1] : 0.f; p.cz = center ? center[2] : 0.f;
     p.wstream = (const char *)net.d_stream; p.bias = net.d_bias;
-    AVC_REQUIRE(net.oscale.size() <= 24, AVC_ERR_STATE, "internal: too many layers");
-    for (size_t i = 0; i < net.oscale.size(); ++i) p.oscale[i] = net.oscale[i];
     p.out0 = occ; p.out1 = offset; p.out2 = rgba; p.sigmoid_occ = occ_sigmoid;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;
     const bool colour = rgba != nullptr;
@@ -689,7 +789,6 @@ int launch_recon(avc_ctx *ctx, const float *pts, int64_t n, const float center[3
     p.pts = pts; p.n = n; p.feat = ctx->img_feat_hwc; p.H = ctx->img_H; p.W = ctx->img_W;
     p.cx = center[0]; p.cy = center[1]; p.cz = center[2];
     p.wstream = (const char *)net.d_stream; p.bias = net.d_bias;
-    for (size_t i = 0; i < net.oscale.size(); ++i) p.oscale[i] = net.oscale[i];
     p.stream_bytes = bytes_until(net, net.chunks.size());
     p.out0 = out;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;

@@ -31,6 +31,7 @@ struct Seg { int ks; std::function<int(int)> col; };   // slot -> column of W (o
 
 struct Builder {
     PackedNet &net;
+    bool overflow = false;
     explicit Builder(PackedNet &n) : net(n) { net.stream.clear(); net.chunks.clear(); net.bias.clear(); net.oscale.clear(); }
 
     // W: (cout, cin) row-major effective weights, b: (cout).  tpc = tiles per chunk (accumulators
@@ -42,9 +43,12 @@ struct Builder {
         const int nt = ((nt_raw + tpc - 1) / tpc) * tpc;
         double m = 0;
         for (double w : W) m = std::fmax(m, std::fabs(w));
-        int sw = 0;
-        if (m > 0) sw = (int)std::floor(std::log2(30000.0 / m));
-        sw = sw < -24 ? -24 : (sw > 24 ? 24 : sw);
+        // Power-of-two pre-scaling of a layer's weights (undone in the epilogue) would keep the fp16 `lo`
+        // halves normal.  It is only needed when the largest weight would overflow fp16: gfx950 MFMA
+        // does not flush fp16 subnormal inputs, a subnormal `lo` still carries the residual to 2^-25
+        // absolute, and skipping the rescale saves one VALU instruction per activation.
+        const int sw = 0;
+        if (m > 30000.0) overflow = true;     // reported by the caller: |w| must stay below the fp16 range
         const double scale = std::ldexp(1.0, sw);
         net.oscale.push_back((float)std::ldexp(1.0, -sw));
         for (int r = 0; r < nt * 32; ++r) net.bias.push_back(r < cout ? (float)(b[r] * scale) : 0.0f);
@@ -133,6 +137,7 @@ int upload(PackedNet &net)
     release(net);
     AVC_HIP(hipMalloc(&net.d_stream, net.stream.size()));
     AVC_HIP(hipMalloc((void **)&net.d_chunks, net.chunks.size() * sizeof(ChunkDesc)));
+    net.bias.resize(net.bias.size() + 64, 0.0f);    // BiasQueue fetches 64 floats ahead of a 32-float head block
     AVC_HIP(hipMalloc((void **)&net.d_bias, net.bias.size() * sizeof(float)));
     AVC_HIP(hipMemcpy(net.d_stream, net.stream.data(), net.stream.size(), hipMemcpyHostToDevice));
     AVC_HIP(hipMemcpy(net.d_chunks, net.chunks.data(), net.chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
@@ -142,13 +147,26 @@ int upload(PackedNet &net)
 }
 
 // Layer order here IS the kernel's consumption order (avatar_kernel in fused_mlp.hip).
+//
+// Softplus in the log2 domain: softplus(x) = ln2 * log2(1 + 2^(x log2 e)).  The kernel's epilogue only
+// evaluates y' = log2(1 + 2^m) (v_exp_f32 / v_log_f32), so for every Softplus layer the weights and
+// bias are pre-multiplied by log2(e) (the accumulator becomes m) and every consumer of a Softplus output
+// absorbs the missing ln(2) into its weight columns.  For a Softplus layer fed by a Softplus layer the
+// two factors cancel (log2 e * ln 2 = 1): only the bias changes.
 static void add_warp(Builder &B, const avc_ctx::Staged &w)
 {
-    B.layer(w.W[0], w.b[0], 256, 67, {seg_in67()}, 2, 16);                       // conv1
-    for (int i = 1; i <= 3; ++i) B.layer(w.W[i], w.b[i], 256, 256, {seg_d(16)}, 2, 16);   // conv2..4
-    B.layer(w.W[4], w.b[4], 256, 323, {seg_d(16, 67), seg_in67()}, 2, 16);       // conv5: cat([x0, x4]) (mlp.py:106)
-    for (int i = 5; i <= 6; ++i) B.layer(w.W[i], w.b[i], 256, 256, {seg_d(16)}, 2, 16);   // conv6..7
-    B.layer(w.W[7], w.b[7], 3, 256, {seg_d(16)}, 1, 16);                         // out_layer_coord_affine
+    const double LOG2E = 1.4426950408889634074, LN2 = 0.69314718055994530942;
+    auto scaled = [](std::vector<double> v, double f, int cin = 0, int c0 = 0, int c1 = -1) {
+        if (c1 < 0) { for (double &x : v) x *= f; return v; }
+        for (size_t i = 0; i < v.size(); ++i) { const int c = (int)(i % cin); if (c >= c0 && c < c1) v[i] *= f; }
+        return v;
+    };
+    B.layer(scaled(w.W[0], LOG2E), scaled(w.b[0], LOG2E), 256, 67, {seg_in67()}, 2, 16);                 // conv1 (raw inputs)
+    for (int i = 1; i <= 3; ++i) B.layer(w.W[i], scaled(w.b[i], LOG2E), 256, 256, {seg_d(16)}, 2, 16);      // conv2..4
+    B.layer(scaled(w.W[4], LOG2E, 323, 0, 67), scaled(w.b[4], LOG2E), 256, 323,
+            {seg_d(16, 67), seg_in67()}, 2, 16);                                 // conv5: cat([x0 (raw), x4 (softplus)]) (mlp.py:106)
+    for (int i = 5; i <= 6; ++i) B.layer(w.W[i], scaled(w.b[i], LOG2E), 256, 256, {seg_d(16)}, 2, 16);      // conv6..7
+    B.layer(scaled(w.W[7], LN2), w.b[7], 3, 256, {seg_d(16)}, 1, 16);             // out_layer_coord_affine (linear consumer)
 }
 
 static void add_template(Builder &B, const avc_ctx::Staged &t, bool colour)
@@ -173,6 +191,7 @@ int pack_avatar(avc_ctx *ctx)
     if (ctx->tmpl_set) {
         Builder B(ctx->tmpl_only);
         add_template(B, ctx->tmpl_st, colour);
+        AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "template weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
         ctx->tmpl_only.has_colour = colour;
         int rc = upload(ctx->tmpl_only);
         if (rc) return rc;
@@ -181,6 +200,7 @@ int pack_avatar(avc_ctx *ctx)
         Builder B(ctx->warp_tmpl);
         add_warp(B, ctx->warp_st);
         add_template(B, ctx->tmpl_st, colour);
+        AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "avatar weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
         ctx->warp_tmpl.has_colour = colour;
         int rc = upload(ctx->warp_tmpl);
         if (rc) return rc;
@@ -216,6 +236,7 @@ int pack_recon(avc_ctx *ctx, const avc_dense fc[4])
     B.layer(W[1], zero256, 256, 545, {seg_d(16, 256), seg_in33(512)}, 8, 4);   // fc1 over x[256..511] and in(33)
     B.layer(W[2], b[2], 128, 289, {seg_d(16), seg_in33(256)}, 2, 16);    // fc2: [x(256) | in(33)]
     B.layer(W[3], b[3], 1, 128, {seg_d(8)}, 1, 16);                      // fc3
+    AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "recon weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
     return upload(ctx->recon);
 }
 

@@ -1,0 +1,27 @@
+"""Scratch: max abs error of the fused avatar query vs the fp64 oracle on 4096 points."""
+import sys
+import numpy as np, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from avatarcap_amd import config
+config.cfg = config.default_cfg()
+import golden_inputs as gi
+from common import geotex_sd, recon_sd
+from avatarcap_amd.network.arch_avatar import GeoTexAvatar, OccupancyNet
+from avatarcap_amd.network.arch_recon import ReconNetwork
+from oracle import avatarcap_oracle as orc
+net = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume()).to('cuda').eval()
+net.load_state_dict({k: torch.from_numpy(v) for k, v in geotex_sd().items()})
+fmap = gi.pose_feat_map()
+net.warping_field.pose_feat_map = torch.from_numpy(fmap[None]).cuda()
+pts = gi.query_points(11, 4096)
+out = OccupancyNet(net).query({'cano_pts': torch.from_numpy(pts[None]).cuda(), 'cano_smpl_center': torch.from_numpy(gi.center()[None]).cuda()})
+ref = orc.occupancy_query(pts, fmap, gi.center(), geotex_sd())
+print('occ   err', np.abs(out['cano_pts_ov'][0].cpu().numpy() - ref['cano_pts_ov']).max(), 'scale', np.abs(ref['cano_pts_ov']).max())
+print('off   err', np.abs(out['nonrigid_offset'][0].cpu().numpy() - ref['nonrigid_offset']).max(), 'scale', np.abs(ref['nonrigid_offset']).max())
+ref32 = orc.occupancy_query(pts, fmap, gi.center(), geotex_sd(), dt=np.float32)
+print('fp32-oracle vs fp64-oracle occ', np.abs(ref32['cano_pts_ov'] - ref['cano_pts_ov']).max())
+rn = ReconNetwork().to('cuda').eval()
+rn.load_state_dict({k: torch.from_numpy(v) for k, v in recon_sd().items()})
+imap = gi.img_feat_map()
+y = rn.decode(torch.from_numpy(pts[None]).cuda(), torch.from_numpy(imap[None]).cuda(), torch.from_numpy(gi.center()[None]).cuda())
+print('recon err', np.abs(y.cpu().numpy().reshape(-1) - orc.recon_infer(pts, imap, gi.center(), recon_sd())).max())

@@ -1,0 +1,20 @@
+"""Minimal driver for rocprofv3 --pmc runs: one warm-up and N dense avatar queries at RES^3."""
+import sys
+import numpy as np, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from avatarcap_amd import config, synthetic as syn
+config.cfg = config.default_cfg()
+from avatarcap_amd.network.arch_avatar import GeoTexAvatar, OccupancyNet
+from avatarcap_amd.grid import generate_volume_points
+res = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+net = GeoTexAvatar(base_weight_volume=np.zeros((2, 2, 2, 24), np.float32)).to('cuda').eval()
+sd = syn.synth_state_dict(syn.module_shapes(net), syn.SEED)
+net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+net.warping_field.pose_feat_map = torch.randn(1, 64, 256, 256, device='cuda')
+pts = generate_volume_points(syn.CANO_BOUNDS, (res, res, res), 'cuda')[None]
+batch = {'cano_pts': pts, 'cano_smpl_center': torch.zeros(1, 3, device='cuda')}
+for _ in range(reps + 1):
+    OccupancyNet(net).query(batch)
+torch.cuda.synchronize()
+print('done')
