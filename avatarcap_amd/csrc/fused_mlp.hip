@@ -11,8 +11,8 @@
 //   * arithmetic: every fp32 product a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with
 //     (hi, lo) fp16 pairs on v_mfma_f32_32x32x16_f16, fp32 accumulation (22+ significant bits,
 //     ~1e-6 relative; the parity bar is 1e-4 absolute).  3 MFMA passes at 16x the fp32-MFMA rate.
-//   * weights (3.6 MB, pre-split and pre-permuted by pack.cpp) stream L2 -> LDS with
-//     global_load_lds_dwordx4 into a 2 x 64 KiB ring, one chunk ahead of the MFMAs that read it
+//   * weights (3.6 MB, pre-split and pre-permuted by pack.cpp) stream L2 -> VGPR -> LDS with
+//     global_load_dwordx4 + ds_write_b128 into a 2 x 64 KiB ring, one chunk ahead of the MFMAs that read it
 //     (ds_read_b128, lane-linear => conflict-free); one barrier per chunk.
 //   * everything is a compile-time unrolled sequence of CHUNK STEPS.  Inside a chunk every k-step
 //     issues, in the shadow of its 3*TPC MFMAs: the LDS reads of the next k-step's A fragments, a
@@ -40,8 +40,17 @@
 #ifndef AVC_DBG_NO_SIDE
 #define AVC_DBG_NO_SIDE 0
 #endif
-#ifndef AVC_DBG_NO_MFMA
-#define AVC_DBG_NO_MFMA 0
+#ifndef AVC_DBG_TIMING
+#define AVC_DBG_TIMING 0
+#endif
+#ifndef AVC_DBG_PF_LOAD_ONLY
+#define AVC_DBG_PF_LOAD_ONLY 0
+#endif
+#ifndef AVC_DBG_PF_STORE_ONLY
+#define AVC_DBG_PF_STORE_ONLY 0
+#endif
+#ifndef AVC_DBG_PF_SAME
+#define AVC_DBG_PF_SAME 0
 #endif
 
 namespace avc {
@@ -63,7 +72,7 @@ constexpr int TILE_PTS = 32 * WAVES;
 constexpr int PARK_BASE = 2 * layout::SLOT_BYTES;     // per-wave 8 KiB: 4 input k-steps parked in LDS (see ParkIn)
 constexpr int PARK_PER_WAVE = 4 * layout::UNIT_BYTES;
 constexpr int LDS_BYTES = PARK_BASE + WAVES * PARK_PER_WAVE;   // 128 KiB weight ring + 32 KiB = the whole 160 KiB
-constexpr int PIECE = WAVES * 1024;          // bytes one round of 4 wave-wide glds instructions moves
+constexpr int PIECE = WAVES * 1024;          // chunk sizes are multiples of this
 
 constexpr int chunk_bytes(int ks, int tpc) { return ks * tpc * layout::UNIT_BYTES; }
 
@@ -132,68 +141,119 @@ __device__ __forceinline__ void park_store(unsigned base, int k, const Frag &f)
 // weight stream: 2-slot LDS ring, one chunk of prefetch, sizes known at compile time
 // ------------------------------------------------------------------------------------------
 struct Stream {
-    const char *gs;          // weight stream (wave-uniform: stays in SGPRs, glds uses the saddr form)
-    unsigned voff;           // per-lane source offset: wave*1024 + lane*16
+    const char *gs;          // weight stream (wave-uniform: stays in SGPRs => saddr-form global loads)
     unsigned total;          // bytes per pass
     unsigned pf_off;         // offset of the next chunk to prefetch
     unsigned parity;         // ring slot of the chunk about to be consumed
-    unsigned wave_off;       // wave * 1024
+    unsigned wave;           // wave index in the workgroup
     unsigned lane_off;       // lane * 16
+#if AVC_DBG_TIMING
+    long long t_bar = 0;     // cycles spent waiting at chunk barriers
+#endif
 };
 
-// One prefetch instruction = 1 KiB per wave (64 lanes x 16 B).  A chunk is covered in GROUPS of 16 KiB
-// (a shorter last group for sizes that are not a multiple of 16 KiB): inside a group wave w owns a
-// contiguous quarter and walks it with the instruction's immediate offset (added to the global AND
-// the LDS address), so a group costs one address and one M0 set-up per wave, not one per instruction.
-template <int IMM>
-__device__ __forceinline__ void glds16(const char *src_lane, unsigned lds_wave_base)
+// The next chunk travels global -> VGPR -> LDS (global_load_dwordx4 + ds_write_b128), NOT through
+// LDS-DMA: a global_load_lds costs the issuing wave 60-100 cycles (MI355X_MICROARCH.md), and with one
+// wave per SIMD those cycles come straight out of the MFMA stream (measured: 889 of them per tile
+// = 23 % of the kernel).  A chunk is covered in GROUPS of 16 KiB (a shorter last group for sizes that
+// are not a multiple of 16 KiB); inside a group wave w owns a contiguous quarter and walks it with
+// immediate offsets, so a piece needs no address arithmetic beyond one scalar add per group.
+constexpr int GROUP = 16384;
+constexpr int pf_group_bytes(int bytes, int g) { return bytes - g * GROUP >= GROUP ? GROUP : bytes - g * GROUP; }
+constexpr int pf_slots(int bytes) { return 4 * ((bytes + GROUP - 1) / GROUP); }          // piece ids incl. holes
+constexpr bool pf_valid(int bytes, int i) { return (i % 4) * 1024 < pf_group_bytes(bytes, i / 4) / WAVES; }
+constexpr int pf_count(int bytes) { int n = 0; for (int i = 0; i < pf_slots(bytes); ++i) n += pf_valid(bytes, i); return n; }
+constexpr int pf_nth(int bytes, int n) { for (int i = 0; i < pf_slots(bytes); ++i) { if (pf_valid(bytes, i)) { if (n == 0) return i; --n; } } return -1; }
+
+// schedule of the n-th piece over the 3*KS issue slots of a chunk: load at L, store to LDS at L + D
+struct PfPlan { int slots, npw, dist, ring; };
+constexpr PfPlan pf_plan(int ks, int bytes)
+{
+    PfPlan p{3 * ks, pf_count(bytes), 0, 1};
+    if (p.npw == 0) return p;
+    p.dist = p.slots >= 36 ? 12 : (p.slots >= 18 ? 6 : (p.slots >= 9 ? 4 : 2));
+    const int span = p.slots - p.dist;                     // loads spread over [0, span)
+    // pieces in flight at once = ceil(dist * npw / span) (+1 for the slot where a store and a load meet)
+    p.ring = (p.dist * p.npw + span - 1) / span + 1;
+    return p;
+}
+constexpr int pf_load_slot(const PfPlan &p, int n) { return n * (p.slots - p.dist) / p.npw; }
+
+template <int BYTES, int I>
+__device__ __forceinline__ u32x4 pf_load(const char *src, unsigned lane16, unsigned wave)
+{
+    constexpr int g = I / 4, j = I % 4, pw = pf_group_bytes(BYTES, g) / WAVES;
+    const char *sg = src + g * GROUP;                                    // scalar
+    return *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(
+        (const __attribute__((address_space(1))) char *)sg + (wave * pw + lane16) + j * 1024);
+}
+template <int BYTES, int I>
+__device__ __forceinline__ void pf_store(unsigned dst_slot, unsigned lane16, unsigned wave, const u32x4 &v)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
-                                     (__attribute__((address_space(3))) void *)(smem + lds_wave_base), 16, IMM, 0);
-}
-constexpr int GROUP = 16384;
-// instruction index i (0 .. bytes/4096-1) of a chunk of `bytes` -> group, position in group
-constexpr int pf_group(int i) { return i / 4; }
-constexpr int pf_group_bytes(int bytes, int g) { return bytes - g * GROUP >= GROUP ? GROUP : bytes - g * GROUP; }
-template <int BYTES, int I>
-__device__ __forceinline__ void prefetch_piece(const char *src, unsigned lane16, unsigned wave, unsigned dst_slot)
-{
-    // pieces are numbered group-major; a full group has 4 per wave, the last may have 1..3
-    constexpr int g = I / 4, j = I % 4;
-    constexpr int gb = pf_group_bytes(BYTES, g);
-    constexpr int per_wave = gb / WAVES;                 // bytes of this group owned by one wave
-    if constexpr (j * 1024 < per_wave) {
-        const unsigned woff = g * GROUP + wave * per_wave;
-        glds16<j * 1024>(src + woff + lane16, dst_slot + woff);
-    }
+    constexpr int g = I / 4, j = I % 4, pw = pf_group_bytes(BYTES, g) / WAVES;
+    *reinterpret_cast<u32x4 *>(smem + (dst_slot + wave * pw + lane16) + g * GROUP + j * 1024) = v;
 }
 
-// One chunk step: KS k-steps x TPC output tiles (units k-major in LDS).  While it computes, it
-// prefetches the next chunk (NEXT_BYTES, compile-time) and runs `side(k)` once per k-step.
+// work of issue slot SLOT: first retire the pieces whose data is due, then start new loads
+template <int KS, int NEXT_BYTES, int SLOT, int RING>
+__device__ __forceinline__ void pf_step(u32x4 (&st)[RING], const char *src, unsigned dst, unsigned lane16, unsigned wave)
+{
+#if !AVC_DBG_NO_PREFETCH
+    constexpr PfPlan P = pf_plan(KS, NEXT_BYTES);
+    static_for<P.npw>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+#if AVC_DBG_PF_LOAD_ONLY
+        if constexpr (pf_load_slot(P, n) + P.dist == SLOT) asm volatile("" :: "v"(st[n % RING]));   // keep the load alive
+#else
+        if constexpr (pf_load_slot(P, n) + P.dist == SLOT) pf_store<NEXT_BYTES, pf_nth(NEXT_BYTES, n)>(dst, lane16, wave, st[n % RING]);
+#endif
+    });
+    static_for<P.npw>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+#if AVC_DBG_PF_STORE_ONLY
+        if constexpr (pf_load_slot(P, n) == SLOT) asm volatile("" : "=v"(st[n % RING]));
+#else
+        if constexpr (pf_load_slot(P, n) == SLOT) st[n % RING] = pf_load<NEXT_BYTES, pf_nth(NEXT_BYTES, n)>(src, lane16, wave);
+#endif
+    });
+#endif
+}
+
+// One chunk step: KS k-steps x TPC output tiles (units k-major in LDS).  Every k-step is three issue
+// slots -- (hi,hi), (hi,lo), (lo,hi) products, one MFMA per tile each -- fenced by sched_barriers so
+// that consecutive MFMAs never share an accumulator (an 8-pass MFMA that depends on its predecessor
+// issues 8 cycles late) and the side work is spread evenly: slot 0 carries the LDS reads of the next
+// k-step's operands, every slot one step of the next chunk's global->VGPR->LDS copy, slot 2 a slice of
+// the previous tile pair's epilogue (`side`).
 template <int KS, int TPC, int NEXT_BYTES, class In, class Side>
 __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restrict__ acc, Side &&side)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    static_assert(NEXT_BYTES % PIECE == 0, "chunk sizes are multiples of 4 KiB");
-    // acquire: this chunk's loads (issued during the previous chunk) have landed for every wave, and
-    // every wave has finished reading the other slot
+    // acquire: every wave has stored its share of this chunk (ds_write) and finished reading the other slot
+#if AVC_DBG_TIMING
+    const long long tb0 = clock64();
+#endif
 #if !AVC_DBG_NO_BARRIER
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
+#if AVC_DBG_TIMING
+    s.t_bar += clock64() - tb0;
 #endif
     // Values every address of this chunk derives from are made opaque HERE, after the barrier: with
     // everything unrolled and compile-time, the compiler otherwise hoists the address arithmetic of all
-    // ~60 chunks of a tile (hundreds of 64-bit values) to the top of the tile loop and spills them.
+    // ~60 chunks of a tile (hundreds of values) to the top of the tile loop and spills them.
     unsigned base = s.parity * layout::SLOT_BYTES + s.lane_off;
     unsigned so = s.pf_off;
     unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES;
     asm volatile("" : "+v"(base), "+s"(so), "+s"(dst));
+#if AVC_DBG_PF_SAME
+    const char *src = s.gs + (so & 0u);
+#else
     const char *src = s.gs + so;
-    constexpr int NP = 4 * ((NEXT_BYTES + GROUP - 1) / GROUP);   // prefetch slots per wave (4 per 16 KiB group)
-    constexpr int WIN = KS > 1 ? KS - 1 : 1;                     // issue them over the first KS-1 k-steps
-    constexpr int PPK = (NP + WIN - 1) / WIN;
-    const unsigned wave = s.wave_off >> 10;
+#endif
+    constexpr PfPlan P = pf_plan(KS, NEXT_BYTES);
+    u32x4 st[P.ring];
 
     half8 ah[2][TPC], al[2][TPC];
     Frag b[2];
@@ -206,6 +266,7 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
     static_for<KS>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int cur = k & 1, nxt = cur ^ 1;
+        // ---- slot 0
         if constexpr (k + 1 < KS) {
             b[nxt] = in.template get<k + 1>();
 #pragma unroll
@@ -214,21 +275,24 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
                 al[nxt][t] = *reinterpret_cast<const half8 *>(smem + base + ((k + 1) * TPC + t) * layout::UNIT_BYTES + 1024);
             }
         }
-        static_for<PPK>([&](auto pc) {
-            constexpr int piece = k * PPK + decltype(pc)::value;
-            if constexpr (piece < NP && !AVC_DBG_NO_PREFETCH) prefetch_piece<NEXT_BYTES, piece>(src, s.lane_off, wave, dst);
-        });
+        pf_step<KS, NEXT_BYTES, 3 * k + 0, P.ring>(st, src, dst, s.lane_off, s.wave);
 #pragma unroll
         for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- slot 1
+        pf_step<KS, NEXT_BYTES, 3 * k + 1, P.ring>(st, src, dst, s.lane_off, s.wave);
 #pragma unroll
         for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].lo), acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- slot 2
+        pf_step<KS, NEXT_BYTES, 3 * k + 2, P.ring>(st, src, dst, s.lane_off, s.wave);
 #if AVC_DBG_NO_SIDE
         if constexpr (k == 0) side(kc);
 #else
         side(kc);
 #endif
+#pragma unroll
+        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     });
     const unsigned no = s.pf_off + NEXT_BYTES;
@@ -291,14 +355,18 @@ __device__ __forceinline__ float softplus_f(float m)
     // m = x*log2(e) and the activation carried between layers is y/ln2 = log2(1 + 2^m): v_exp_f32,
     // v_add, v_log_f32.  m is clamped at 64, where 1 + 2^m == 2^m in fp32, so large x returns x (the
     // reference's threshold branch) and nothing overflows; for very negative x the result underflows
-    // to 0 with absolute error < 1e-7.
-    return __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(__builtin_fminf(m, 64.0f)));
+    // to 0 with absolute error < 1e-7.  The clamp is a bare v_min_f32: fminf() would add a
+    // canonicalising v_max in front of it, and at one wave per SIMD every VALU instruction costs
+    // ~2.5 cycles of MFMA issue (tools/ubench/mfma_fill.hip).
+    float c;
+    asm("v_min_f32 %0, 0x42800000, %1" : "=v"(c) : "v"(m));
+    return __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(c));
 }
 
 template <int ACT>
 __device__ __forceinline__ float act_f(float x)
 {
-    if constexpr (ACT == ACT_RELU) return __builtin_fmaxf(x, 0.0f);
+    if constexpr (ACT == ACT_RELU) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; }   // bare max, no canonicalise
     else if constexpr (ACT == ACT_LEAKY) return x > 0.0f ? x : 0.02f * x;     // network/mlp.py:11
     else if constexpr (ACT == ACT_SOFTPLUS) return softplus_f(x);
     else return x;
@@ -405,57 +473,47 @@ __device__ __forceinline__ void flush(const f32x16 *__restrict__ pend, Frag *__r
     static_for<4>([&](auto kc) { epi_slice<ACT, 4, decltype(kc)::value>(pend, out4); });
 }
 
-// one-tile linear head (rows 0..31 of which only the first few are real); two accumulators over
-// even / odd k-steps break the dependent MFMA chain.  Returns scaled outputs.
+// one-tile linear head (rows 0..31 of which only the first few are real): the three products of a
+// k-step go to three accumulators, so no MFMA depends on its predecessor.  Same slot structure as chunk().
 template <int KS, int NEXT_BYTES, bool LAST, class Bias, class Pre>
 __device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, Bias &bias, const float *bias_head, int h, Pre &&pre)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x16 a0, a1;
+    f32x16 a0, a1, a2;
     bias.take(&a0, 1, h);
     if constexpr (LAST) bias.rewind(bias_head);      // the next block is the first one of the next point tile
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { a1[r] = 0.f; a2[r] = 0.f; }
 #if !AVC_DBG_NO_BARRIER
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #endif
-    // Values every address of this chunk derives from are made opaque HERE, after the barrier: with
-    // everything unrolled and compile-time, the compiler otherwise hoists the address arithmetic of all
-    // ~60 chunks of a tile (hundreds of 64-bit values) to the top of the tile loop and spills them.
     unsigned base = s.parity * layout::SLOT_BYTES + s.lane_off;
     unsigned so = s.pf_off;
     unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES;
     asm volatile("" : "+v"(base), "+s"(so), "+s"(dst));
     const char *src = s.gs + so;
-    constexpr int NP = 4 * ((NEXT_BYTES + GROUP - 1) / GROUP);
-    constexpr int PPK = (NP + KS - 2) / (KS - 1);
-    const unsigned wave = s.wave_off >> 10;
+    constexpr PfPlan P = pf_plan(KS, NEXT_BYTES);
+    u32x4 st[P.ring];
     static_for<KS>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const half8 ah = *reinterpret_cast<const half8 *>(smem + base + k * layout::UNIT_BYTES);
         const half8 al = *reinterpret_cast<const half8 *>(smem + base + k * layout::UNIT_BYTES + 1024);
-        static_for<PPK>([&](auto pc) {
-            constexpr int piece = k * PPK + decltype(pc)::value;
-            if constexpr (piece < NP && !AVC_DBG_NO_PREFETCH) prefetch_piece<NEXT_BYTES, piece>(src, s.lane_off, wave, dst);
-        });
         if constexpr (k == 0) bias.after_barrier(h);
+        pf_step<KS, NEXT_BYTES, 3 * k + 0, P.ring>(st, src, dst, s.lane_off, s.wave);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].hi), a0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        pf_step<KS, NEXT_BYTES, 3 * k + 1, P.ring>(st, src, dst, s.lane_off, s.wave);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].lo), a1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        pf_step<KS, NEXT_BYTES, 3 * k + 2, P.ring>(st, src, dst, s.lane_off, s.wave);
         pre(kc);
-        if constexpr (k & 1) {
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].hi), a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].lo), a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_half8(in[k].hi), a1, 0, 0, 0);
-        } else {
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].hi), a0, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].lo), a0, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_half8(in[k].hi), a0, 0, 0, 0);
-        }
+        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_half8(in[k].hi), a2, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     });
     const unsigned no = s.pf_off + NEXT_BYTES;
     s.pf_off = no >= s.total ? 0u : no;
     s.parity ^= 1u;
-    return a0 + a1;
+    return a0 + a1 + a2;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -531,14 +589,18 @@ __device__ __forceinline__ void posenc(const float q[3], int h, unsigned park)
 
 __device__ __forceinline__ Stream stream_init(const QueryParams &p, int wave, int lane, int first_bytes)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     Stream s;
-    s.wave_off = wave * 1024u; s.lane_off = lane * 16u;
-    s.gs = p.wstream; s.voff = s.wave_off + s.lane_off;
+    s.wave = wave; s.lane_off = lane * 16u;
+    s.gs = p.wstream;
     s.total = p.stream_bytes; s.parity = 0;
-    // chunk 0 -> slot 0 (same group layout as prefetch_piece, run-time sizes)
+    // chunk 0 -> slot 0, synchronously (same group layout as the pipelined copy; run-time sizes)
     for (int g0 = 0; g0 < first_bytes; g0 += GROUP) {
         const int gb = first_bytes - g0 >= GROUP ? GROUP : first_bytes - g0, per_wave = gb / WAVES;
-        for (int o = 0; o < per_wave; o += 1024) glds16<0>(s.gs + g0 + wave * per_wave + o + s.lane_off, g0 + wave * per_wave + o);
+        for (int o = 0; o < per_wave; o += 1024) {
+            const unsigned off = g0 + wave * per_wave + o + s.lane_off;
+            *reinterpret_cast<u32x4 *>(smem + off) = *reinterpret_cast<const u32x4 *>(p.wstream + off);
+        }
     }
     s.pf_off = first_bytes;
     return s;
@@ -561,6 +623,9 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
     constexpr int B_FIRST = WARP ? B_IN67 : B_PE;       // first chunk of a pass (the prefetcher wraps to it)
 
     Stream s = stream_init(p, wave, lane, B_FIRST);
+#if AVC_DBG_TIMING
+    const long long tk0 = clock64();
+#endif
     BiasQueue bias;
     bias.next = p.bias;
     bias.fetch(h);                       // first block; afterwards every chunk fetches its successor's
@@ -639,8 +704,12 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#if AVC_DBG_TIMING
+    if (lane == 0 && p.out1) {     // debug: overwrite the head of the offsets buffer with (total, barrier) cycles per wave
+        long long *dbg = reinterpret_cast<long long *>(p.out1) + 2 * (blockIdx.x * 4 + wave);
+        dbg[0] = clock64() - tk0; dbg[1] = s.t_bar;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -706,8 +775,6 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
         const f32x16 o = head<8, B_IN33, true>(s, X, bias, p.bias, h, Pending<ACT_LEAKY, 4>{pend, X + 4});
         if (h == 0 && pidx_raw < p.n) p.out0[pidx_raw] = sigmoid_f(o[0]);                         // last_op sigmoid
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------

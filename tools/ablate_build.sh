@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 OBJ=avatarcap_amd/csrc/_obj; OUT=avatarcap_amd/csrc/_abl; mkdir -p $OUT
-for V in NO_PREFETCH NO_BARRIER NO_SIDE "NO_PREFETCH NO_BARRIER" "NO_PREFETCH NO_BARRIER NO_SIDE"; do
+for V in ${ABL_VARIANTS:-NO_PREFETCH PF_LOAD_ONLY PF_STORE_ONLY PF_SAME}; do
   TAG=$(echo "$V" | tr ' ' '_')
   FL=$(for x in $V; do echo -n "-DAVC_DBG_$x=1 "; done)
   [ -f $OUT/lib_$TAG.so ] && [ $OUT/lib_$TAG.so -nt avatarcap_amd/csrc/fused_mlp.hip ] && continue
