@@ -352,15 +352,15 @@ __device__ __forceinline__ float softplus_f(float m)
 {
     // torch.nn.Softplus(beta=1, threshold=20)   (network/mlp.py:99).  pack.cpp folds log2(e) into the
     // weights/bias of every Softplus layer and ln(2) into its consumers, so the accumulator already is
-    // m = x*log2(e) and the activation carried between layers is y/ln2 = log2(1 + 2^m): v_exp_f32,
-    // v_add, v_log_f32.  m is clamped at 64, where 1 + 2^m == 2^m in fp32, so large x returns x (the
-    // reference's threshold branch) and nothing overflows; for very negative x the result underflows
-    // to 0 with absolute error < 1e-7.  The clamp is a bare v_min_f32: fminf() would add a
-    // canonicalising v_max in front of it, and at one wave per SIMD every VALU instruction costs
-    // ~2.5 cycles of MFMA issue (tools/ubench/mfma_fill.hip).
-    float c;
-    asm("v_min_f32 %0, 0x42800000, %1" : "=v"(c) : "v"(m));
-    return __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(c));
+    // m = x*log2(e) and the activation carried between layers is y/ln2 = log2(1 + 2^m), evaluated as
+    //     max(m, 0) + log2(1 + 2^-|m|)
+    // on v_exp_f32 / v_log_f32 (the -|m| is a free source modifier): exact for any magnitude (large x
+    // returns x, the reference's threshold branch; nothing overflows), absolute error ~1e-7.
+    // The max is a bare v_max_f32: fmaxf() would add a canonicalising v_max in front of it, and at one
+    // wave per SIMD every VALU instruction costs ~2.5 cycles of MFMA issue (tools/ubench/mfma_fill.hip).
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(m));
+    return r + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-__builtin_fabsf(m)));
 }
 
 template <int ACT>

@@ -192,6 +192,15 @@ def main():
     o = net.forward(t(wp[None].copy()), None, t(dists), b2, pts_space='cano')
     out['G12_raw'], out['G12_occ'], out['G12_off'] = o['raw'].numpy()[0], o['occ'].numpy()[0], o['nonrigid_offset'].numpy()[0]
 
+    # ---- G13: GeoTexAvatar.forward(pts_space='posed') (inverse skinning + blend-weight volume) -------
+    jm13 = syn.random_pose_jnt_mats(gi.SEED_POSE + 1, sigma=0.15)
+    live_v = gi.live_smpl_vertices(body, jm13)
+    wl = gi.live_query_points(112, 500, live_v)
+    b3 = {'cano_smpl_center': t(center[None]), 'cano_bounds': t(syn.CANO_BOUNDS[None]), 'live_smpl_v': t(live_v[None]),
+          'cano2live_jnt_mats': t(jm13[None])}
+    o = net.forward(t(wl[None].copy()), None, t(np.full((1, 500, 1), 0.0016, np.float32)), b3, pts_space='posed')
+    out['G13_raw'], out['G13_occ'], out['G13_off'] = o['raw'].numpy()[0], o['occ'].numpy()[0], o['nonrigid_offset'].numpy()[0]
+
     path = os.path.join(HERE, 'reference_golden.npz')
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024), 'keys', len(out))

@@ -119,3 +119,16 @@ def raw_and_z(seed, rays, samples):
     raw[..., 3] *= 0.3
     z = np.sort(rs.uniform(0.9, 1.1, (rays, samples)), -1).astype(np.float32)
     return raw, z
+
+
+def live_smpl_vertices(body, jnt_mats):
+    """Posed synthetic-SMPL vertices: plain LBS of the canonical vertices with their own skin weights."""
+    M = np.einsum('nj,jxy->nxy', body['skin_weights'].astype(np.float64), jnt_mats.astype(np.float64))
+    v = body['cano_smpl_v'].astype(np.float64)
+    return (np.einsum('nxy,ny->nx', M[:, :3, :3], v) + M[:, :3, 3]).astype(np.float32)
+
+
+def live_query_points(seed, n, live_v):
+    rs = np.random.RandomState(seed)
+    v = live_v[rs.choice(live_v.shape[0], n, replace=False)]
+    return (v + rs.uniform(-0.03, 0.03, v.shape)).astype(np.float32)

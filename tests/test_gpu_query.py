@@ -108,3 +108,23 @@ def test_recon_decoder_vs_oracle(n):
     imap = gi.img_feat_map(seed=210)
     y = rn.decode(_t(pts[None]), _t(imap[None]), _t(gi.center()[None]))
     assert maxabs(y.cpu().numpy().reshape(-1), orc.recon_infer(pts, imap, gi.center(), recon_sd())) < TOL
+
+
+def test_avatar_query_large_preactivations(net):
+    """Softplus pre-activations far beyond torch's threshold (20) and beyond 64*ln2: the log2-domain
+    evaluation must keep returning x there (a clamp once silently saturated them)."""
+    from avatarcap_amd.network.arch_avatar import OccupancyNet
+    from oracle import avatarcap_oracle as orc
+    config.if_type = 'sdf'
+    fmap = (6.0 * gi.pose_feat_map(seed=321)).astype(np.float32)
+    net.warping_field.pose_feat_map = _t(fmap[None])
+    net.warping_field._map_on_device = None
+    pts = gi.query_points(4321, 3000)
+    out = OccupancyNet(net).query(_batch(pts))
+    ref = orc.occupancy_query(pts, fmap, gi.center(), geotex_sd())
+    scale = max(1.0, float(np.abs(ref['nonrigid_offset']).max()))
+    assert maxabs(out['nonrigid_offset'][0].cpu().numpy(), ref['nonrigid_offset']) < 1e-4 * scale
+    # the template is ill-conditioned in its input (2^9 positional frequency): compare it on the offsets the GPU produced
+    q = pts.astype(np.float64) + out['nonrigid_offset'][0].cpu().numpy().astype(np.float64)
+    _, _, occ = orc.double_tnet(q.astype(np.float32), geotex_sd(), with_colour=False)
+    assert maxabs(out['cano_pts_ov'][0].cpu().numpy(), occ) < 1e-4

@@ -111,3 +111,14 @@ def test_G12_geotex_forward_cano(golden, body):
     assert maxabs(raw, golden['G12_raw']) < 1e-4
     assert maxabs(occ, golden['G12_occ']) < 1e-4
     assert maxabs(off, golden['G12_off']) < 1e-4
+
+
+def test_G13_geotex_forward_posed(golden, body):
+    jm = syn.random_pose_jnt_mats(gi.SEED_POSE + 1, sigma=0.15)
+    live_v = gi.live_smpl_vertices(body, jm)
+    wl = gi.live_query_points(112, 500, live_v)
+    raw, occ, off, _ = orc.geotex_forward_posed(wl, np.full((500, 1), 0.0016, np.float32), gi.pose_feat_map(), gi.center(), syn.CANO_BOUNDS,
+                                                live_v, body['skin_weights'], gi.blend_weight_volume(), jm, geotex_sd())
+    assert maxabs(raw, golden['G13_raw']) < 2e-4
+    assert maxabs(occ, golden['G13_occ']) < 2e-4
+    assert maxabs(off, golden['G13_off']) < 1e-4
