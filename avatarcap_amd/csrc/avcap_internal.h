@@ -49,8 +49,10 @@ struct Timing { bool enabled = false; double total_ms[2] = {0, 0}; int64_t launc
 struct avc_ctx {
     int device = 0;
     int num_cus = 256;
-    avc::PackedNet warp_tmpl;      // warp + template packed as ONE stream (avatar query)
-    avc::PackedNet tmpl_only;      // template alone (pts_space == 'temp')
+    avc::PackedNet warp_tmpl;      // warp + template packed as ONE stream (avatar query), geometry only (shared.6 folded into geo.0)
+    avc::PackedNet warp_tmpl_clr;  // the same with the colour head (shared.6 kept)
+    avc::PackedNet tmpl_only;      // template alone (pts_space == 'temp'), geometry only
+    avc::PackedNet tmpl_only_clr;
     avc::PackedNet recon;
     bool warp_set = false, tmpl_set = false;
     // staged host-side effective weights until both halves of the avatar net have arrived

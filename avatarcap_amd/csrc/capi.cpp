@@ -37,7 +37,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
 {
     if (!ctx) return AVC_OK;
     hipSetDevice(ctx->device);
-    release(ctx->warp_tmpl); release(ctx->tmpl_only); release(ctx->recon);
+    release(ctx->warp_tmpl); release(ctx->warp_tmpl_clr); release(ctx->tmpl_only); release(ctx->tmpl_only_clr); release(ctx->recon);
     if (ctx->pose_feat_hwc) hipFree(ctx->pose_feat_hwc);
     if (ctx->img_feat_hwc) hipFree(ctx->img_feat_hwc);
     if (ctx->mc_scratch) hipFree(ctx->mc_scratch);

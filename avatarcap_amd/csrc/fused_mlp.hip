@@ -682,11 +682,17 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TY, TY, X, bias, h, RP{pb, Y + 12}, pa);
         dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12}, pb);
         dense<8, 16, layout::PE_KS, ACT_RELU, B_MAIN>(s, TY, P, X, bias, h, RP{pb, Y + 12}, pa);                     // shared 4 on [x|x0]
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12}, pb);
-        dense<8, 16, 0, ACT_NONE, B_MAIN>(s, TY, TY, X, bias, h, RP{pb, Y + 12}, pa);                                // shared 6: no activation (mlp.py:46,64)
-        dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TX, TX, Y, bias, h, Pending<ACT_NONE, 8>{pa, X + 12}, pb);           // geo 0
-        constexpr int AFTER_GEO = COLOUR ? B_MAIN : B_FIRST;
-        const f32x16 g = head<8, AFTER_GEO, !COLOUR>(s, Y, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pb, Y + 4});                         // geo 1: row 0 = occ/sdf, row 1 = sigma
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12}, pb);                                                       // shared 5
+        f32x16 g;
+        if constexpr (COLOUR) {
+            dense<8, 16, 0, ACT_NONE, B_MAIN>(s, TY, TY, X, bias, h, RP{pb, Y + 12}, pa);                                // shared 6: no activation (mlp.py:46,64)
+            dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TX, TX, Y, bias, h, Pending<ACT_NONE, 8>{pa, X + 12}, pb);           // geo 0
+            g = head<8, B_MAIN, false>(s, Y, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pb, Y + 4});                      // geo 1: row 0 = occ/sdf, row 1 = sigma
+        } else {
+            // geometry only: pack.cpp folded shared.6 (linear) into geo.0 -- one 256->128 layer instead of two
+            dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TY, TY, X, bias, h, RP{pb, Y + 12}, pa);                              // geo 0 o shared 6
+            g = head<8, B_FIRST, true>(s, X, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pa, X + 4});                      // geo 1
+        }
 
         const bool writer = (h == 0) && (pidx_raw < p.n);
         if (writer) {
@@ -811,10 +817,12 @@ static unsigned bytes_until(const PackedNet &net, size_t nchunks)
 int launch_avatar(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], int occ_sigmoid,
                   float *occ, float *offset, float *rgba, bool template_only, hipStream_t s)
 {
-    PackedNet &net = template_only ? ctx->tmpl_only : ctx->warp_tmpl;
+    const bool colour = rgba != nullptr;
+    PackedNet &net = template_only ? (colour ? ctx->tmpl_only_clr : ctx->tmpl_only) : (colour ? ctx->warp_tmpl_clr : ctx->warp_tmpl);
+    AVC_REQUIRE(!colour || net.ready || !(template_only ? ctx->tmpl_only : ctx->warp_tmpl).ready, AVC_ERR_STATE,
+                "avatar query: rgba requested but clr_mlp weights were not packed");
     AVC_REQUIRE(net.ready, AVC_ERR_STATE, "avatar query: weights not packed (call avc_pack_warp_weights and avc_pack_template_weights)");
     AVC_REQUIRE(template_only || ctx->pose_feat_hwc, AVC_ERR_STATE, "avatar query: pose feature map not set (WarpingField.precompute_conv)");
-    AVC_REQUIRE(!rgba || net.has_colour, AVC_ERR_STATE, "avatar query: rgba requested but clr_mlp weights were not packed");
     if (n == 0) return AVC_OK;
     QueryParams p{};
     p.pts = pts; p.n = n; p.feat = ctx->pose_feat_hwc; p.H = ctx->pose_H; p.W = ctx->pose_W;
@@ -822,12 +830,7 @@ int launch_avatar(avc_ctx *ctx, const float *pts, int64_t n, const float center[
     p.wstream = (const char *)net.d_stream; p.bias = net.d_bias;
     p.out0 = occ; p.out1 = offset; p.out2 = rgba; p.sigmoid_occ = occ_sigmoid;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;
-    const bool colour = rgba != nullptr;
-    // a colour-capable stream ends with the clr chunks (clr0: 4 pair chunks, clr1: 2, clr2: 1); a
-    // geometry-only launch wraps around before them
-    size_t nch = net.chunks.size();
-    if (net.has_colour && !colour) nch -= 4 + 2 + 1;
-    p.stream_bytes = bytes_until(net, nch);
+    p.stream_bytes = bytes_until(net, net.chunks.size());
     const int grid = (int)std::min<int64_t>(p.ntiles, ctx->num_cus);
     hipEvent_t e0, e1;
     timing_begin(ctx, 0, s, e0, e1);

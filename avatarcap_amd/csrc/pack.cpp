@@ -169,14 +169,31 @@ static void add_warp(Builder &B, const avc_ctx::Staged &w)
     B.layer(scaled(w.W[7], LN2), w.b[7], 3, 256, {seg_d(16)}, 1, 16);             // out_layer_coord_affine (linear consumer)
 }
 
+// `colour` streams keep shared.6 (its output feeds both heads).  Geometry-only streams fold shared.6
+// (linear, no activation: mlp.py:46,64) into geo.0:  W_g0 (W_6 x + b_6) + b_g0 = (W_g0 W_6) x + (W_g0 b_6 + b_g0),
+// an exact identity that removes 65,536 of the 886,784 MAC per point (and one epilogue).
 static void add_template(Builder &B, const avc_ctx::Staged &t, bool colour)
 {
     B.layer(t.W[0], t.b[0], 256, 63, {seg_pe()}, 2, 16);                         // shared 0
     for (int i = 1; i <= 3; ++i) B.layer(t.W[i], t.b[i], 256, 256, {seg_d(16)}, 2, 16);
     B.layer(t.W[4], t.b[4], 256, 319, {seg_d(16), seg_pe(256)}, 2, 16);          // shared 4: cat([x, x0]) (mlp.py:61)
     B.layer(t.W[5], t.b[5], 256, 256, {seg_d(16)}, 2, 16);
-    B.layer(t.W[6], t.b[6], 256, 256, {seg_d(16)}, 2, 16);                       // shared 6 (linear)
-    B.layer(t.W[7], t.b[7], 128, 256, {seg_d(16)}, 2, 16);                       // geo 0
+    if (colour) {
+        B.layer(t.W[6], t.b[6], 256, 256, {seg_d(16)}, 2, 16);                   // shared 6 (linear)
+        B.layer(t.W[7], t.b[7], 128, 256, {seg_d(16)}, 2, 16);                   // geo 0
+    } else {
+        std::vector<double> Wf((size_t)128 * 256, 0.0), bf(128, 0.0);
+        for (int o = 0; o < 128; ++o) {
+            double acc_b = t.b[7][o];
+            for (int m = 0; m < 256; ++m) {
+                const double g = t.W[7][(size_t)o * 256 + m];
+                acc_b += g * t.b[6][m];
+                for (int i = 0; i < 256; ++i) Wf[(size_t)o * 256 + i] += g * t.W[6][(size_t)m * 256 + i];
+            }
+            bf[o] = acc_b;
+        }
+        B.layer(Wf, bf, 128, 256, {seg_d(16)}, 2, 16);                           // geo 0 o shared 6
+    }
     B.layer(t.W[8], t.b[8], 2, 128, {seg_d(8)}, 1, 16);                          // geo 1
     if (colour) {
         B.layer(t.W[9], t.b[9], 256, 256, {seg_d(16)}, 2, 16);                   // clr 0
@@ -187,23 +204,24 @@ static void add_template(Builder &B, const avc_ctx::Staged &t, bool colour)
 
 int pack_avatar(avc_ctx *ctx)
 {
-    const bool colour = ctx->tmpl_st.W.size() == 12;
-    if (ctx->tmpl_set) {
-        Builder B(ctx->tmpl_only);
+    const bool has_clr = ctx->tmpl_st.W.size() == 12;
+    auto build = [&](PackedNet &net, bool warp, bool colour) -> int {
+        Builder B(net);
+        if (warp) add_warp(B, ctx->warp_st);
         add_template(B, ctx->tmpl_st, colour);
-        AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "template weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
-        ctx->tmpl_only.has_colour = colour;
-        int rc = upload(ctx->tmpl_only);
+        AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
+        net.has_colour = colour;
+        return upload(net);
+    };
+    if (ctx->tmpl_set) {
+        int rc = build(ctx->tmpl_only, false, false);
         if (rc) return rc;
+        if (has_clr && (rc = build(ctx->tmpl_only_clr, false, true))) return rc;
     }
     if (ctx->warp_set && ctx->tmpl_set) {
-        Builder B(ctx->warp_tmpl);
-        add_warp(B, ctx->warp_st);
-        add_template(B, ctx->tmpl_st, colour);
-        AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "avatar weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
-        ctx->warp_tmpl.has_colour = colour;
-        int rc = upload(ctx->warp_tmpl);
+        int rc = build(ctx->warp_tmpl, true, false);
         if (rc) return rc;
+        if (has_clr && (rc = build(ctx->warp_tmpl_clr, true, true))) return rc;
     }
     return AVC_OK;
 }

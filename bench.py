@@ -18,7 +18,8 @@ The JSON line also carries:
   roofline     -- the dominant kernel (avatar_kernel): algorithmic FLOP/launch (1,773,568 per point,
                   SURVEY.md 8(d)) / mean launch time measured with HIP events on the launch stream,
                   against the dense fp16 MFMA peak (the kernel issues 3 fp16 MFMA passes per fp32
-                  product, so `mfma_util` = 3.06 x frac is the matrix-pipe utilisation).
+                  product, so `mfma_util` = 2.84 x frac is the matrix-pipe utilisation; `traffic` is the
+                  HBM byte count of the committed rocprofv3 --pmc pass, profiles/r01_pmc_avatar.md).
   cpu_baseline -- the CPU oracle (NumPy float32 port of the reference path + C marching cubes) timed
                   on this host on a bounded sample and scaled to one 256^3 frame.
   masked       -- the same frame with the reference's own valid-band masking (only points within 0.1 m
@@ -39,8 +40,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_POINT = 1_773_568          # warp 428,288 + shared 425,472 + geo 33,024 MAC
-MFMA_ISSUED_PER_POINT = 5304 * 32 * 32 * 16 * 2 / 32   # 5304 v_mfma_f32_32x32x16_f16 per 32 points
+MFMA_ISSUED_PER_POINT = 4920 * 32 * 32 * 16 * 2 / 32   # 4920 v_mfma_f32_32x32x16_f16 per 32 points (3 split passes,
+                                                        # tile padding, shared.6 folded into geo.0: DESIGN.md section 2)
 PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+HBM_TRAFFIC_BYTES_256 = 2.93e9      # per dense 256^3 launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc
 
 
 def build_pipeline(res, valid, n_frames, device):
@@ -168,7 +171,8 @@ def main():
                        'grid': [res] * 3, 'points_per_frame': N, 'vertices_last_frame': int(out['cano_v'].shape[0]),
                        'faces_last_frame': int(out['f'].shape[0]), 'parallelism': f'frame-sharded x{world}'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F16_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_F16_TFLOPS,
+                         'traffic': HBM_TRAFFIC_BYTES_256 if res == 256 else None, 'traffic_source': 'profiles/r01_pmc_avatar.md (FETCH_SIZE x2 + WRITE_SIZE)',
                          'kernel': 'avc::avatar_kernel<true,false>', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
                          'algorithmic_flop_per_launch': N * FLOP_PER_POINT,
                          'mfma_issued_tflops': N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0,
