@@ -40,6 +40,9 @@
 #ifndef AVC_DBG_NO_SIDE
 #define AVC_DBG_NO_SIDE 0
 #endif
+#ifndef AVC_DBG_OCML_SINCOS
+#define AVC_DBG_OCML_SINCOS 0
+#endif
 #ifndef AVC_DBG_TIMING
 #define AVC_DBG_TIMING 0
 #endif
@@ -562,18 +565,47 @@ __device__ __forceinline__ void bilinear_frag(const Bilinear &b, int c, Frag &f)
     split8(v, f.hi, f.lo);
 }
 
+// sin and cos of q * S for S = 2^f, to ~1.6e-7 absolute (tools: see DESIGN.md section 2) in ~25 VALU
+// instead of the ~300 of ocml's sincosf for arguments of a few hundred radians: the angle is reduced
+// in REVOLUTIONS, q/(2 pi) as an unevaluated fp32 pair (p + e) via one FMA error term, so that the
+// power-of-two scaling, the round-to-nearest and the subtraction are all exact; then quadrant + the
+// classic degree-7/8 minimax polynomials on [-pi/4, pi/4].
+__device__ __forceinline__ void sincos_pow2(float q, float S, float &sn, float &cs)
+{
+    const float C_HI = 0.15915494f, C_LO = 4.5929136e-09f;           // 1/(2 pi) = C_HI + C_LO
+    const float p = q * C_HI;
+    float e = __builtin_fmaf(q, C_HI, -p);
+    e = __builtin_fmaf(q, C_LO, e);
+    const float ps = p * S, es = e * S;
+    const float r = (ps - __builtin_rintf(ps)) + es;                   // revolutions, |r| <= 0.5 (+ eps)
+    const float kq = __builtin_rintf(4.0f * r);
+    const float x = __builtin_fmaf(kq, -0.25f, r) * 6.2831853071795865f;   // [-pi/4, pi/4]
+    const float z = x * x;
+    const float sp = (-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f;
+    const float sinp = __builtin_fmaf(sp * z, x, x);
+    const float cp = (2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f;
+    const float cosp = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    const int iq = (int)kq & 3;
+    const float a = (iq & 1) ? cosp : sinp, b = (iq & 1) ? sinp : cosp;
+    sn = (iq & 2) ? -a : a;
+    cs = ((iq + 1) & 2) ? -b : b;
+}
+
 // NeRF positional encoding of q (3 floats) into the 4 k-steps of the PE layout (mlp_layout.h):
 // lane-half h evaluates arguments 15h .. 15h+14: coordinate i%3, frequency 2^(5h + i/3) -- exact
-// power-of-two scaling like the reference's x * freq (net_util.py:27-33), accurate sincosf.
+// power-of-two scaling like the reference's x * freq (net_util.py:27-33).
 __device__ __forceinline__ void posenc(const float q[3], int h, unsigned park)
 {
     float v[32];
     const float hs = h ? 32.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < 15; ++i) {
-        const float arg = q[i % 3] * (float)(1 << (i / 3)) * hs;
         float sn, cs;
-        sincosf(arg, &sn, &cs);
+#if AVC_DBG_OCML_SINCOS
+        sincosf(q[i % 3] * (float)(1 << (i / 3)) * hs, &sn, &cs);
+#else
+        sincos_pow2(q[i % 3], (float)(1 << (i / 3)) * hs, sn, cs);
+#endif
         v[2 * i] = sn;
         v[2 * i + 1] = cs;
     }

@@ -14,32 +14,55 @@
 namespace avc {
 namespace {
 
-constexpr int REF_TILE = 2048;   // reference points per LDS tile (24 KiB)
+constexpr int REF_TILE = 2048;   // reference points per LDS tile (32 KiB as float4)
 
 template <int K>
+__device__ __forceinline__ void knn_insert(float d, int id, float (&bd)[K], int (&bi)[K])
+{
+    if (d < bd[K - 1]) {
+        bd[K - 1] = d; bi[K - 1] = id;
+#pragma unroll
+        for (int k = K - 1; k > 0; --k) {
+            if (bd[k] < bd[k - 1]) {
+                const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
+                const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
+            }
+        }
+    }
+}
+
+// Reference points are staged as float4 {x,y,z,-} so one ds_read_b128 (a broadcast: every lane reads
+// the same address) feeds a candidate, four candidates per loop trip; the running K-th best distance
+// gates the (rare) sorted insertion.
+template <int K>
 __device__ __forceinline__ void knn_scan(const float *__restrict__ ref, int nr, float qx, float qy, float qz,
-                                         float (&bd)[K], int (&bi)[K], float *lds)
+                                         float (&bd)[K], int (&bi)[K], float4 *lds)
 {
 #pragma unroll
     for (int k = 0; k < K; ++k) { bd[k] = __builtin_inff(); bi[k] = 0x7fffffff; }
     for (int r0 = 0; r0 < nr; r0 += REF_TILE) {
         const int cnt = min(REF_TILE, nr - r0);
         __syncthreads();
-        for (int i = threadIdx.x; i < cnt * 3; i += blockDim.x) lds[i] = ref[(size_t)r0 * 3 + i];
+        for (int i = threadIdx.x; i < REF_TILE; i += blockDim.x) {
+            float4 v = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);       // padding: never among the K nearest
+            if (i < cnt) v = make_float4(ref[(size_t)(r0 + i) * 3], ref[(size_t)(r0 + i) * 3 + 1], ref[(size_t)(r0 + i) * 3 + 2], 0.f);
+            lds[i] = v;
+        }
         __syncthreads();
-        for (int i = 0; i < cnt; ++i) {
-            // (dx*dx + dy*dy) + dz*dz with separately rounded operations, as the oracle computes it
-            const float dx = qx - lds[3 * i], dy = qy - lds[3 * i + 1], dz = qz - lds[3 * i + 2];
-            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            if (d < bd[K - 1]) {
-                bd[K - 1] = d; bi[K - 1] = r0 + i;
+        const int cnt4 = (cnt + 3) & ~3;
+        for (int i = 0; i < cnt4; i += 4) {
+            float d[4];
 #pragma unroll
-                for (int k = K - 1; k > 0; --k) {
-                    if (bd[k] < bd[k - 1]) {
-                        const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
-                        const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
-                    }
-                }
+            for (int u = 0; u < 4; ++u) {
+                const float4 r = lds[i + u];
+                // (dx*dx + dy*dy) + dz*dz with separately rounded operations (file built with -ffp-contract=off)
+                const float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
+                d[u] = (dx * dx + dy * dy) + dz * dz;
+            }
+            const float m = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+            if (m < bd[K - 1]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) knn_insert<K>(d[u], r0 + i + u, bd, bi);
             }
         }
     }
@@ -49,7 +72,7 @@ template <int K>
 __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ q, int64_t nq, const float *__restrict__ ref, int nr,
                                                   float *__restrict__ d2, int64_t *__restrict__ idx)
 {
-    __shared__ float lds[REF_TILE * 3];
+    __shared__ float4 lds[REF_TILE];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ii = i < nq ? i : nq - 1;
     float bd[K]; int bi[K];
@@ -63,7 +86,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ q, i
 __global__ __launch_bounds__(256) void lbs_kernel(const float *__restrict__ pts, int64_t n, const float *__restrict__ cano_v,
                                                   const float *__restrict__ skin_w, int nv, float *__restrict__ lbs)
 {
-    __shared__ float lds[REF_TILE * 3];
+    __shared__ float4 lds[REF_TILE];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ii = i < n ? i : n - 1;
     float bd[4]; int bi[4];

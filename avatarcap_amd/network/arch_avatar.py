@@ -226,6 +226,55 @@ class GeoTexAvatar(nn.Module):
         return {'raw': torch.cat([rgb, alpha], -1), 'occ': occ, 'nonrigid_offset': offsets}
 
 
+class NerfRenderer:
+    """Volume rendering along rays with the GeoTexAvatar as the field (arch_avatar.py:240-349), eval mode
+    (no stratified perturbation: `config.perturb` only acts while training, :257).  Used by the test
+    loop to colour the avatar's vertices: rays start one unit off the surface along the normal and
+    march back through it (main.py:464-477)."""
+
+    def __init__(self, net: GeoTexAvatar):
+        self.net = net
+
+    def get_wsampling_points(self, ray_o, ray_d, near, far):
+        t_vals = torch.linspace(0., 1., steps=config.N_samples).to(near)                   # :251
+        z_vals = near[..., None] * (1. - t_vals) + far[..., None] * t_vals
+        pts = ray_o[:, :, None] + ray_d[:, :, None] * z_vals[..., None]
+        return pts, z_vals
+
+    def get_density_color(self, wpts, viewdir, z_vals, batch, pts_space):
+        n_batch, n_pixel, n_sample = wpts.shape[:3]
+        wpts = wpts.reshape(n_batch, n_pixel * n_sample, -1)
+        dists = z_vals[..., 1:] - z_vals[..., :-1]                                         # :279-281
+        dists = torch.cat([dists, dists[..., -1:]], dim=2).reshape(n_batch, n_pixel * n_sample, -1)
+        return self.net(wpts, None, dists, batch, pts_space)
+
+    def get_pixel_value(self, ray_o, ray_d, near, far, occ, depth, batch, pts_space='posed', near_dist=0.05, far_dist=0.05):
+        valid = depth > 1e-6                                                               # :289-291
+        near = torch.where(valid, depth - near_dist, near)
+        far = torch.where(valid, depth + far_dist, far)
+        wpts, z_vals = self.get_wsampling_points(ray_o, ray_d, near, far)
+        ret = self.get_density_color(wpts, ray_d, z_vals, batch, pts_space)
+        n_batch, n_pixel, n_sample = z_vals.shape
+        from ..utils.nerf_util import raw2outputs
+        raw = ret['raw'].reshape(-1, n_sample, 4)
+        rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals.reshape(-1, n_sample), white_bkgd=False)
+        ret.update({'rgb_map': rgb_map.view(n_batch, n_pixel, -1), 'acc_map': acc_map.view(n_batch, n_pixel),
+                    'depth_map': depth_map.view(n_batch, n_pixel), 'raw': raw.view(n_batch, -1, 4)})
+        return ret
+
+    def render(self, batch, pts_space='posed', near_dist=0.05, far_dist=0.05, chunk=1 << 16):
+        """batch keys: ray_o, ray_d (B,P,3), near, far, occupancy, depth (B,P).  The reference walks the
+        rays 2048 at a time (:330); the fused kernel has no activation tensors to bound, so the chunk is
+        only a cap on the (P*64,3) point buffer."""
+        n_pixel = batch['ray_o'].shape[1]
+        rets = []
+        for i in range(0, n_pixel, chunk):
+            sl = slice(i, i + chunk)
+            rets.append(self.get_pixel_value(batch['ray_o'][:, sl], batch['ray_d'][:, sl], batch['near'][:, sl], batch['far'][:, sl],
+                                             batch['occupancy'][:, sl], batch['depth'][:, sl], batch, pts_space, near_dist, far_dist))
+        return {k: torch.cat([r[k] for r in rets], dim=1) for k in rets[0].keys()}
+
+
 class OccupancyNet:
     """Chunk-free grid query (arch_avatar.py:352-381)."""
 

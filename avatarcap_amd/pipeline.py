@@ -67,3 +67,21 @@ class FramePipeline:
             res['live_v'] = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'])[0]       # :452
             res['live_vn'] = smpl_util.skinning_normal(n[None], lbs, items['cano2live_jnt_mats'])[0]   # :453
         return res
+
+
+    @torch.no_grad()
+    def colour_vertices(self, items: dict, cano_v: torch.Tensor, cano_vn: torch.Tensor, renderer=None):
+        """4. vertex colours from the texture template (main.py:464-477): one 64-sample ray per vertex,
+        starting at v + n and marching along -n, alpha-composited.  Returns (V,3) in the reference's BGR order."""
+        from .network.arch_avatar import NerfRenderer
+        renderer = renderer or NerfRenderer(self.network)
+        items = dict(items)
+        items['ray_o'] = (cano_v + cano_vn)[None]
+        items['ray_d'] = -cano_vn[None]
+        items['depth'] = torch.ones((1, cano_v.shape[0]), dtype=cano_v.dtype, device=cano_v.device)
+        items['near'] = items['depth'] - 0.05
+        items['far'] = items['depth'] + 0.05
+        items['occupancy'] = items['depth'].clone()
+        self.network.warping_field.precompute_conv(items)                                           # :474
+        out = renderer.render(items, pts_space='cano', near_dist=0.02, far_dist=0.05)               # :475
+        return out['rgb_map'][0][:, [2, 1, 0]]                                                      # :476

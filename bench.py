@@ -43,7 +43,7 @@ FLOP_PER_POINT = 1_773_568          # warp 428,288 + shared 425,472 + geo 33,024
 MFMA_ISSUED_PER_POINT = 4920 * 32 * 32 * 16 * 2 / 32   # 4920 v_mfma_f32_32x32x16_f16 per 32 points (3 split passes,
                                                         # tile padding, shared.6 folded into geo.0: DESIGN.md section 2)
 PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
-HBM_TRAFFIC_BYTES_256 = 2.93e9      # per dense 256^3 launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc
+HBM_TRAFFIC_BYTES_256 = 0.72e9      # per dense 256^3 launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc
 
 
 def build_pipeline(res, valid, n_frames, device):
