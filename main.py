@@ -19,7 +19,8 @@ import numpy as np
 import torch
 
 
-def run_avatarcap(w_recon=True, frame_idx=None, interval=1, synthetic=False, n_frames=2, valid='band'):
+def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w_nerf=False, frame_idx=None, interval=1,
+                  synthetic=False, n_frames=2, valid='band'):
     from avatarcap_amd import config, synthetic as syn
     from avatarcap_amd.dataset import SyntheticTestDataset, to_cuda
     from avatarcap_amd.network.arch_avatar import GeoTexAvatar
@@ -58,6 +59,15 @@ def run_avatarcap(w_recon=True, frame_idx=None, interval=1, synthetic=False, n_f
             items['front_normal'], items['back_normal'] = nm[None, :3], nm[None, 3:]
             r = pipe.recon_frame(items)                                           # step 3
             save.update({'recon_' + k: v for k, v in r.items() if k != 'occ_volume'})
+        if w_nerf:                                                                # step 4 (main.py:464-477)
+            save['live_vc'] = pipe.colour_vertices(items, a['cano_v'], a['cano_vn'])
+        from avatarcap_amd.utils import obj_io
+        if save_avatar_mesh and a.get('live_v') is not None:                          # main.py:491-493
+            obj_io.save_mesh_as_ply('%s/%04d_avatar.ply' % (out_dir, items['data_idx']), a['live_v'].cpu().numpy(), a['f'].cpu().numpy(),
+                                    a['live_vn'].cpu().numpy(), save['live_vc'].cpu().numpy() if w_nerf else None)
+        if w_recon and save_final_mesh and 'recon_live_v' in save:                     # main.py:495-498
+            obj_io.save_mesh_as_ply('%s/%04d_recon.ply' % (out_dir, items['data_idx']), save['recon_live_v'].cpu().numpy(),
+                                    save['recon_f'].cpu().numpy(), save['recon_live_vn'].cpu().numpy(), None)
         np.savez(os.path.join(out_dir, '%04d_mesh.npz' % items['data_idx']),
                  **{k: v.cpu().numpy() for k, v in save.items() if v is not None})
         print('# frame %d: avatar %d verts / %d faces%s' % (i, a['cano_v'].shape[0], a['f'].shape[0],
@@ -74,10 +84,13 @@ if __name__ == '__main__':
     arg_parser.add_argument('--synthetic', action='store_true', help='synthetic body / weights instead of the licensed data')
     arg_parser.add_argument('--frames', type=int, default=2)
     arg_parser.add_argument('--valid', type=str, default='band', choices=['band', 'dense'])
+    arg_parser.add_argument('--save-ply', action='store_true', help='write the live avatar / recon meshes as PLY (obj_io layout)')
+    arg_parser.add_argument('--nerf', action='store_true', help='also evaluate vertex colours (w_nerf)')
     args = arg_parser.parse_args()
 
     from avatarcap_amd import config
     config.cfg = config.load_config(args.config_path) if args.config_path else config.default_cfg()
     if args.mode == 'train':
         raise SystemExit('-m train is out of scope for the MI355X hot-path build (SURVEY.md section 2, row 12)')
-    run_avatarcap(w_recon=True, synthetic=args.synthetic, n_frames=args.frames, valid=args.valid)
+    run_avatarcap(w_recon=True, save_avatar_mesh=args.save_ply, save_final_mesh=args.save_ply, w_nerf=args.nerf,
+                  synthetic=args.synthetic, n_frames=args.frames, valid=args.valid)

@@ -201,6 +201,14 @@ def main():
     o = net.forward(t(wl[None].copy()), None, t(np.full((1, 500, 1), 0.0016, np.float32)), b3, pts_space='posed')
     out['G13_raw'], out['G13_occ'], out['G13_off'] = o['raw'].numpy()[0], o['occ'].numpy()[0], o['nonrigid_offset'].numpy()[0]
 
+    # ---- G14: binary PLY layout (utils/obj_io.py:223-269), bytes of three tiny meshes ---------------
+    from utils import obj_io
+    pv, pf, pn, pc = gi.ply_mesh()
+    for tag, kw in (('v', {}), ('vn', {'normals': pn}), ('vnc', {'normals': pn, 'colors': pc.copy()})):
+        fn = os.path.join(tempfile.mkdtemp(), 'm.ply')
+        obj_io.save_mesh_as_ply(fn, pv, pf, **kw)
+        out['G14_ply_' + tag] = np.frombuffer(open(fn, 'rb').read(), np.uint8)
+
     path = os.path.join(HERE, 'reference_golden.npz')
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in out.items()})
     print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024), 'keys', len(out))

@@ -132,3 +132,10 @@ def live_query_points(seed, n, live_v):
     rs = np.random.RandomState(seed)
     v = live_v[rs.choice(live_v.shape[0], n, replace=False)]
     return (v + rs.uniform(-0.03, 0.03, v.shape)).astype(np.float32)
+
+
+def ply_mesh():
+    rs = np.random.RandomState(14)
+    v = rs.randn(7, 3).astype(np.float32); n = unit_vectors(15, 7)
+    f = rs.randint(0, 7, (5, 3)).astype(np.int32); c = rs.rand(7, 3).astype(np.float32) * 0.99
+    return v, f, n, c

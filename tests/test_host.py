@@ -122,3 +122,12 @@ def test_dense_dataset_item_keys_cpu():
     assert it['cano2live_jnt_mats'].shape == (24, 4, 4)
     with pytest.raises(ValueError):
         SyntheticTestDataset([4, 4, 4], valid='nope', device='cpu')
+
+
+def test_ply_writer_is_byte_identical_to_reference(golden, tmp_path):
+    from avatarcap_amd.utils.obj_io import save_mesh_as_ply
+    v, f, n, c = gi.ply_mesh()
+    for tag, kw in (('v', {}), ('vn', {'normals': n}), ('vnc', {'normals': n, 'colors': c.copy()})):
+        fn = tmp_path / f'{tag}.ply'
+        save_mesh_as_ply(str(fn), v, f, **kw)
+        assert np.array_equal(np.frombuffer(fn.read_bytes(), np.uint8), golden['G14_ply_' + tag]), tag
