@@ -63,6 +63,7 @@ struct avc_ctx {
     // scratch for meshing
     void *mc_scratch = nullptr; size_t mc_scratch_bytes = 0;
     uint32_t *mc_tables_dev = nullptr;
+    void *raster_scratch = nullptr; size_t raster_scratch_bytes = 0;
     avc::Timing timing;
 };
 
@@ -81,6 +82,9 @@ int launch_scatter(const uint8_t *valid, int64_t N, const float *values, const f
 // mesh.hip
 int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float bounds[6], float iso,
                float *verts, float *normals, int32_t *faces, int64_t cap_v, int64_t cap_f, int64_t counts[2], hipStream_t s);
+// raster.hip
+int render_cano_maps(avc_ctx *ctx, const float *verts, const float *attrs, const int32_t *faces, int64_t nf, const float center[3],
+                     int size, float *front, float *back, hipStream_t s);
 // knn_lbs.hip
 int knn(const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, hipStream_t s);
 int calculate_lbs(const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s);

@@ -42,6 +42,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->img_feat_hwc) hipFree(ctx->img_feat_hwc);
     if (ctx->mc_scratch) hipFree(ctx->mc_scratch);
     if (ctx->mc_tables_dev) hipFree(ctx->mc_tables_dev);
+    if (ctx->raster_scratch) hipFree(ctx->raster_scratch);
     for (int w = 0; w < 2; ++w)
         for (auto &pr : ctx->timing.pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     delete ctx;
@@ -177,6 +178,16 @@ int avc_recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const f
     AVC_REQUIRE((int64_t)res[0] * res[1] * res[2] < (int64_t)1 << 31, AVC_ERR_ARG, "avc_recon_mesh: volume too large for 32-bit voxel indices");
     AVC_HIP(hipSetDevice(ctx->device));
     return recon_mesh(ctx, vol, res, bounds, iso, verts, normals, faces, cap_v, cap_f, counts, (hipStream_t)stream);
+}
+
+int avc_render_cano_maps(avc_ctx *ctx, const float *verts, const float *attrs, int64_t nv, const int32_t *faces, int64_t nf,
+                         const float center[3], int size, float *front, float *back, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && center && front && back && nf >= 0 && nv >= 0 && (nf == 0 || (verts && attrs && faces)), AVC_ERR_ARG,
+                "avc_render_cano_maps: NULL argument");
+    AVC_REQUIRE(size >= 1 && size <= 8192, AVC_ERR_ARG, "avc_render_cano_maps: size must be in [1, 8192]");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return render_cano_maps(ctx, verts, attrs, faces, nf, center, size, front, back, (hipStream_t)stream);
 }
 
 int avc_knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, avc_stream stream)

@@ -29,12 +29,12 @@ def _pack(meshes, device):
     return counts, vbuf.to(torch.float32), fbuf
 
 
-def all_gather_meshes(meshes: list[dict], n_frames: int, group=None) -> list[dict]:
+def all_gather_meshes(meshes: list[dict], n_frames: int, group=None, force: bool = False) -> list[dict]:
     """meshes: this rank's frames in ascending frame order, each {'v' (V,3) f32, 'vn' (V,3) f32,
     'f' (F,3) i32}.  Returns, on every rank, all n_frames meshes in frame order."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if world == 1:
+    if world == 1 and not force:      # `force` runs the collectives even with one rank (RCCL smoke test)
         return list(meshes)
     device = meshes[0]['v'].device if meshes else torch.device('cpu')
     kmax = (n_frames + world - 1) // world

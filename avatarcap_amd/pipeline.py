@@ -70,6 +70,26 @@ class FramePipeline:
 
 
     @torch.no_grad()
+    def cano_normal_maps(self, cano_v, cano_vn, faces, size=512):
+        """Front / back canonical normal maps of a mesh (visualize_util.render_cano_mesh, main.py:369):
+        (1,3,H,W) tensors in the layout ReconNetwork.infer expects (main.py:432-433)."""
+        from .utils.visualize_util import render_cano_mesh_device
+        fr, bk = render_cano_mesh_device(cano_v, cano_vn, faces, self.ds.cano_smpl_center, size)
+        return fr.permute(2, 0, 1)[None].contiguous(), bk.permute(2, 0, 1)[None].contiguous()
+
+    @torch.no_grad()
+    def full_frame(self, items: dict):
+        """Steps 1 and 3 chained on the device: avatar geometry -> its normal maps -> reconstruction.
+        Step 2 of the reference (fusion with image-observed normals, normal_fusion.py) needs a captured
+        image and is not part of this path: the avatar's own maps are passed through, which is what
+        `merge_normal_images_cover` yields when no pixel is observed (normal_fusion.py:158-167)."""
+        a = self.avatar_frame(items)
+        items = dict(items)
+        items['front_normal'], items['back_normal'] = self.cano_normal_maps(a['cano_v'], a['cano_vn'], a['f'])
+        r = self.recon_frame(items)
+        return a, r
+
+    @torch.no_grad()
     def colour_vertices(self, items: dict, cano_v: torch.Tensor, cano_vn: torch.Tensor, renderer=None):
         """4. vertex colours from the texture template (main.py:464-477): one 64-sample ray per vertex,
         starting at v + n and marching along -n, alpha-composited.  Returns (V,3) in the reference's BGR order."""

@@ -110,7 +110,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
+    force_dist = os.environ.get('AVC_FORCE_DIST') == '1' and 'RANK' in os.environ    # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
@@ -134,8 +135,8 @@ def main():
     out = None
     for s in range(W):
         out = pipe.avatar_frame(my[s])
-    if world > 1:   # warm the collective too
-        all_gather_meshes([{'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']}], world)
+    if world > 1 or force_dist:   # warm the collective too
+        all_gather_meshes([{'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']}], world, force=force_dist)
     barrier()
     _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
     t0 = time.perf_counter()
@@ -143,8 +144,8 @@ def main():
     for s in range(W, W + K):
         out = pipe.avatar_frame(my[s])
         meshes.append({'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']})
-    if world > 1:
-        gathered = all_gather_meshes(meshes, world * K)
+    if world > 1 or force_dist:
+        gathered = all_gather_meshes(meshes, world * K, force=force_dist)
         assert len(gathered) == world * K
     barrier()
     dt = time.perf_counter() - t0
@@ -187,7 +188,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(pipe, sd, out, res)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -118,6 +118,18 @@ int avc_recon_mesh(avc_ctx *ctx, const float *vol_dev, const int32_t res[3], con
                    float iso, float *verts_out_dev, float *normals_out_dev, int32_t *faces_out_dev,
                    int64_t cap_v, int64_t cap_f, int64_t counts_out[2], avc_stream stream);
 
+/* ---- canonical normal maps -------------------------------------------------------------------
+ * visualize_util.render_cano_mesh with the 'vertex_attribute' renderer (utils/visualize_util.py:11-52,
+ * utils/renderer.py:10-29,316-323,432-451): orthographic front and back rasters of the mesh translated
+ * by -center, x,y in [-1,1] -> size x size pixels (row 0 at y=+1), depth-tested, back faces culled,
+ * per-vertex attribute (the canonical normal) interpolated, 0 background; the back map is already
+ * mirrored so that both maps are pixel-aligned.  Replaces the reference's OpenGL context + read-back;
+ * parity with a GL driver is UNPINNED (oracle/raster_oracle.c).
+ *   verts_dev, attrs_dev (nv,3) f32; faces_dev (nf,3) i32; front_out_dev, back_out_dev (size,size,3) f32 */
+int avc_render_cano_maps(avc_ctx *ctx, const float *verts_dev, const float *attrs_dev, int64_t nv,
+                         const int32_t *faces_dev, int64_t nf, const float center[3], int size,
+                         float *front_out_dev, float *back_out_dev, avc_stream stream);
+
 /* ---- SMPL utilities ------------------------------------------------------------------------
  * K nearest of nr reference points per query, squared L2 ascending, ties -> lower index
  * (pytorch3d.ops.knn_points as used at utils/smpl_util.py:33, dataset/avatarcap_dataset.py:114,

@@ -165,3 +165,26 @@ def test_vertex_colours_match_oracle(pipe64):
                                         ds.cano_bounds, ds.body['cano_smpl_v'], geotex_sd())
     rgb_ref = orc.raw2outputs(raw.reshape(300, -1, 4), np.tile(z, (300, 1)))[0][:, [2, 1, 0]]
     assert maxabs(rgb.cpu().numpy(), rgb_ref) < 2e-4
+
+
+def test_full_frame_chain(pipe64):
+    """avatar -> canonical normal maps -> reconstruction network, all on the device (main.py:357-453 minus
+    the image-normal fusion).  The maps must equal the oracle rasteriser's on the avatar mesh and the
+    reconstruction must equal recon_frame fed with those maps."""
+    from avatarcap_amd.dataset import to_cuda
+    from oracle import raster
+    ds = pipe64.ds
+    items = to_cuda(ds[0], add_batch=True)
+    a, r = pipe64.full_frame(items)
+    fr, bk = pipe64.cano_normal_maps(a['cano_v'], a['cano_vn'], a['f'])
+    assert fr.shape == (1, 3, 512, 512)
+    ofr, obk = raster.render_cano_mesh(a['cano_v'].cpu().numpy(), a['cano_vn'].cpu().numpy(), a['f'].cpu().numpy(),
+                                       np.asarray(ds.cano_smpl_center, np.float32), 512)
+    assert np.array_equal(fr[0].permute(1, 2, 0).cpu().numpy(), ofr)
+    assert np.array_equal(bk[0].permute(1, 2, 0).cpu().numpy(), obk)
+    cov = (np.linalg.norm(ofr, axis=-1) > 0).mean()
+    assert 0.02 < cov < 0.6                                                        # the body silhouette
+    items2 = dict(items); items2['front_normal'], items2['back_normal'] = fr, bk
+    r2 = pipe64.recon_frame(items2)
+    assert torch.equal(r2['occ_volume'], r['occ_volume']) and torch.equal(r2['f'], r['f'])
+    assert r['cano_v'].shape[0] > 0

@@ -1,0 +1,67 @@
+"""Orthographic normal-map rasteriser: analytic checks of the CPU oracle (CPU) and
+bit-exact agreement of the HIP kernel with it (GPU).  Parity with an OpenGL driver is UNPINNED."""
+import numpy as np
+import pytest
+
+from oracle import mc, raster
+
+
+def _sphere_mesh(n=40, R=0.6):
+    g = np.linspace(-1, 1, n, dtype=np.float32)
+    x, y, z = np.meshgrid(g, g, g, indexing='ij')
+    vol = (R - np.sqrt(x * x + y * y + z * z)).astype(np.float32)
+    h = 2.0 / (n - 1)
+    v, f = mc.marching_cubes(vol, 0.0, [h, h, h])
+    v = v - 1.0
+    return v.astype(np.float32), f[:, [2, 1, 0]].copy(), (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+
+def test_oracle_on_sphere():
+    v, f, nrm = _sphere_mesh()
+    fr, bk = raster.render_cano_mesh(v, nrm, f, np.zeros(3, np.float32), 256)
+    m = np.linalg.norm(fr, axis=-1) > 0
+    assert abs(m.sum() / (np.pi * (0.6 * 128) ** 2) - 1) < 0.01                       # silhouette area
+    rr, cc = np.nonzero(m)
+    xs, ys = (cc + 0.5) / 128 - 1, 1 - (rr + 0.5) / 128                             # row 0 is y = +1
+    inner = np.sqrt(xs * xs + ys * ys) < 0.5
+    exp = np.stack([xs, ys, np.sqrt(np.maximum(0.36 - xs * xs - ys * ys, 0))], -1) / 0.6
+    assert np.abs(fr[m] - exp)[inner].max() < 0.01                                    # front map = outward normal of the near side
+    mb = np.linalg.norm(bk, axis=-1) > 0
+    assert np.array_equal(m, mb)                                                      # maps are pixel-aligned (back is mirrored back)
+    assert np.all(fr[m][:, 2] > 0) and np.all(bk[mb][:, 2] < 0)                       # back map shows the far side, normals not rotated
+    assert np.abs(bk[mb][:, :2] - fr[m][:, :2])[inner].max() < 0.02
+    # translation by -center
+    fr2, _ = raster.render_cano_mesh(v + np.float32([0.1, -0.2, 0.3]), nrm, f, np.float32([0.1, -0.2, 0.3]), 256)
+    assert np.abs(fr2 - fr).max() < 1e-5
+
+
+def test_oracle_depth_and_culling():
+    # two parallel quads facing +z at z = 0 and z = 0.5: the front map must show the nearer (z = 0.5) one
+    q = np.float32([[-0.5, -0.5, 0], [0.5, -0.5, 0], [0.5, 0.5, 0], [-0.5, 0.5, 0]])
+    v = np.concatenate([q, q + np.float32([0, 0, 0.5])])
+    f = np.int32([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7]])                       # CCW seen from +z
+    a = np.concatenate([np.tile(np.float32([[1, 0, 0]]), (4, 1)), np.tile(np.float32([[0, 1, 0]]), (4, 1))])
+    fr, bk = raster.render_cano_mesh(v, a, f, np.zeros(3, np.float32), 64)
+    assert np.allclose(fr[32, 32], [0, 1, 0]) and np.allclose(bk[32, 32], 0)          # back view culls +z-facing faces
+    fr, bk = raster.render_cano_mesh(v, a, f[:, [2, 1, 0]].copy(), np.zeros(3, np.float32), 64)
+    assert np.allclose(fr[32, 32], 0) and np.allclose(bk[32, 32], [1, 0, 0])          # flipped: visible from behind, nearest there is z = 0
+    assert np.count_nonzero(np.linalg.norm(bk, axis=-1)) == 32 * 32                   # exact coverage of a pixel-aligned square (top-left rule)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('size', [64, 512])
+def test_hip_rasteriser_matches_oracle(size):
+    import torch
+    from avatarcap_amd.utils.visualize_util import render_cano_mesh_device
+    v, f, nrm = _sphere_mesh(48)
+    rs = np.random.RandomState(0)
+    v2 = np.concatenate([v, (0.4 * v + np.float32([0.3, 0.2, 0.4]))]).astype(np.float32)          # a second blob partly in front
+    f2 = np.concatenate([f, f + v.shape[0]]).astype(np.int32)
+    a2 = np.concatenate([nrm, rs.randn(*nrm.shape).astype(np.float32)])
+    c = np.float32([0.05, -0.03, 0.1])
+    ofr, obk = raster.render_cano_mesh(v2, a2, f2, c, size)
+    fr, bk = render_cano_mesh_device(torch.from_numpy(v2).cuda(), torch.from_numpy(a2).cuda(), torch.from_numpy(f2).cuda(), c, size)
+    assert np.array_equal(fr.cpu().numpy(), ofr)
+    assert np.array_equal(bk.cpu().numpy(), obk)
+    e, _ = render_cano_mesh_device(torch.zeros(3, 3).cuda(), torch.zeros(3, 3).cuda(), torch.zeros((0, 3), dtype=torch.int32).cuda(), c, 32)
+    assert float(e.abs().max()) == 0.0
