@@ -64,6 +64,7 @@ struct avc_ctx {
     void *mc_scratch = nullptr; size_t mc_scratch_bytes = 0;
     uint32_t *mc_tables_dev = nullptr;
     void *raster_scratch = nullptr; size_t raster_scratch_bytes = 0;
+    void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
     avc::Timing timing;
 };
 
@@ -86,7 +87,7 @@ int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float
 int render_cano_maps(avc_ctx *ctx, const float *verts, const float *attrs, const int32_t *faces, int64_t nf, const float center[3],
                      int size, float *front, float *back, hipStream_t s);
 // knn_lbs.hip
-int knn(const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, hipStream_t s);
-int calculate_lbs(const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s);
+int knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, hipStream_t s);
+int calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s);
 int skinning(const float *pts, const float *nrm, int64_t n, const float *lbs, const float *jm, float *po, float *no, float *mo, hipStream_t s);
 }  // namespace avc

@@ -43,6 +43,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->mc_scratch) hipFree(ctx->mc_scratch);
     if (ctx->mc_tables_dev) hipFree(ctx->mc_tables_dev);
     if (ctx->raster_scratch) hipFree(ctx->raster_scratch);
+    if (ctx->knn_scratch) hipFree(ctx->knn_scratch);
     for (int w = 0; w < 2; ++w)
         for (auto &pr : ctx->timing.pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     delete ctx;
@@ -195,7 +196,7 @@ int avc_knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t 
     AVC_REQUIRE(ctx && nq >= 0 && nr > 0 && (nq == 0 || (q && ref)), AVC_ERR_ARG, "avc_knn: NULL argument");
     AVC_REQUIRE(K >= 1 && K <= 8 && K <= nr, AVC_ERR_ARG, "avc_knn: K must be in [1, min(8, nr)], got %d", K);
     AVC_HIP(hipSetDevice(ctx->device));
-    return knn(q, nq, ref, nr, K, d2, idx, (hipStream_t)stream);
+    return knn(ctx, q, nq, ref, nr, K, d2, idx, (hipStream_t)stream);
 }
 
 int avc_calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, avc_stream stream)
@@ -203,7 +204,7 @@ int avc_calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *ca
     AVC_REQUIRE(ctx && n >= 0 && (n == 0 || (pts && lbs)), AVC_ERR_ARG, "avc_calculate_lbs: NULL argument");
     AVC_REQUIRE(cano_v && skin_w && nv >= 4, AVC_ERR_STATE, "Canonical smpl vertices are invalid!");   // smpl_util.py:31
     AVC_HIP(hipSetDevice(ctx->device));
-    return calculate_lbs(pts, n, cano_v, skin_w, nv, lbs, (hipStream_t)stream);
+    return calculate_lbs(ctx, pts, n, cano_v, skin_w, nv, lbs, (hipStream_t)stream);
 }
 
 int avc_skinning(avc_ctx *ctx, const float *pts, const float *nrm, int64_t n, const float *lbs, const float *jm,

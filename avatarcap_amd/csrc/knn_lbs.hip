@@ -1,13 +1,22 @@
 // SMPL utilities on the device (reference utils/smpl_util.py):
 //   knn            : pytorch3d.ops.knn_points as the reference uses it (smpl_util.py:33,
-//                    avatarcap_dataset.py:114, arch_avatar.py:190,208) -- brute force, the 6890
-//                    reference points are staged through LDS in tiles and every thread keeps its
-//                    query's K best in registers (sorted insertion, ties -> lower index).
+//                    avatarcap_dataset.py:114, arch_avatar.py:190,208).  Exact K nearest, squared L2
+//                    ascending, ties -> lower index.  The reference points are binned into a uniform grid
+//                    (<= 32^3 cells, rebuilt on the device per call: one workgroup, tens of us for the 6890
+//                    SMPL vertices).  A WAVE searches together: it takes the cell bounding box of its 64
+//                    queries and scans the cells of that box, then ring after ring around it, until every
+//                    lane's K-th best is closer than the nearest unscanned cell face.  All control flow and
+//                    all candidate addresses are wave-uniform, so candidates arrive through scalar loads and
+//                    each costs ~9 VALU ops per lane, as in a brute-force scan -- but mesh vertices / grid
+//                    points that sit next to each other only ever look at the few hundred candidates around
+//                    them instead of all of them.  Small or huge reference sets use the brute-force scan
+//                    (reference points staged through LDS in tiles).
 //   calculate_lbs  : KNN-4 + Gaussian weights + gather/blend of the 24-wide skin weights (:24-39), fused
 //   skinning       : per-point blend of the 24 joint 4x4s and its application to points / normals (:58-81)
 // All HBM/VALU-bound elementwise work; queries are read once, coalesced.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "avcap_internal.h"
 
@@ -68,29 +77,262 @@ __device__ __forceinline__ void knn_scan(const float *__restrict__ ref, int nr, 
     }
 }
 
+
+// ---- uniform grid over the reference points ----------------------------------------------------
+constexpr int GRID_AXIS = 32;                   // cells per axis (upper bound)
+constexpr int GRID_CELLS = GRID_AXIS * GRID_AXIS * GRID_AXIS;
+constexpr int GRID_MIN_REFS = 512, GRID_MAX_REFS = 1 << 18;   // outside: brute force
+struct GridHdr { float ox, oy, oz, h, inv_h, eps; int nx, ny, nz, ncell; };
+
+__device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int n)
+{
+    const int c = (int)floorf((v - o) * inv_h);
+    return min(max(c, 0), n - 1);
+}
+
+__device__ __forceinline__ float wave_minf(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_maxf(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int wave_mini(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int wave_maxi(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return __builtin_amdgcn_readfirstlane(v); }
+
+// One workgroup: bounding box -> cell size -> histogram -> exclusive scan -> scatter of {x,y,z,index} by cell
+// (z fastest, so a run of cells along z is one contiguous candidate range).
+__global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restrict__ ref, int nr, GridHdr *hdr, int *start, int *cursor,
+                                                          float4 *sorted)
+{
+    __shared__ float red[6][16];
+    __shared__ int part[1024];
+    __shared__ GridHdr H;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = tid; i < nr; i += 1024)
+        for (int a = 0; a < 3; ++a) { const float v = ref[(size_t)i * 3 + a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+    for (int a = 0; a < 3; ++a) {
+        const float lo = wave_minf(mn[a]), hi = wave_maxf(mx[a]);
+        if (lane == 0) { red[a][wave] = lo; red[3 + a][wave] = hi; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = red[a][0]; hi[a] = red[3 + a][0];
+            for (int w = 1; w < 16; ++w) { lo[a] = fminf(lo[a], red[a][w]); hi[a] = fmaxf(hi[a], red[3 + a][w]); }
+        }
+        const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+        float h = ext / (float)GRID_AXIS;
+        if (!(h > 0.f) || !(h < __builtin_inff())) h = 1.f;        // all points identical / non-finite input: one cell per axis
+        H.ox = lo[0]; H.oy = lo[1]; H.oz = lo[2]; H.h = h; H.inv_h = 1.f / h;
+        const float mag = fmaxf(fmaxf(fmaxf(fabsf(lo[0]), fabsf(hi[0])), fmaxf(fabsf(lo[1]), fabsf(hi[1]))), fmaxf(fabsf(lo[2]), fabsf(hi[2])));
+        H.eps = 8e-6f * (mag + ext) + 1e-30f;                       // rounding slop of the cell assignment (see knn_grid_scan)
+        H.nx = min(GRID_AXIS, (int)floorf((hi[0] - lo[0]) * H.inv_h) + 1);
+        H.ny = min(GRID_AXIS, (int)floorf((hi[1] - lo[1]) * H.inv_h) + 1);
+        H.nz = min(GRID_AXIS, (int)floorf((hi[2] - lo[2]) * H.inv_h) + 1);
+        if (!(H.nx >= 1)) H.nx = 1; if (!(H.ny >= 1)) H.ny = 1; if (!(H.nz >= 1)) H.nz = 1;
+        H.ncell = H.nx * H.ny * H.nz;
+        *hdr = H;
+    }
+    __syncthreads();
+    const int ncell = H.ncell;
+    for (int c = tid; c <= ncell; c += 1024) start[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < nr; i += 1024) {
+        const int cx = cell_coord(ref[(size_t)i * 3], H.ox, H.inv_h, H.nx), cy = cell_coord(ref[(size_t)i * 3 + 1], H.oy, H.inv_h, H.ny),
+                  cz = cell_coord(ref[(size_t)i * 3 + 2], H.oz, H.inv_h, H.nz);
+        atomicAdd(&start[(cx * H.ny + cy) * H.nz + cz + 1], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the counts held in start[1..ncell]: thread t owns the run [t*per, (t+1)*per)
+    const int per = (ncell + 1023) / 1024;
+    int sum = 0;
+    for (int c = tid * per; c < min((tid + 1) * per, ncell); ++c) sum += start[c + 1];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int c = tid * per; c < min((tid + 1) * per, ncell); ++c) { const int n = start[c + 1]; cursor[c] = run; run += n; start[c + 1] = run; }
+    __syncthreads();
+    for (int i = tid; i < nr; i += 1024) {
+        const float x = ref[(size_t)i * 3], y = ref[(size_t)i * 3 + 1], z = ref[(size_t)i * 3 + 2];
+        const int cx = cell_coord(x, H.ox, H.inv_h, H.nx), cy = cell_coord(y, H.oy, H.inv_h, H.ny), cz = cell_coord(z, H.oz, H.inv_h, H.nz);
+        const int pos = atomicAdd(&cursor[(cx * H.ny + cy) * H.nz + cz], 1);
+        sorted[pos] = make_float4(x, y, z, __int_as_float(i));
+    }
+    if (tid < 8) sorted[nr + tid] = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));   // read, masked, by the last trips
+}
+
+// insertion under the total order (distance, index): candidates arrive in cell order, not index order
 template <int K>
-__global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ q, int64_t nq, const float *__restrict__ ref, int nr,
+__device__ __forceinline__ void knn_insert_lex(float d, int id, float (&bd)[K], int (&bi)[K])
+{
+    if (d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1])) {
+        bd[K - 1] = d; bi[K - 1] = id;
+#pragma unroll
+        for (int k = K - 1; k > 0; --k) {
+            if (bd[k] < bd[k - 1] || (bd[k] == bd[k - 1] && bi[k] < bi[k - 1])) {
+                const float td = bd[k]; bd[k] = bd[k - 1]; bd[k - 1] = td;
+                const int ti = bi[k]; bi[k] = bi[k - 1]; bi[k - 1] = ti;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float cand_d2(const float4 r, float qx, float qy, float qz)
+{
+    // (dx*dx + dy*dy) + dz*dz with separately rounded operations (file built with -ffp-contract=off)
+    const float dx = qx - r.x, dy = qy - r.y, dz = qz - r.z;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+template <int K>
+__device__ __forceinline__ void scan_range(const float4 *__restrict__ sorted, int s, int e, float qx, float qy, float qz,
+                                           float (&bd)[K], int (&bi)[K])
+{
+    // s, e, j are wave-uniform: the candidates come through scalar loads, 4 a trip, the next trip's load in
+    // flight while this trip's candidates are tested (the array is padded by 8 entries: the loads may run
+    // past `e`; what they bring from there is masked out)
+    if (s >= e) return;
+    float4 nxt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) nxt[u] = sorted[s + u];
+    for (int j = s; j < e; j += 4) {
+        float4 c[4]; float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = nxt[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nxt[u] = sorted[j + 4 + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = cand_d2(c[u], qx, qy, qz);
+        if (j + 4 > e) {
+#pragma unroll
+            for (int u = 1; u < 4; ++u) if (j + u >= e) { d[u] = __builtin_inff(); c[u].w = __int_as_float(0x7fffffff); }   // never inserted
+        }
+        const float m = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+        if (m <= bd[K - 1]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) knn_insert_lex<K>(d[u], __float_as_int(c[u].w), bd, bi);
+        }
+    }
+}
+
+struct GridDims { int nx, ny, nz; };
+
+// all reference points in the cell box [x0,x1] x [y0,y1] x [z0,z1]; cells are stored z fastest, then y, then x,
+// so full-depth / full-height boxes collapse into long contiguous runs
+template <int K>
+__device__ __forceinline__ void scan_box(const int *__restrict__ start, const float4 *__restrict__ sorted, GridDims g, int x0, int x1, int y0, int y1,
+                                         int z0, int z1, float qx, float qy, float qz, float (&bd)[K], int (&bi)[K])
+{
+    if (x0 > x1 || y0 > y1 || z0 > z1) return;
+    auto cell = [&](int x, int y, int z) { return (x * g.ny + y) * g.nz + z; };
+    auto run = [&](int ca, int cb) {
+        scan_range<K>(sorted, __builtin_amdgcn_readfirstlane(start[ca]), __builtin_amdgcn_readfirstlane(start[cb + 1]), qx, qy, qz, bd, bi);
+    };
+    const bool zfull = z0 == 0 && z1 == g.nz - 1, yfull = y0 == 0 && y1 == g.ny - 1;
+    if (zfull && yfull) { run(cell(x0, 0, 0), cell(x1, g.ny - 1, g.nz - 1)); return; }
+    for (int x = x0; x <= x1; ++x) {
+        if (zfull) { run(cell(x, y0, 0), cell(x, y1, g.nz - 1)); continue; }
+        for (int y = y0; y <= y1; ++y) run(cell(x, y, z0), cell(x, y, z1));
+    }
+}
+
+// Exact KNN of one query per lane, searched by the whole wave (see the header comment).  Correctness of the
+// stopping rule: after ring r every cell of the box [lo-r, hi+r] (clipped to the grid) has been scanned; a
+// reference point outside it lies beyond one of the box's faces that is not a grid boundary, hence at least
+// the lane's distance to the nearest such face away (less `eps` for the rounding of the cell assignment).
+template <int K>
+__device__ __forceinline__ void knn_grid_scan(const GridHdr *__restrict__ hdr, const int *__restrict__ start, const float4 *__restrict__ sorted,
+                                              float qx, float qy, float qz, float (&bd)[K], int (&bi)[K])
+{
+    const float ox = hdr->ox, oy = hdr->oy, oz = hdr->oz, h = hdr->h, inv_h = hdr->inv_h, eps = hdr->eps;
+    const int nx = hdr->nx, ny = hdr->ny, nz = hdr->nz;
+    const GridDims g{nx, ny, nz};
+#pragma unroll
+    for (int k = 0; k < K; ++k) { bd[k] = __builtin_inff(); bi[k] = 0x7fffffff; }
+    const int cx = cell_coord(qx, ox, inv_h, nx), cy = cell_coord(qy, oy, inv_h, ny), cz = cell_coord(qz, oz, inv_h, nz);
+    const int lx = wave_mini(cx), hx = wave_maxi(cx), ly = wave_mini(cy), hy = wave_maxi(cy), lz = wave_mini(cz), hz = wave_maxi(cz);
+    scan_box<K>(start, sorted, g, lx, hx, ly, hy, lz, hz, qx, qy, qz, bd, bi);
+    for (int r = 0;; ++r) {
+        const int X0 = max(lx - r, 0), X1 = min(hx + r, nx - 1), Y0 = max(ly - r, 0), Y1 = min(hy + r, ny - 1),
+                  Z0 = max(lz - r, 0), Z1 = min(hz + r, nz - 1);
+        if (r > 0) {
+            // the shell added by ring r, as six disjoint slabs: two x faces (full y, z extent), two y faces
+            // (x without the new x faces), two z faces (x and y without the new faces)
+            const int xi0 = max(lx - r + 1, 0), xi1 = min(hx + r - 1, nx - 1), yi0 = max(ly - r + 1, 0), yi1 = min(hy + r - 1, ny - 1);
+            if (lx - r >= 0) scan_box<K>(start, sorted, g, lx - r, lx - r, Y0, Y1, Z0, Z1, qx, qy, qz, bd, bi);
+            if (hx + r <= nx - 1) scan_box<K>(start, sorted, g, hx + r, hx + r, Y0, Y1, Z0, Z1, qx, qy, qz, bd, bi);
+            if (ly - r >= 0) scan_box<K>(start, sorted, g, xi0, xi1, ly - r, ly - r, Z0, Z1, qx, qy, qz, bd, bi);
+            if (hy + r <= ny - 1) scan_box<K>(start, sorted, g, xi0, xi1, hy + r, hy + r, Z0, Z1, qx, qy, qz, bd, bi);
+            if (lz - r >= 0) scan_box<K>(start, sorted, g, xi0, xi1, yi0, yi1, lz - r, lz - r, qx, qy, qz, bd, bi);
+            if (hz + r <= nz - 1) scan_box<K>(start, sorted, g, xi0, xi1, yi0, yi1, hz + r, hz + r, qx, qy, qz, bd, bi);
+        }
+        if (X0 == 0 && X1 == nx - 1 && Y0 == 0 && Y1 == ny - 1 && Z0 == 0 && Z1 == nz - 1) break;          // everything scanned
+        float b = __builtin_inff();
+        if (X0 > 0) b = fminf(b, qx - (ox + (float)X0 * h));
+        if (X1 < nx - 1) b = fminf(b, (ox + (float)(X1 + 1) * h) - qx);
+        if (Y0 > 0) b = fminf(b, qy - (oy + (float)Y0 * h));
+        if (Y1 < ny - 1) b = fminf(b, (oy + (float)(Y1 + 1) * h) - qy);
+        if (Z0 > 0) b = fminf(b, qz - (oz + (float)Z0 * h));
+        if (Z1 < nz - 1) b = fminf(b, (oz + (float)(Z1 + 1) * h) - qz);
+        b = fmaxf(b - eps, 0.f);
+        if (__all(bd[K - 1] < b * b)) break;
+    }
+}
+
+struct GridView { const GridHdr *hdr; const int *start; const float4 *sorted; uint8_t *flags; int scatter_div; };   // hdr == nullptr: brute force
+
+// Two launches share the work of a call.  The grid launch (GRID = true) serves every workgroup whose waves
+// are spatially coherent; a workgroup holding a wave whose queries are scattered over more than a quarter of
+// the grid would end up scanning most cells through the (slower) scalar path, so it only raises its flag and
+// leaves.  The exhaustive launch (GRID = false) then serves exactly the flagged workgroups (all of them when
+// there is no grid: flags == nullptr).  Returns false when this launch has nothing to do for the workgroup.
+template <int K, bool GRID>
+__device__ __forceinline__ bool knn_any(const float *__restrict__ ref, int nr, const GridView &g, float qx, float qy, float qz,
+                                        float (&bd)[K], int (&bi)[K])
+{
+    if constexpr (GRID) {
+        const GridHdr *hdr = g.hdr;
+        const int cx = cell_coord(qx, hdr->ox, hdr->inv_h, hdr->nx), cy = cell_coord(qy, hdr->oy, hdr->inv_h, hdr->ny),
+                  cz = cell_coord(qz, hdr->oz, hdr->inv_h, hdr->nz);
+        const int box = (wave_maxi(cx) - wave_mini(cx) + 1) * (wave_maxi(cy) - wave_mini(cy) + 1) * (wave_maxi(cz) - wave_mini(cz) + 1);
+        const bool scattered = __syncthreads_or(g.scatter_div * box > hdr->ncell);
+        if (threadIdx.x == 0) g.flags[blockIdx.x] = scattered;
+        if (scattered) return false;
+        knn_grid_scan<K>(hdr, g.start, g.sorted, qx, qy, qz, bd, bi);
+    } else {
+        __shared__ float4 lds[REF_TILE];
+        if (g.flags && !g.flags[blockIdx.x]) return false;
+        knn_scan<K>(ref, nr, qx, qy, qz, bd, bi, lds);
+    }
+    return true;
+}
+
+template <int K, bool GRID>
+__global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ q, int64_t nq, const float *__restrict__ ref, int nr, GridView g,
                                                   float *__restrict__ d2, int64_t *__restrict__ idx)
 {
-    __shared__ float4 lds[REF_TILE];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ii = i < nq ? i : nq - 1;
     float bd[K]; int bi[K];
-    knn_scan<K>(ref, nr, q[3 * ii], q[3 * ii + 1], q[3 * ii + 2], bd, bi, lds);
+    if (!knn_any<K, GRID>(ref, nr, g, q[3 * ii], q[3 * ii + 1], q[3 * ii + 2], bd, bi)) return;
     if (i < nq) {
 #pragma unroll
         for (int k = 0; k < K; ++k) { if (d2) d2[i * K + k] = bd[k]; if (idx) idx[i * K + k] = bi[k]; }
     }
 }
 
+template <bool GRID>
 __global__ __launch_bounds__(256) void lbs_kernel(const float *__restrict__ pts, int64_t n, const float *__restrict__ cano_v,
-                                                  const float *__restrict__ skin_w, int nv, float *__restrict__ lbs)
+                                                  const float *__restrict__ skin_w, int nv, GridView g, float *__restrict__ lbs)
 {
-    __shared__ float4 lds[REF_TILE];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ii = i < n ? i : n - 1;
     float bd[4]; int bi[4];
-    knn_scan<4>(cano_v, nv, pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2], bd, bi, lds);
+    if (!knn_any<4, GRID>(cano_v, nv, g, pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2], bd, bi)) return;
     if (i >= n) return;
     // weights = exp(-dists / (2 r^2)), r = 0.05; weights /= sum + 1e-16     (smpl_util.py:34-36)
     const float denom = (float)(2 * 0.05 * 0.05);
@@ -160,12 +402,39 @@ __global__ __launch_bounds__(256) void skinning_kernel(const float *__restrict__
 
 }  // namespace
 
-int knn(const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, hipStream_t s)
+// Builds the grid over `ref` in the context's scratch (stream-ordered; no host synchronisation).
+static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, GridView &g, hipStream_t s)
+{
+    g = GridView{nullptr, nullptr, nullptr, nullptr, 0};
+    if (nr < GRID_MIN_REFS || nr > GRID_MAX_REFS || getenv("AVC_KNN_BRUTE")) return AVC_OK;
+    const size_t bytes = 256 + 2 * sizeof(int) * (GRID_CELLS + 64) + sizeof(float4) * ((size_t)nr + 8) + (size_t)((nq + 255) / 256);
+    if (ctx->knn_scratch_bytes < bytes) {
+        if (ctx->knn_scratch) AVC_HIP(hipFree(ctx->knn_scratch));
+        ctx->knn_scratch = nullptr; ctx->knn_scratch_bytes = 0;
+        AVC_HIP(hipMalloc(&ctx->knn_scratch, bytes));
+        ctx->knn_scratch_bytes = bytes;
+    }
+    char *base = static_cast<char *>(ctx->knn_scratch);
+    GridHdr *hdr = reinterpret_cast<GridHdr *>(base);
+    int *start = reinterpret_cast<int *>(base + 256);
+    int *cursor = start + GRID_CELLS + 64;
+    float4 *sorted = reinterpret_cast<float4 *>(cursor + GRID_CELLS + 64);
+    hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, s, ref, nr, hdr, start, cursor, sorted);
+    AVC_HIP(hipGetLastError());
+    const char *sd = getenv("AVC_KNN_SCATTER_DIV");     // debugging knob: 0 = never fall back to the exhaustive scan
+    g = GridView{hdr, start, sorted, reinterpret_cast<uint8_t *>(sorted + nr + 8), sd ? atoi(sd) : 4};
+    return AVC_OK;
+}
+
+int knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, hipStream_t s)
 {
     if (nq == 0) return AVC_OK;
+    GridView g;
+    if (int rc = make_grid(ctx, ref, nr, nq, g, s)) return rc;
     const dim3 grid((unsigned)((nq + 255) / 256)), block(256);
     switch (K) {
-#define CASE(k) case k: hipLaunchKernelGGL(knn_kernel<k>, grid, block, 0, s, q, nq, ref, nr, d2, idx); break;
+#define CASE(k) case k: if (g.hdr) hipLaunchKernelGGL((knn_kernel<k, true>), grid, block, 0, s, q, nq, ref, nr, g, d2, idx); \
+                       hipLaunchKernelGGL((knn_kernel<k, false>), grid, block, 0, s, q, nq, ref, nr, g, d2, idx); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
         default: set_error("avc_knn: unsupported K %d", K); return AVC_ERR_ARG;
@@ -174,10 +443,14 @@ int knn(const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *
     return AVC_OK;
 }
 
-int calculate_lbs(const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s)
+int calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s)
 {
     if (n == 0) return AVC_OK;
-    hipLaunchKernelGGL(lbs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pts, n, cano_v, skin_w, nv, lbs);
+    GridView g;
+    if (int rc = make_grid(ctx, cano_v, nv, n, g, s)) return rc;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (g.hdr) hipLaunchKernelGGL(lbs_kernel<true>, grid, block, 0, s, pts, n, cano_v, skin_w, nv, g, lbs);
+    hipLaunchKernelGGL(lbs_kernel<false>, grid, block, 0, s, pts, n, cano_v, skin_w, nv, g, lbs);
     AVC_HIP(hipGetLastError());
     return AVC_OK;
 }

@@ -1,0 +1,94 @@
+"""BASELINE configs[1] at its full size -- one dense 256^3 frame -- checked through properties that do not
+need a full-size CPU run: sampled oracle parity, independence of the per-point result from its position in the
+batch, vertex count = number of sign-changing grid edges, a closed surface away from the volume border,
+unit normals, exact KNN (grid search vs exhaustive scan) and partition-of-unity skin weights."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from avatarcap_amd import config
+from common import geotex_sd, maxabs
+
+pytestmark = pytest.mark.gpu
+RES = [256, 256, 256]
+
+
+@pytest.fixture(scope='module')
+def frame():
+    from avatarcap_amd.dataset import SyntheticTestDataset, to_cuda
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar
+    from avatarcap_amd.pipeline import FramePipeline
+    config.cfg = config.default_cfg()
+    config.cfg['testing']['vol_res'] = RES
+    config.device = torch.device('cuda')
+    ds = SyntheticTestDataset(RES, valid='dense', n_frames=1)
+    net = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume()).to('cuda').eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in geotex_sd().items()})
+    pipe = FramePipeline(net, ds)
+    items = to_cuda(ds[0], add_batch=True)
+    return pipe, ds, items, pipe.avatar_frame(items)
+
+
+def test_sampled_occupancy_matches_oracle_and_is_batch_independent(frame):
+    from oracle import avatarcap_oracle as orc
+    pipe, ds, items, out = frame
+    vol = out['occ_volume']
+    assert vol.numel() == 256 ** 3 and bool(torch.isfinite(vol).all())
+    rs = np.random.RandomState(11)
+    sel = np.sort(rs.choice(vol.numel(), 1500, replace=False))
+    pts = ds.infer_pts[torch.from_numpy(sel).cuda()].cpu().numpy()
+    fmap = pipe.network.warping_field.pose_feat_map[0].cpu().numpy()
+    ref = orc.occupancy_query(pts, fmap, ds.cano_smpl_center, geotex_sd())['cano_pts_ov'][:, 0]
+    assert maxabs(vol.cpu().numpy()[sel], ref) < 1e-4                               # BASELINE.json: occupancy within 1e-4
+    # the value of a point does not depend on which other points share its launch, tile or wave
+    perm = torch.from_numpy(rs.permutation(vol.numel())[:200_003]).cuda()
+    sub = dict(items); sub['cano_pts'] = ds.infer_pts[perm][None].contiguous()
+    again = pipe.occ_net.query(sub)['cano_pts_ov'][0, :, 0]
+    assert torch.equal(again, vol[perm])
+
+
+def test_mesh_topology_at_full_size(frame):
+    pipe, ds, items, out = frame
+    v, f, n, vol = out['cano_v'], out['f'].long(), out['cano_vn'], out['occ_volume'].reshape(RES)
+    inside = vol > config.iso_value
+    crossings = sum(int((inside.narrow(a, 0, 255) != inside.narrow(a, 1, 255)).sum()) for a in range(3))
+    assert v.shape[0] == crossings                                                    # one vertex per sign-changing grid edge
+    assert int(f.min()) == 0 and int(f.max()) == v.shape[0] - 1
+    assert bool((f[:, 0] != f[:, 1]).all() and (f[:, 1] != f[:, 2]).all() and (f[:, 0] != f[:, 2]).all())
+    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    key = torch.minimum(e[:, 0], e[:, 1]) * v.shape[0] + torch.maximum(e[:, 0], e[:, 1])
+    uniq, cnt = torch.unique(key, return_counts=True)
+    assert int(cnt.max()) == 2                                                        # manifold: no edge shared by 3+ faces
+    b0, b1 = torch.from_numpy(ds.cano_bounds[0]).cuda(), torch.from_numpy(ds.cano_bounds[1]).cuda()
+    voxel = (b1 - b0) / 256
+    border = ((v - b0 < 1.01 * voxel) | (b1 - v < 1.01 * voxel)).any(1)
+    open_e = uniq[cnt == 1]
+    assert bool(border[open_e // v.shape[0]].all() and border[open_e % v.shape[0]].all())   # open edges only on the volume border
+    # opposite orientation across every shared edge: directed edges are unique
+    dkey = e[:, 0] * v.shape[0] + e[:, 1]
+    assert torch.unique(dkey).numel() == dkey.numel()
+    nn = torch.linalg.norm(n, dim=1)
+    assert float((nn - 1).abs().max()) < 1e-5
+
+
+def test_lbs_at_full_vertex_count(frame, monkeypatch):
+    from avatarcap_amd.utils.smpl_util import smpl_util
+    pipe, ds, items, out = frame
+    v = out['cano_v']
+    lbs = smpl_util.calculate_lbs(v[None])
+    monkeypatch.setenv('AVC_KNN_BRUTE', '1')
+    lbs_b = smpl_util.calculate_lbs(v[None])
+    monkeypatch.delenv('AVC_KNN_BRUTE')
+    assert torch.equal(lbs, lbs_b)                                                    # grid search == exhaustive scan, bit for bit
+    s = lbs[0].sum(1)
+    d2, _ = smpl_util.knn_points(v[None], ds.cano_smpl_v.cuda()[None], K=1)
+    near = d2[0, :, 0] < 0.1                              # exp(-0.1 / 0.005) = 2e-9 >> the 1e-16 of smpl_util.py:36
+    assert int(near.sum()) > 1000
+    assert float((s[near] - 1).abs().max()) < 1e-5      # partition of unity where the Gaussian weights have not underflowed
+    assert float(s.max()) < 1 + 1e-5                      # ... and sum / (sum + 1e-16) in [0, 1] everywhere else
+    assert bool((lbs >= 0).all())
+    eye = torch.eye(4, device='cuda').expand(1, 24, 4, 4).contiguous()
+    same = smpl_util.skinning(v[None], lbs, eye)[0]
+    assert float((same[near] - v[near]).abs().max()) < 2e-6
+    assert torch.equal(out['live_v'], smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'])[0])

@@ -87,6 +87,34 @@ def test_knn_vs_oracle(body, K):
     assert np.array_equal(d2[0].cpu().numpy(), od2)
 
 
+@pytest.mark.parametrize('K', [1, 4, 8])
+def test_knn_grid_equals_brute_force(body, K, monkeypatch):
+    """The wave-cooperative grid search must return exactly what the exhaustive scan returns: scattered
+    queries (large wave bounding boxes), grid lines far from the body, queries outside the reference box,
+    duplicated reference points (ties -> lower index), and a reference set too small for the grid."""
+    from avatarcap_amd.utils.smpl_util import SmplUtil
+    from avatarcap_amd.grid import generate_volume_points_np
+    su = SmplUtil()
+    rs = np.random.RandomState(7 + K)
+    ref = body['cano_smpl_v'].copy()
+    ref[1000:1100] = ref[2000:2100]                                           # exact duplicates
+    ref[3000:3010] = ref[3000]
+    lines = generate_volume_points_np(syn.CANO_BOUNDS, [24, 24, 96])            # z-fastest runs, like the frame's grid
+    q = np.concatenate([rs.uniform(-1.5, 1.5, (5000, 3)), lines, gi.surface_points(31, 4000, body), ref[990:1110], ref[2995:3015],
+                        np.float32([[50, 0, 0], [-3, -3, -3], [0, 0, 0]])]).astype(np.float32)
+    for refs in (ref, ref[:700], ref[:40]):
+        qt, rt = _t(q[None]), _t(refs[None])
+        d_g, i_g = su.knn_points(qt, rt, K=K)
+        monkeypatch.setenv('AVC_KNN_BRUTE', '1')
+        d_b, i_b = su.knn_points(qt, rt, K=K)
+        monkeypatch.delenv('AVC_KNN_BRUTE')
+        assert torch.equal(i_g, i_b) and torch.equal(d_g, d_b)
+        assert bool((d_g[0, :, 1:] >= d_g[0, :, :-1]).all())
+        if K > 1:                                                              # ties resolved towards the lower index
+            tie = d_g[0, :, 1:] == d_g[0, :, :-1]
+            assert bool((i_g[0, :, 1:][tie] > i_g[0, :, :-1][tie]).all())
+
+
 def test_lbs_skinning_matches_reference_golden(golden, body):
     from avatarcap_amd.utils.smpl_util import SmplUtil
     su = SmplUtil(body['skin_weights'])
