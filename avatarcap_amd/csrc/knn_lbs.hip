@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <cmath>
 
 #include "avcap_internal.h"
 
@@ -79,9 +81,9 @@ __device__ __forceinline__ void knn_scan(const float *__restrict__ ref, int nr, 
 
 
 // ---- uniform grid over the reference points ----------------------------------------------------
-constexpr int GRID_AXIS = 32;                   // cells per axis (upper bound)
-constexpr int GRID_CELLS = GRID_AXIS * GRID_AXIS * GRID_AXIS;
-constexpr int GRID_MIN_REFS = 512, GRID_MAX_REFS = 1 << 18;   // outside: brute force
+constexpr int GRID_MAX_AXIS = 128;              // cells per axis (upper bound)
+constexpr int GRID_MIN_REFS = 512;               // below: exhaustive scan only
+constexpr int GRID_FALLBACK_REFS = 1 << 16;      // above: no exhaustive-scan fallback for scattered workgroups
 struct GridHdr { float ox, oy, oz, h, inv_h, eps; int nx, ny, nz, ncell; };
 
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int n)
@@ -95,53 +97,61 @@ __device__ __forceinline__ float wave_maxf(float v) { for (int o = 32; o > 0; o 
 __device__ __forceinline__ int wave_mini(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int wave_maxi(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return __builtin_amdgcn_readfirstlane(v); }
 
-// One workgroup: bounding box -> cell size -> histogram -> exclusive scan -> scatter of {x,y,z,index} by cell
-// (z fastest, so a run of cells along z is one contiguous candidate range).
-__global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restrict__ ref, int nr, GridHdr *hdr, int *start, int *cursor,
-                                                          float4 *sorted)
+// ---- grid construction (stream-ordered, no host round trip) ---------------------------------------
+//   bbox (atomics on order-preserving keys) -> header -> histogram -> exclusive scan (one workgroup)
+//   -> scatter of {x, y, z, index} by cell (z fastest, so a run of cells along z is one contiguous range)
+__device__ __forceinline__ unsigned f2key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ __launch_bounds__(256) void grid_bbox_kernel(const float *__restrict__ ref, int nr, unsigned *keys /* [6] min xyz, max xyz */)
 {
-    __shared__ float red[6][16];
-    __shared__ int part[1024];
-    __shared__ GridHdr H;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    for (int i = tid; i < nr; i += 1024)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x)
         for (int a = 0; a < 3; ++a) { const float v = ref[(size_t)i * 3 + a]; mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
     for (int a = 0; a < 3; ++a) {
         const float lo = wave_minf(mn[a]), hi = wave_maxf(mx[a]);
-        if (lane == 0) { red[a][wave] = lo; red[3 + a][wave] = hi; }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&keys[a], f2key(lo)); atomicMax(&keys[3 + a], f2key(hi)); }
     }
-    __syncthreads();
-    if (tid == 0) {
-        float lo[3], hi[3];
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = red[a][0]; hi[a] = red[3 + a][0];
-            for (int w = 1; w < 16; ++w) { lo[a] = fminf(lo[a], red[a][w]); hi[a] = fmaxf(hi[a], red[3 + a][w]); }
-        }
-        const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
-        float h = ext / (float)GRID_AXIS;
-        if (!(h > 0.f) || !(h < __builtin_inff())) h = 1.f;        // all points identical / non-finite input: one cell per axis
-        H.ox = lo[0]; H.oy = lo[1]; H.oz = lo[2]; H.h = h; H.inv_h = 1.f / h;
-        const float mag = fmaxf(fmaxf(fmaxf(fabsf(lo[0]), fabsf(hi[0])), fmaxf(fabsf(lo[1]), fabsf(hi[1]))), fmaxf(fabsf(lo[2]), fabsf(hi[2])));
-        H.eps = 8e-6f * (mag + ext) + 1e-30f;                       // rounding slop of the cell assignment (see knn_grid_scan)
-        H.nx = min(GRID_AXIS, (int)floorf((hi[0] - lo[0]) * H.inv_h) + 1);
-        H.ny = min(GRID_AXIS, (int)floorf((hi[1] - lo[1]) * H.inv_h) + 1);
-        H.nz = min(GRID_AXIS, (int)floorf((hi[2] - lo[2]) * H.inv_h) + 1);
-        if (!(H.nx >= 1)) H.nx = 1; if (!(H.ny >= 1)) H.ny = 1; if (!(H.nz >= 1)) H.nz = 1;
-        H.ncell = H.nx * H.ny * H.nz;
-        *hdr = H;
-    }
-    __syncthreads();
-    const int ncell = H.ncell;
-    for (int c = tid; c <= ncell; c += 1024) start[c] = 0;
-    __syncthreads();
-    for (int i = tid; i < nr; i += 1024) {
-        const int cx = cell_coord(ref[(size_t)i * 3], H.ox, H.inv_h, H.nx), cy = cell_coord(ref[(size_t)i * 3 + 1], H.oy, H.inv_h, H.ny),
-                  cz = cell_coord(ref[(size_t)i * 3 + 2], H.oz, H.inv_h, H.nz);
-        atomicAdd(&start[(cx * H.ny + cy) * H.nz + cz + 1], 1);
-    }
-    __syncthreads();
-    // exclusive scan of the counts held in start[1..ncell]: thread t owns the run [t*per, (t+1)*per)
+}
+
+__global__ void grid_header_kernel(const unsigned *keys, int axis, GridHdr *hdr)
+{
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = key2f(keys[a]); hi[a] = key2f(keys[3 + a]); }
+    GridHdr H;
+    const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+    float h = ext / (float)axis;
+    if (!(h > 0.f) || !(h < __builtin_inff())) h = 1.f;            // all points identical / non-finite input: one cell per axis
+    H.ox = lo[0]; H.oy = lo[1]; H.oz = lo[2]; H.h = h; H.inv_h = 1.f / h;
+    const float mag = fmaxf(fmaxf(fmaxf(fabsf(lo[0]), fabsf(hi[0])), fmaxf(fabsf(lo[1]), fabsf(hi[1]))), fmaxf(fabsf(lo[2]), fabsf(hi[2])));
+    H.eps = 8e-6f * (mag + ext) + 1e-30f;                           // rounding slop of the cell assignment (see knn_grid_scan)
+    H.nx = min(axis, (int)floorf((hi[0] - lo[0]) * H.inv_h) + 1);
+    H.ny = min(axis, (int)floorf((hi[1] - lo[1]) * H.inv_h) + 1);
+    H.nz = min(axis, (int)floorf((hi[2] - lo[2]) * H.inv_h) + 1);
+    if (!(H.nx >= 1)) H.nx = 1;
+    if (!(H.ny >= 1)) H.ny = 1;
+    if (!(H.nz >= 1)) H.nz = 1;
+    H.ncell = H.nx * H.ny * H.nz;
+    *hdr = H;
+}
+
+__device__ __forceinline__ int cell_of(const GridHdr &H, float x, float y, float z)
+{
+    return (cell_coord(x, H.ox, H.inv_h, H.nx) * H.ny + cell_coord(y, H.oy, H.inv_h, H.ny)) * H.nz + cell_coord(z, H.oz, H.inv_h, H.nz);
+}
+
+__global__ __launch_bounds__(256) void grid_count_kernel(const float *__restrict__ ref, int nr, const GridHdr *__restrict__ hdr, int *start)
+{
+    const GridHdr H = *hdr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x)
+        atomicAdd(&start[cell_of(H, ref[(size_t)i * 3], ref[(size_t)i * 3 + 1], ref[(size_t)i * 3 + 2]) + 1], 1);
+}
+
+// start[c + 1] holds the count of cell c on entry; on exit start[c] .. start[c + 1] is cell c's range and cursor[c] = start[c]
+__global__ __launch_bounds__(1024) void grid_scan_kernel(const GridHdr *__restrict__ hdr, int *start, int *cursor)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, ncell = hdr->ncell;
     const int per = (ncell + 1023) / 1024;
     int sum = 0;
     for (int c = tid * per; c < min((tid + 1) * per, ncell); ++c) sum += start[c + 1];
@@ -155,14 +165,18 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float *__restric
     }
     int run = part[tid] - sum;
     for (int c = tid * per; c < min((tid + 1) * per, ncell); ++c) { const int n = start[c + 1]; cursor[c] = run; run += n; start[c + 1] = run; }
-    __syncthreads();
-    for (int i = tid; i < nr; i += 1024) {
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const float *__restrict__ ref, int nr, const GridHdr *__restrict__ hdr, int *cursor,
+                                                           float4 *sorted)
+{
+    const GridHdr H = *hdr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) {
         const float x = ref[(size_t)i * 3], y = ref[(size_t)i * 3 + 1], z = ref[(size_t)i * 3 + 2];
-        const int cx = cell_coord(x, H.ox, H.inv_h, H.nx), cy = cell_coord(y, H.oy, H.inv_h, H.ny), cz = cell_coord(z, H.oz, H.inv_h, H.nz);
-        const int pos = atomicAdd(&cursor[(cx * H.ny + cy) * H.nz + cz], 1);
-        sorted[pos] = make_float4(x, y, z, __int_as_float(i));
+        sorted[atomicAdd(&cursor[cell_of(H, x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(i));
     }
-    if (tid < 8) sorted[nr + tid] = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));   // read, masked, by the last trips
+    if (blockIdx.x == 0 && threadIdx.x < 8)                         // read, masked, by the last trips of scan_range
+        sorted[nr + threadIdx.x] = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
 }
 
 // insertion under the total order (distance, index): candidates arrive in cell order, not index order
@@ -256,19 +270,19 @@ __device__ __forceinline__ void knn_grid_scan(const GridHdr *__restrict__ hdr, c
     const int cx = cell_coord(qx, ox, inv_h, nx), cy = cell_coord(qy, oy, inv_h, ny), cz = cell_coord(qz, oz, inv_h, nz);
     const int lx = wave_mini(cx), hx = wave_maxi(cx), ly = wave_mini(cy), hy = wave_maxi(cy), lz = wave_mini(cz), hz = wave_maxi(cz);
     scan_box<K>(start, sorted, g, lx, hx, ly, hy, lz, hz, qx, qy, qz, bd, bi);
-    for (int r = 0;; ++r) {
+    for (int r = 0, rp = 0;;) {                  // box radius scanned so far (r) and before that (rp), in cells around [l, h]
         const int X0 = max(lx - r, 0), X1 = min(hx + r, nx - 1), Y0 = max(ly - r, 0), Y1 = min(hy + r, ny - 1),
                   Z0 = max(lz - r, 0), Z1 = min(hz + r, nz - 1);
-        if (r > 0) {
-            // the shell added by ring r, as six disjoint slabs: two x faces (full y, z extent), two y faces
-            // (x without the new x faces), two z faces (x and y without the new faces)
-            const int xi0 = max(lx - r + 1, 0), xi1 = min(hx + r - 1, nx - 1), yi0 = max(ly - r + 1, 0), yi1 = min(hy + r - 1, ny - 1);
-            if (lx - r >= 0) scan_box<K>(start, sorted, g, lx - r, lx - r, Y0, Y1, Z0, Z1, qx, qy, qz, bd, bi);
-            if (hx + r <= nx - 1) scan_box<K>(start, sorted, g, hx + r, hx + r, Y0, Y1, Z0, Z1, qx, qy, qz, bd, bi);
-            if (ly - r >= 0) scan_box<K>(start, sorted, g, xi0, xi1, ly - r, ly - r, Z0, Z1, qx, qy, qz, bd, bi);
-            if (hy + r <= ny - 1) scan_box<K>(start, sorted, g, xi0, xi1, hy + r, hy + r, Z0, Z1, qx, qy, qz, bd, bi);
-            if (lz - r >= 0) scan_box<K>(start, sorted, g, xi0, xi1, yi0, yi1, lz - r, lz - r, qx, qy, qz, bd, bi);
-            if (hz + r <= nz - 1) scan_box<K>(start, sorted, g, xi0, xi1, yi0, yi1, hz + r, hz + r, qx, qy, qz, bd, bi);
+        if (r > rp) {
+            // the shell between radius rp and r as six disjoint slabs: two x slabs (whole y, z extent of the new box),
+            // two y slabs (x extent of the old box), two z slabs (x and y extent of the old box)
+            const int xi0 = max(lx - rp, 0), xi1 = min(hx + rp, nx - 1), yi0 = max(ly - rp, 0), yi1 = min(hy + rp, ny - 1);
+            scan_box<K>(start, sorted, g, X0, min(lx - rp - 1, nx - 1), Y0, Y1, Z0, Z1, qx, qy, qz, bd, bi);
+            scan_box<K>(start, sorted, g, max(hx + rp + 1, 0), X1, Y0, Y1, Z0, Z1, qx, qy, qz, bd, bi);
+            scan_box<K>(start, sorted, g, xi0, xi1, Y0, min(ly - rp - 1, ny - 1), Z0, Z1, qx, qy, qz, bd, bi);
+            scan_box<K>(start, sorted, g, xi0, xi1, max(hy + rp + 1, 0), Y1, Z0, Z1, qx, qy, qz, bd, bi);
+            scan_box<K>(start, sorted, g, xi0, xi1, yi0, yi1, Z0, min(lz - rp - 1, nz - 1), qx, qy, qz, bd, bi);
+            scan_box<K>(start, sorted, g, xi0, xi1, yi0, yi1, max(hz + rp + 1, 0), Z1, qx, qy, qz, bd, bi);
         }
         if (X0 == 0 && X1 == nx - 1 && Y0 == 0 && Y1 == ny - 1 && Z0 == 0 && Z1 == nz - 1) break;          // everything scanned
         float b = __builtin_inff();
@@ -279,7 +293,15 @@ __device__ __forceinline__ void knn_grid_scan(const GridHdr *__restrict__ hdr, c
         if (Z0 > 0) b = fminf(b, qz - (oz + (float)Z0 * h));
         if (Z1 < nz - 1) b = fminf(b, (oz + (float)(Z1 + 1) * h) - qz);
         b = fmaxf(b - eps, 0.f);
-        if (__all(bd[K - 1] < b * b)) break;
+        const bool done = bd[K - 1] < b * b;
+        if (__all(done)) break;
+        // next radius: grow by a quarter (at least one cell), but never beyond the radius that settles the worst unsettled
+        // lane even if its K-th best does not improve any more
+        const float need = done ? 0.f : sqrtf(bd[K - 1]) + 2.f * eps;                   // inf while fewer than K candidates seen
+        const float worst = wave_maxf(need);
+        const int cap = worst < 1e30f ? (int)fminf(ceilf(worst * inv_h) + 1.f, 1e6f) : 0x7fffffff;
+        const int rn = __builtin_amdgcn_readfirstlane(max(r + 1, min(cap, r + max(1, r / 4))));
+        rp = r; r = rn;
     }
 }
 
@@ -406,8 +428,11 @@ __global__ __launch_bounds__(256) void skinning_kernel(const float *__restrict__
 static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, GridView &g, hipStream_t s)
 {
     g = GridView{nullptr, nullptr, nullptr, nullptr, 0};
-    if (nr < GRID_MIN_REFS || nr > GRID_MAX_REFS || getenv("AVC_KNN_BRUTE")) return AVC_OK;
-    const size_t bytes = 256 + 2 * sizeof(int) * (GRID_CELLS + 64) + sizeof(float4) * ((size_t)nr + 8) + (size_t)((nq + 255) / 256);
+    if (nr < GRID_MIN_REFS || getenv("AVC_KNN_BRUTE")) return AVC_OK;
+    // cells per axis: about one occupied cell per few reference points for surface-like sets (6890 -> 32, 1e6 -> 128)
+    const int axis = std::min(GRID_MAX_AXIS, std::max(8, (int)(1.7 * cbrt((double)nr))));
+    const size_t ncell = (size_t)axis * axis * axis;
+    const size_t bytes = 256 + 2 * sizeof(int) * (ncell + 64) + sizeof(float4) * ((size_t)nr + 8) + (size_t)((nq + 255) / 256);
     if (ctx->knn_scratch_bytes < bytes) {
         if (ctx->knn_scratch) AVC_HIP(hipFree(ctx->knn_scratch));
         ctx->knn_scratch = nullptr; ctx->knn_scratch_bytes = 0;
@@ -416,13 +441,24 @@ static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, Gri
     }
     char *base = static_cast<char *>(ctx->knn_scratch);
     GridHdr *hdr = reinterpret_cast<GridHdr *>(base);
+    unsigned *keys = reinterpret_cast<unsigned *>(base + 128);
     int *start = reinterpret_cast<int *>(base + 256);
-    int *cursor = start + GRID_CELLS + 64;
-    float4 *sorted = reinterpret_cast<float4 *>(cursor + GRID_CELLS + 64);
-    hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, s, ref, nr, hdr, start, cursor, sorted);
+    int *cursor = start + ncell + 64;
+    float4 *sorted = reinterpret_cast<float4 *>(cursor + ncell + 64);
+    AVC_HIP(hipMemsetAsync(keys, 0xff, 3 * sizeof(unsigned), s));                 // running minima start at the largest key
+    AVC_HIP(hipMemsetAsync(keys + 3, 0x00, 3 * sizeof(unsigned), s));
+    AVC_HIP(hipMemsetAsync(start, 0, sizeof(int) * (ncell + 1), s));
+    const dim3 blocks((unsigned)std::min<int64_t>(1024, (nr + 255) / 256)), threads(256);
+    hipLaunchKernelGGL(grid_bbox_kernel, blocks, threads, 0, s, ref, nr, keys);
+    hipLaunchKernelGGL(grid_header_kernel, dim3(1), dim3(1), 0, s, keys, axis, hdr);
+    hipLaunchKernelGGL(grid_count_kernel, blocks, threads, 0, s, ref, nr, hdr, start);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, hdr, start, cursor);
+    hipLaunchKernelGGL(grid_scatter_kernel, blocks, threads, 0, s, ref, nr, hdr, cursor, sorted);
     AVC_HIP(hipGetLastError());
-    const char *sd = getenv("AVC_KNN_SCATTER_DIV");     // debugging knob: 0 = never fall back to the exhaustive scan
-    g = GridView{hdr, start, sorted, reinterpret_cast<uint8_t *>(sorted + nr + 8), sd ? atoi(sd) : 4};
+    // Workgroups with scattered queries fall back to the exhaustive scan only while that is affordable; beyond it the
+    // grid search (which then degenerates into one pass over the sorted array) is the exhaustive scan.
+    const char *sd = getenv("AVC_KNN_SCATTER_DIV");     // debugging knob: 0 = never fall back
+    g = GridView{hdr, start, sorted, reinterpret_cast<uint8_t *>(sorted + nr + 8), sd ? atoi(sd) : (nr <= GRID_FALLBACK_REFS ? 4 : 0)};
     return AVC_OK;
 }
 

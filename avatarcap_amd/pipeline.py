@@ -90,6 +90,13 @@ class FramePipeline:
         return a, r
 
     @torch.no_grad()
+    def transfer_colours(self, vertices: torch.Tensor, vertices_avatar: torch.Tensor, colour_avatar: torch.Tensor):
+        """Colour of the nearest avatar vertex for every reconstructed vertex (main.py:478-482:
+        knn_points(vertices, vertices_avatar) with K = 1, then knn_gather)."""
+        _, idx = smpl_util.knn_points(vertices[None].contiguous(), vertices_avatar[None].contiguous(), K=1)
+        return colour_avatar[idx[0, :, 0]]
+
+    @torch.no_grad()
     def colour_vertices(self, items: dict, cano_v: torch.Tensor, cano_vn: torch.Tensor, renderer=None):
         """4. vertex colours from the texture template (main.py:464-477): one 64-sample ray per vertex,
         starting at v + n and marching along -n, alpha-composited.  Returns (V,3) in the reference's BGR order."""

@@ -55,19 +55,23 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
         a = pipe.avatar_frame(items)                                              # step 1
         save = {'cano_v': a['cano_v'], 'cano_vn': a['cano_vn'], 'f': a['f'], 'live_v': a.get('live_v'), 'live_vn': a.get('live_vn')}
         if w_recon:
-            nm = torch.from_numpy(syn.smooth_normal_maps(1000 + i, 512)).to(config.device)   # stands in for step 2 (normal fusion)
-            items['front_normal'], items['back_normal'] = nm[None, :3], nm[None, 3:]
+            # step 2 (fusion with image-observed normals) needs a captured image; the avatar's own canonical normal
+            # maps (visualize_util.render_cano_mesh, main.py:369) go to the reconstruction network unchanged
+            items['front_normal'], items['back_normal'] = pipe.cano_normal_maps(a['cano_v'], a['cano_vn'], a['f'])
             r = pipe.recon_frame(items)                                           # step 3
             save.update({'recon_' + k: v for k, v in r.items() if k != 'occ_volume'})
         if w_nerf:                                                                # step 4 (main.py:464-477)
             save['live_vc'] = pipe.colour_vertices(items, a['cano_v'], a['cano_vn'])
+            if w_recon and save['recon_cano_v'].shape[0] > 0 and a['cano_v'].shape[0] > 0:        # main.py:478-482
+                save['recon_live_vc'] = pipe.transfer_colours(save['recon_cano_v'], a['cano_v'], save['live_vc'])
         from avatarcap_amd.utils import obj_io
         if save_avatar_mesh and a.get('live_v') is not None:                          # main.py:491-493
             obj_io.save_mesh_as_ply('%s/%04d_avatar.ply' % (out_dir, items['data_idx']), a['live_v'].cpu().numpy(), a['f'].cpu().numpy(),
                                     a['live_vn'].cpu().numpy(), save['live_vc'].cpu().numpy() if w_nerf else None)
         if w_recon and save_final_mesh and 'recon_live_v' in save:                     # main.py:495-498
             obj_io.save_mesh_as_ply('%s/%04d_recon.ply' % (out_dir, items['data_idx']), save['recon_live_v'].cpu().numpy(),
-                                    save['recon_f'].cpu().numpy(), save['recon_live_vn'].cpu().numpy(), None)
+                                    save['recon_f'].cpu().numpy(), save['recon_live_vn'].cpu().numpy(),
+                                    save['recon_live_vc'].cpu().numpy() if 'recon_live_vc' in save else None)
         np.savez(os.path.join(out_dir, '%04d_mesh.npz' % items['data_idx']),
                  **{k: v.cpu().numpy() for k, v in save.items() if v is not None})
         print('# frame %d: avatar %d verts / %d faces%s' % (i, a['cano_v'].shape[0], a['f'].shape[0],

@@ -115,6 +115,29 @@ def test_knn_grid_equals_brute_force(body, K, monkeypatch):
             assert bool((i_g[0, :, 1:][tie] > i_g[0, :, :-1][tie]).all())
 
 
+@pytest.mark.parametrize('K', [1, 3])
+def test_knn_large_reference_set(body, K, monkeypatch):
+    """main.py:478-481 looks every reconstructed vertex up among ~1e6 avatar vertices: the grid is built by
+    several workgroups and is finer (up to 128 cells per axis); far, near and scattered queries stay exact."""
+    from avatarcap_amd.utils.smpl_util import SmplUtil
+    su = SmplUtil()
+    rs = np.random.RandomState(5)
+    bv = body['cano_smpl_v']
+    ref = (bv[rs.randint(0, bv.shape[0], 400_000)] + rs.normal(0, 0.01, (400_000, 3))).astype(np.float32)
+    ref[5000:5050] = ref[100:150]                                             # duplicates
+    q = np.concatenate([bv[rs.randint(0, bv.shape[0], 30_000)] + rs.normal(0, 0.02, (30_000, 3)),
+                        rs.uniform(-1.2, 1.2, (3000, 3)), ref[90:160], np.float32([[9, 9, 9]])]).astype(np.float32)
+    q[:30_000] = q[:30_000][np.lexsort(np.floor(q[:30_000] * 20).T)]          # spatially coherent, like mesh vertices
+    qt, rt = _t(q[None]), _t(ref[None])
+    d_g, i_g = su.knn_points(qt, rt, K=K)
+    monkeypatch.setenv('AVC_KNN_BRUTE', '1')
+    d_b, i_b = su.knn_points(qt, rt, K=K)
+    monkeypatch.delenv('AVC_KNN_BRUTE')
+    assert torch.equal(i_g, i_b) and torch.equal(d_g, d_b)
+    dd = torch.cdist(qt[0, :2000].double(), rt[0].double()) ** 2                # an independent check of a sample
+    assert float((dd.min(1).values - d_g[0, :2000, 0].double()).abs().max()) < 1e-6
+
+
 def test_lbs_skinning_matches_reference_golden(golden, body):
     from avatarcap_amd.utils.smpl_util import SmplUtil
     su = SmplUtil(body['skin_weights'])

@@ -188,3 +188,16 @@ def test_full_frame_chain(pipe64):
     r2 = pipe64.recon_frame(items2)
     assert torch.equal(r2['occ_volume'], r['occ_volume']) and torch.equal(r2['f'], r['f'])
     assert r['cano_v'].shape[0] > 0
+
+
+def test_colour_transfer_to_recon_vertices(pipe64):
+    """main.py:478-482: nearest avatar vertex's colour for each reconstructed vertex."""
+    from avatarcap_amd.dataset import to_cuda
+    from oracle import avatarcap_oracle as orc
+    items = to_cuda(pipe64.ds[0], add_batch=True)
+    a, r = pipe64.full_frame(items)
+    col = torch.rand((a['cano_v'].shape[0], 3), device='cuda')
+    out = pipe64.transfer_colours(r['cano_v'], a['cano_v'], col)
+    _, idx = orc.knn(r['cano_v'][:500].cpu().numpy(), a['cano_v'].cpu().numpy(), 1)
+    assert torch.equal(out[:500], col[torch.from_numpy(idx[:, 0]).cuda()])
+    assert out.shape == (r['cano_v'].shape[0], 3)
