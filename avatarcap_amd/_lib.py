@@ -38,6 +38,8 @@ _SIGNATURES = {
     'avc_avatar_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_template_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_recon_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
+    'avc_group_norm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                 C.c_int, C.c_void_p, C.c_void_p]),
     'avc_scatter_volume': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_recon_mesh': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_float, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),

@@ -64,6 +64,7 @@ struct avc_ctx {
     void *mc_scratch = nullptr; size_t mc_scratch_bytes = 0;
     uint32_t *mc_tables_dev = nullptr;
     void *raster_scratch = nullptr; size_t raster_scratch_bytes = 0;
+    void *gn_scratch = nullptr; size_t gn_scratch_bytes = 0;       // GroupNorm slice sums
     void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
     avc::Timing timing;
 };
@@ -79,6 +80,8 @@ int launch_avatar(avc_ctx *ctx, const float *pts, int64_t n, const float center[
                   float *occ, float *offset, float *rgba, bool template_only, hipStream_t s);
 int launch_recon(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], float *out, hipStream_t s);
 int launch_nchw_to_hwc(const float *src, float *dst, int C, int H, int W, hipStream_t s);
+int launch_group_norm(avc_ctx *ctx, const float *x, int N, int C, int64_t HW, int G, const float *gamma, const float *beta, float eps,
+                      int relu, float *y, hipStream_t s);
 int launch_scatter(const uint8_t *valid, int64_t N, const float *values, const float *fill, float *vol, hipStream_t s);
 // mesh.hip
 int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float bounds[6], float iso,

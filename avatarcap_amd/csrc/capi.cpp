@@ -44,6 +44,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->mc_tables_dev) hipFree(ctx->mc_tables_dev);
     if (ctx->raster_scratch) hipFree(ctx->raster_scratch);
     if (ctx->knn_scratch) hipFree(ctx->knn_scratch);
+    if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
     for (int w = 0; w < 2; ++w)
         for (auto &pr : ctx->timing.pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     delete ctx;
@@ -162,6 +163,17 @@ int avc_recon_query(avc_ctx *ctx, const float *pts, int64_t n, const float cente
     AVC_REQUIRE(ctx && center && n >= 0 && (n == 0 || (pts && out)), AVC_ERR_ARG, "avc_recon_query: NULL argument or negative n");
     AVC_HIP(hipSetDevice(ctx->device));
     return launch_recon(ctx, pts, n, center, out, (hipStream_t)stream);
+}
+
+int avc_group_norm(avc_ctx *ctx, const float *x, int N, int C, int64_t HW, int G, const float *gamma, const float *beta, float eps,
+                   int relu, float *y, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && x && y, AVC_ERR_ARG, "avc_group_norm: NULL argument");
+    AVC_REQUIRE(N >= 1 && C >= 1 && HW >= 1 && G >= 1 && C % G == 0, AVC_ERR_ARG,
+                "avc_group_norm: need N, C, HW >= 1 and C divisible by G (got N=%d C=%d HW=%lld G=%d)", N, C, (long long)HW, G);
+    AVC_REQUIRE((int64_t)N * C <= 1 << 30, AVC_ERR_ARG, "avc_group_norm: N * C too large");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return launch_group_norm(ctx, x, N, C, HW, G, gamma, beta, eps, relu, y, (hipStream_t)stream);
 }
 
 int avc_scatter_volume(avc_ctx *ctx, const uint8_t *valid, int64_t N, const float *values, const float *fill, float *vol, avc_stream stream)

@@ -12,6 +12,23 @@ def _norm(kind, c):
     return nn.GroupNorm(32, c) if kind == 'group' else nn.BatchNorm2d(c)
 
 
+def norm_relu(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """relu(norm(x)) -- every normalisation of the encoder is followed by one (HGFilters.py:64-66,178,204).
+    On the GPU a GroupNorm goes through the fused HIP op (avc_group_norm): eager PyTorch spends more time in its
+    55 statistics launches per frame than in the convolutions.  Inference only (no autograd through the HIP op)."""
+    if isinstance(m, nn.GroupNorm) and x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad):
+        from .. import _lib
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        N, C = x.shape[0], x.shape[1]
+        _lib.check(_lib.lib().avc_group_norm(_lib.ctx(x.device), x.data_ptr(), N, C, x.numel() // (N * C), m.num_groups,
+                                             m.weight.data_ptr() if m.weight is not None else None,
+                                             m.bias.data_ptr() if m.bias is not None else None, float(m.eps), 1, y.data_ptr(),
+                                             _lib.stream_ptr(x.device)))
+        return y
+    return F.relu(m(x))
+
+
 class ConvBlock(nn.Module):
     """Three pre-activated 3x3 convs (c/2, c/4, c/4) concatenated + residual (HGFilters.py:33-75).
     `bn4` is allocated even when the 1x1 projection is absent -- it is in the checkpoints."""
@@ -28,10 +45,10 @@ class ConvBlock(nn.Module):
             self.downsample = nn.Sequential(self.bn4, nn.ReLU(True), nn.Conv2d(cin, cout, 1, 1, bias=False))
 
     def forward(self, x):
-        o1 = self.conv1(F.relu(self.bn1(x)))
-        o2 = self.conv2(F.relu(self.bn2(o1)))
-        o3 = self.conv3(F.relu(self.bn3(o2)))
-        res = x if self.downsample is None else self.downsample(x)
+        o1 = self.conv1(norm_relu(self.bn1, x))
+        o2 = self.conv2(norm_relu(self.bn2, o1))
+        o3 = self.conv3(norm_relu(self.bn3, o2))
+        res = x if self.downsample is None else self.downsample[2](norm_relu(self.bn4, x))
         return torch.cat([o1, o2, o3], 1) + res
 
 
@@ -77,10 +94,10 @@ class HGFilter(nn.Module):
         self.l0 = nn.Conv2d(256, last_ch, 1)
 
     def forward(self, x):
-        x = F.relu(self.bn1(self.conv1(x)))
+        x = norm_relu(self.bn1, self.conv1(x))
         normx = x = self.conv2(x)                       # 'no_down' branch (HGFilters.py:184-185)
         x = self.conv4(self.conv3(x))
         ll = self.top_m_0(self.m0(x))
-        ll = F.relu(self.bn_end0(self.conv_last0(ll)))
+        ll = norm_relu(self.bn_end0, self.conv_last0(ll))
         out = self.l0(ll)
         return [torch.tanh(out) if self.use_sigmoid else out], normx

@@ -75,6 +75,13 @@ int avc_set_pose_feat_map(avc_ctx *ctx, const float *map_nchw_dev, int C, int H,
 /* img_feat_map = HGFilter(cat(front,back))[-1], (1,C=32,H,W) (network/arch_recon.py:51-52) */
 int avc_set_img_feat_map(avc_ctx *ctx, const float *map_nchw_dev, int C, int H, int W, avc_stream stream);
 
+/* GroupNorm of the image encoder, with the ReLU that follows every one of them fused in
+ * (network/HGFilters.py:46-49,64-66,141,165,178,204; torch.nn.GroupNorm semantics: per (n, group) mean and
+ * biased variance over (C/G, H, W), y = (x - mean) / sqrt(var + eps) * gamma[c] + beta[c]).
+ * x_dev, y_dev (N, C, HW) contiguous float32 (y_dev may equal x_dev); gamma_dev, beta_dev (C) or NULL. */
+int avc_group_norm(avc_ctx *ctx, const float *x_dev, int N, int C, int64_t HW, int G, const float *gamma_dev,
+                   const float *beta_dev, float eps, int relu, float *y_dev, avc_stream stream);
+
 /* ---- queries -------------------------------------------------------------------------------
  * OccupancyNet.query (network/arch_avatar.py:356-381) = WarpingField.query (:113-140) +
  * DoubleTNet.forward (:65-83) on cano_pts + offset, for n points (any n >= 0; the reference's

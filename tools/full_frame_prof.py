@@ -1,0 +1,23 @@
+"""BASELINE configs[2] as one chained frame (avatar -> canonical normal maps -> HGFilter + recon decoder -> mesh -> LBS),
+256^3 band-masked like the reference; run under rocprofv3 --kernel-trace --stats for the per-kernel split."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, '.')
+from avatarcap_amd import config, synthetic as syn
+from avatarcap_amd.dataset import SyntheticTestDataset, to_cuda
+from avatarcap_amd.network.arch_avatar import GeoTexAvatar
+from avatarcap_amd.network.arch_recon import ReconNetwork
+from avatarcap_amd.pipeline import FramePipeline
+dev = torch.device('cuda'); config.device = dev; config.cfg = config.default_cfg()
+net = GeoTexAvatar(base_weight_volume=np.zeros((2, 2, 2, 24), np.float32)).to(dev).eval(); syn.load_synth(net, syn.SEED)
+rn = ReconNetwork().to(dev).eval(); syn.load_synth(rn, syn.SEED)
+config.cfg['testing']['vol_res'] = [256] * 3
+ds = SyntheticTestDataset([256] * 3, valid='band', n_frames=4)
+pipe = FramePipeline(net, ds, rn)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+for i in range(n + 1):
+    if i == 1: torch.cuda.synchronize(); t = time.perf_counter()
+    a, r = pipe.full_frame(to_cuda(ds[i % 4], add_batch=True))
+torch.cuda.synchronize()
+print('full frame (configs[2], %d valid points): %.2f ms/frame, avatar %d verts, recon %d verts' %
+      (ds.infer_pts.shape[0], (time.perf_counter() - t) / n * 1e3, a['cano_v'].shape[0], r['cano_v'].shape[0]))
