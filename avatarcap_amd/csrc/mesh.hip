@@ -274,10 +274,15 @@ __device__ __forceinline__ void vertex_normal(const McArgs &a, const EmitArgs &e
     nrm[0] = -(gx / nn); nrm[1] = -(gy / nn); nrm[2] = -(gz / nn);                // :68
 }
 
+// Owners only describe their vertices (voxel, axis, interpolation parameter) in LDS, in output order; then the
+// whole workgroup shares the position / normal evaluation, one vertex per thread per round: the 64-tap normal
+// stencil is by far the most expensive part, and vertices cluster in few voxels of a tile.
 __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, const unsigned *__restrict__ tile_voff,
                                                        unsigned *__restrict__ first_id, float *__restrict__ verts, float *__restrict__ normals)
 {
     __shared__ unsigned red[4];
+    __shared__ unsigned v_li[3 * TILE];      // voxel of the vertex (tile-local index) | axis << 16
+    __shared__ float v_t[3 * TILE];          // (iso - v0) / (v1 - v0)
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         Voxel q[4];
         unsigned nv = 0;
@@ -287,33 +292,45 @@ __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, con
             if (li < a.N) { q[k] = load_voxel(a, li); nv += q[k].nv; } else { q[k].nv = 0; q[k].cut = 0; }
         }
         unsigned total;
-        unsigned id = tile_voff[tile] + block_exclusive(nv, red, total);
+        const unsigned base = tile_voff[tile];
+        unsigned loc = block_exclusive(nv, red, total);
         if (total == 0) continue;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (q[k].nv == 0) continue;
-            const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
-            first_id[li] = id;
-            const int p[3] = {q[k].x, q[k].y, q[k].z};
+            first_id[(int64_t)tile * TILE + threadIdx.x * 4 + k] = base + loc;
             for (int ax = 0; ax < 3; ++ax) {
                 if (!(q[k].cut & (1u << ax))) continue;
-                const float t = __fdiv_rn(__fsub_rn(0.0f, q[k].v0), __fsub_rn(q[k].v[ax], q[k].v0));   // (iso - v0)/(v1 - v0)
-                float vidx[3], out[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    vidx[c] = __fadd_rn((float)p[c], c == ax ? t : 0.0f);
-                    // vertices = mc * voxel + b0 + 0.5 * voxel   (recon_util.py:64-65)
-                    out[c] = __fadd_rn(__fadd_rn(__fmul_rn(vidx[c], e.vox[c]), e.b0[c]), __fmul_rn(0.5f, e.vox[c]));
-                }
-                verts[3 * (size_t)id + 0] = out[0]; verts[3 * (size_t)id + 1] = out[1]; verts[3 * (size_t)id + 2] = out[2];
-                if (normals) {
-                    float n[3];
-                    vertex_normal(a, e, vidx, n);
-                    normals[3 * (size_t)id + 0] = n[0]; normals[3 * (size_t)id + 1] = n[1]; normals[3 * (size_t)id + 2] = n[2];
-                }
-                ++id;
+                v_li[loc] = (unsigned)(threadIdx.x * 4 + k) | ((unsigned)ax << 16);
+                v_t[loc] = __fdiv_rn(__fsub_rn(0.0f, q[k].v0), __fsub_rn(q[k].v[ax], q[k].v0));   // (iso - v0)/(v1 - v0)
+                ++loc;
             }
         }
+        __syncthreads();
+        for (unsigned j = threadIdx.x; j < total; j += 256) {
+            const unsigned d = v_li[j];
+            const int ax = (int)(d >> 16);
+            const int64_t li = (int64_t)tile * TILE + (d & 0xffffu);
+            const int yz = a.Y * a.Z;
+            const int px = (int)(li / yz), rem = (int)(li - (int64_t)px * yz);
+            const int p[3] = {px, rem / a.Z, rem % a.Z};
+            const float t = v_t[j];
+            float vidx[3], out[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                vidx[c] = __fadd_rn((float)p[c], c == ax ? t : 0.0f);
+                // vertices = mc * voxel + b0 + 0.5 * voxel   (recon_util.py:64-65)
+                out[c] = __fadd_rn(__fadd_rn(__fmul_rn(vidx[c], e.vox[c]), e.b0[c]), __fmul_rn(0.5f, e.vox[c]));
+            }
+            const size_t id = (size_t)base + j;
+            verts[3 * id + 0] = out[0]; verts[3 * id + 1] = out[1]; verts[3 * id + 2] = out[2];
+            if (normals) {
+                float n[3];
+                vertex_normal(a, e, vidx, n);
+                normals[3 * id + 0] = n[0]; normals[3 * id + 1] = n[1]; normals[3 * id + 2] = n[2];
+            }
+        }
+        __syncthreads();      // the descriptors are rewritten by the next tile
     }
 }
 
