@@ -175,6 +175,9 @@ constexpr PfPlan pf_plan(int ks, int bytes)
     PfPlan p{3 * ks, pf_count(bytes), 0, 1};
     if (p.npw == 0) return p;
     p.dist = p.slots >= 36 ? 12 : (p.slots >= 18 ? 6 : (p.slots >= 9 ? 4 : 2));
+#ifdef AVC_PF_DIST_PCT
+    p.dist = p.dist * AVC_PF_DIST_PCT / 100; if (p.dist < 1) p.dist = 1; if (p.dist > p.slots - 2) p.dist = p.slots - 2;
+#endif
     const int span = p.slots - p.dist;                     // loads spread over [0, span)
     // pieces in flight at once = ceil(dist * npw / span) (+1 for the slot where a store and a load meet)
     p.ring = (p.dist * p.npw + span - 1) / span + 1;
@@ -405,6 +408,27 @@ __device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo)
 
 // Slice K of NS of the epilogue of a tile pair: accumulators -> scale -> activation -> split fp16,
 // written into the 4 B fragments (k-steps) the pair becomes for the next layer.  32 values per lane.
+// two values at once: both additions of the softplus become one packed v_pk_add_f32 each
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int ACT>
+__device__ __forceinline__ void act2_f(float x0, float x1, float &y0, float &y1)
+{
+    if constexpr (ACT == ACT_SOFTPLUS) {
+        f32x2 r, e;
+        asm("v_max_f32 %0, 0, %1" : "=v"(r.x) : "v"(x0));
+        asm("v_max_f32 %0, 0, %1" : "=v"(r.y) : "v"(x1));
+        e.x = __builtin_amdgcn_exp2f(-__builtin_fabsf(x0));
+        e.y = __builtin_amdgcn_exp2f(-__builtin_fabsf(x1));
+        e = e + 1.0f;
+        e.x = __builtin_amdgcn_logf(e.x);
+        e.y = __builtin_amdgcn_logf(e.y);
+        r = r + e;
+        y0 = r.x; y1 = r.y;
+    } else {
+        y0 = act_f<ACT>(x0); y1 = act_f<ACT>(x1);
+    }
+}
+
 template <int ACT, int NS, int K>
 __device__ __forceinline__ void epi_slice(const f32x16 *__restrict__ acc, Frag *__restrict__ out4)
 {
@@ -414,7 +438,9 @@ __device__ __forceinline__ void epi_slice(const f32x16 *__restrict__ acc, Frag *
         if constexpr (K < NS && pr < 16) {
             constexpr int v = 2 * pr, t = v >> 4, r = v & 15;
             unsigned h, l;
-            split2(act_f<ACT>(acc[t][r]), act_f<ACT>(acc[t][r + 1]), h, l);
+            float y0, y1;
+            act2_f<ACT>(acc[t][r], acc[t][r + 1], y0, y1);
+            split2(y0, y1, h, l);
             out4[2 * t + (r >> 3)].hi[(r & 7) >> 1] = h;
             out4[2 * t + (r >> 3)].lo[(r & 7) >> 1] = l;
         }

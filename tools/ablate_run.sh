@@ -1,4 +1,7 @@
 #!/bin/bash
+# A/B of libavcap_hip.so variants inside ONE gpurun call (box-to-box variance is larger than most effects):
+# every variant in avatarcap_amd/csrc/_abl/lib_*.so, two rounds, dense 256^3 query time.
 cd $GRAFT_REPO_ROOT
-echo "== baseline"; timeout 120 python tools/quick_perf.py 2>&1 | grep "res 256"
-for L in avatarcap_amd/csrc/_abl/lib_*.so; do echo "== $L"; AVCAP_LIB=$PWD/$L timeout 120 python tools/quick_perf.py 2>&1 | grep "res 256"; done
+for round in 1 2; do
+  for L in avatarcap_amd/csrc/_abl/lib_*.so; do echo -n "== $round $(basename $L): "; AVCAP_LIB=$PWD/$L timeout 120 python tools/quick_perf.py 2>&1 | grep "res 256"; done
+done

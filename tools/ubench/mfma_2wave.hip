@@ -72,17 +72,23 @@ void run(const char *name)
 {
     float *out; long long *cyc;
     hipMalloc(&out, 256 * THREADS * 4); hipMalloc(&cyc, 256 * 8);
-    const int iters = 500;
+    const int iters = 20000;
     hipFuncSetAttribute((const void *)bench<MODE, F, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((bench<MODE, F, THREADS>), dim3(256), dim3(THREADS), 65536, 0, out, cyc, iters);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((bench<MODE, F, THREADS>), dim3(256), dim3(THREADS), 65536, 0, out, cyc, iters);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((bench<MODE, F, THREADS>), dim3(256), dim3(THREADS), 65536, 0, out, cyc, iters);
+    hipEventRecord(e1, 0);
     hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> h(256);
     hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
     double avg = 0; for (auto v : h) avg += v; avg /= 256;
     const double per_triple = avg / (iters * 16.0);
     // useful MFMA flops per CU cycle: waves * 3 MFMAs * flops / cycles
     const double flops = (MODE == 0 ? 16.0 * 16 * 32 * 2 : 32.0 * 32 * 16 * 2) * 3 * (THREADS / 64);
-    printf("%-22s F=%2d fillers/triple: %6.1f cycles per triple per wave -> %5.0f MFMA flop/clk/CU (peak 4096)\n", name, F, per_triple, flops / per_triple);
+    printf("%-22s F=%2d fillers/triple: %6.1f cycles per triple per wave -> %5.0f MFMA flop/clk/CU (peak 4096); kernel %.3f ms, clock64 rate %.0f MHz, %.0f TFLOP/s\n",
+           name, F, per_triple, flops / per_triple, ms, avg / (ms * 1e3), flops * iters * 16.0 * 256 / (ms * 1e9));
     hipFree(out); hipFree(cyc);
 }
 
