@@ -19,7 +19,9 @@ The JSON line also carries:
                   SURVEY.md 8(d)) / mean launch time measured with HIP events on the launch stream,
                   against the dense fp16 MFMA peak (the kernel issues 3 fp16 MFMA passes per fp32
                   product, so `mfma_util` = 2.84 x frac is the matrix-pipe utilisation; `traffic` is the
-                  HBM byte count of the committed rocprofv3 --pmc pass, profiles/r01_pmc_avatar.md).
+                  HBM byte count of the committed rocprofv3 --pmc pass, profiles/r01_pmc_avatar.md;
+                  `sustained_mfma_tflops_measured` is the rate a pure MFMA + LDS-read loop holds on this part
+                  under its power-managed clock, profiles/r01_ubench_mfma_clock.md -- information, not `peak`).
   cpu_baseline -- the CPU oracle (NumPy float32 port of the reference path + C marching cubes) timed
                   on this host on a bounded sample and scaled to one 256^3 frame.
   masked       -- the same frame with the reference's own valid-band masking (only points within 0.1 m
@@ -43,6 +45,8 @@ FLOP_PER_POINT = 1_773_568          # warp 428,288 + shared 425,472 + geo 33,024
 MFMA_ISSUED_PER_POINT = 4920 * 32 * 32 * 16 * 2 / 32   # 4920 v_mfma_f32_32x32x16_f16 per 32 points (3 split passes,
                                                         # tile padding, shared.6 folded into geo.0: DESIGN.md section 2)
 PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+SUSTAINED_F16_TFLOPS = 1673.0      # what this part sustains on split-fp16 MFMAs fed from LDS once its clock manager has
+                                    # settled (1.6 GHz, pipe 99 % busy): profiles/r01_ubench_mfma_clock.md -- information only
 HBM_TRAFFIC_BYTES_256 = 0.72e9      # per dense 256^3 launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc
 
 
@@ -178,7 +182,9 @@ def main():
                          'algorithmic_flop_per_launch': N * FLOP_PER_POINT,
                          'mfma_issued_tflops': N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0,
                          'mfma_util': (N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 / PEAK_F16_TFLOPS) if avg_ms.value > 0 else 0.0,
-                         'fp32_mfma_peak_equiv': achieved / 157.3},
+                         'fp32_mfma_peak_equiv': achieved / 157.3,
+                         'sustained_mfma_tflops_measured': SUSTAINED_F16_TFLOPS,
+                         'mfma_issued_vs_sustained': (N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 / SUSTAINED_F16_TFLOPS) if avg_ms.value > 0 else 0.0},
         }
         if world == 1 and not args.no_masked:
             try:
