@@ -89,6 +89,8 @@ int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float
 // raster.hip
 int render_cano_maps(avc_ctx *ctx, const float *verts, const float *attrs, const int32_t *faces, int64_t nf, const float center[3],
                      int size, float *front, float *back, hipStream_t s);
+int render_mesh(avc_ctx *ctx, const float *verts, const float *attrs, const int32_t *faces, int64_t nf, const float mvp[16],
+                int W, int H, float *out, hipStream_t s);
 // knn_lbs.hip
 int knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, hipStream_t s);
 int calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s);

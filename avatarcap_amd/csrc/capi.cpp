@@ -203,6 +203,16 @@ int avc_render_cano_maps(avc_ctx *ctx, const float *verts, const float *attrs, i
     return render_cano_maps(ctx, verts, attrs, faces, nf, center, size, front, back, (hipStream_t)stream);
 }
 
+int avc_render_mesh(avc_ctx *ctx, const float *verts, const float *attrs, int64_t nv, const int32_t *faces, int64_t nf, const float mvp[16],
+                    int width, int height, float *out, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && mvp && out && nv >= 0 && nf >= 0 && (nf == 0 || (verts && faces)), AVC_ERR_ARG, "avc_render_mesh: NULL argument");
+    AVC_REQUIRE(width >= 1 && height >= 1 && width <= 16384 && height <= 16384, AVC_ERR_ARG, "avc_render_mesh: image size must be in [1, 16384]");
+    AVC_REQUIRE(nf < ((int64_t)1 << 32) - 1, AVC_ERR_ARG, "avc_render_mesh: too many faces for 32-bit triangle ids");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return render_mesh(ctx, verts, attrs, faces, nf, mvp, width, height, out, (hipStream_t)stream);
+}
+
 int avc_knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, avc_stream stream)
 {
     AVC_REQUIRE(ctx && nq >= 0 && nr > 0 && (nq == 0 || (q && ref)), AVC_ERR_ARG, "avc_knn: NULL argument");

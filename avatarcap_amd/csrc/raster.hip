@@ -117,6 +117,98 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float *__rest
     for (int k = 0; k < 3; ++k) out[k] = (l0 * A[k] + l1 * B[k]) + l2 * C[k];
 }
 
+
+// ---- general model-view-projection view (oracle/raster_oracle.c: raster_mvp_oracle) ----------------------------
+struct Mvp { float m[16]; };
+struct TriP { long long fx[3], fy[3]; float zn[3], iw[3]; };
+
+__device__ __forceinline__ bool load_tri_mvp(const float *__restrict__ verts, const int32_t *__restrict__ faces, long long t, const Mvp &M,
+                                             int W, int H, TriP &T)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float *p = verts + 3 * (long long)faces[3 * t + k];
+        float c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = ((M.m[4 * r] * p[0] + M.m[4 * r + 1] * p[1]) + M.m[4 * r + 2] * p[2]) + M.m[4 * r + 3];
+        if (!(c[3] > 0.0f)) return false;
+        T.iw[k] = 1.0f / c[3];
+        const float nx = c[0] * T.iw[k], ny = c[1] * T.iw[k];
+        T.zn[k] = c[2] * T.iw[k];
+        const float px = (nx + 1.0f) * (0.5f * (float)W) * (float)SUB + 0.5f, py = (1.0f - ny) * (0.5f * (float)H) * (float)SUB + 0.5f;
+        if (!(fabsf(px) < 1.0e12f) || !(fabsf(py) < 1.0e12f)) return false;
+        T.fx[k] = (long long)floorf(px); T.fy[k] = (long long)floorf(py);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void raster_mvp_depth_kernel(const float *__restrict__ verts, const int32_t *__restrict__ faces, long long nf,
+                                                               Mvp M, int W, int H, unsigned long long *__restrict__ keys)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nf) return;
+    TriP T;
+    if (!load_tri_mvp(verts, faces, t, M, W, H, T)) return;
+    long long area = edge_fn(T.fx[0], T.fy[0], T.fx[1], T.fy[1], T.fx[2], T.fy[2]);
+    if (area >= 0) return;                                   // back-facing or degenerate
+    const int a = 0, b = 2, c = 1; area = -area;
+    const long long minx = min(T.fx[0], min(T.fx[1], T.fx[2])), maxx = max(T.fx[0], max(T.fx[1], T.fx[2]));
+    const long long miny = min(T.fy[0], min(T.fy[1], T.fy[2])), maxy = max(T.fy[0], max(T.fy[1], T.fy[2]));
+    if (maxx < 0 || maxy < 0 || minx > (long long)W * SUB || miny > (long long)H * SUB) return;
+    long long x0 = (minx - SUB / 2 + SUB - 1) / SUB, x1 = (maxx - SUB / 2) / SUB;
+    long long y0 = (miny - SUB / 2 + SUB - 1) / SUB, y1 = (maxy - SUB / 2) / SUB;
+    if (minx - SUB / 2 < 0) x0 = 0;
+    if (miny - SUB / 2 < 0) y0 = 0;
+    x0 = max(x0, 0ll); y0 = max(y0, 0ll); x1 = min(x1, (long long)W - 1); y1 = min(y1, (long long)H - 1);
+    const bool tl0 = top_left(T.fx[c] - T.fx[b], T.fy[c] - T.fy[b]);
+    const bool tl1 = top_left(T.fx[a] - T.fx[c], T.fy[a] - T.fy[c]);
+    const bool tl2 = top_left(T.fx[b] - T.fx[a], T.fy[b] - T.fy[a]);
+    const float inv = 1.0f / (float)area;
+    for (long long py = y0; py <= y1; ++py)
+        for (long long px = x0; px <= x1; ++px) {
+            const long long sx = px * SUB + SUB / 2, sy = py * SUB + SUB / 2;
+            const long long w0 = edge_fn(T.fx[b], T.fy[b], T.fx[c], T.fy[c], sx, sy);
+            const long long w1 = edge_fn(T.fx[c], T.fy[c], T.fx[a], T.fy[a], sx, sy);
+            const long long w2 = edge_fn(T.fx[a], T.fy[a], T.fx[b], T.fy[b], sx, sy);
+            if (w0 < 0 || w1 < 0 || w2 < 0) continue;
+            if ((w0 == 0 && !tl0) || (w1 == 0 && !tl1) || (w2 == 0 && !tl2)) continue;
+            const float l0 = (float)w0 * inv, l1 = (float)w1 * inv, l2 = (float)w2 * inv;
+            const float z = (l0 * T.zn[a] + l1 * T.zn[b]) + l2 * T.zn[c];
+            if (!(z >= -1.0f && z <= 1.0f)) continue;
+            // GL_LESS: the smallest ndc.z wins, ties go to the lower triangle id
+            const unsigned long long key = ((unsigned long long)ordered(-z) << 32) | (unsigned long long)(0xffffffffu - (unsigned)t);
+            atomicMax(keys + py * W + px, key);
+        }
+}
+
+__global__ __launch_bounds__(256) void raster_mvp_resolve_kernel(const float *__restrict__ verts, const float *__restrict__ attrs,
+                                                                 const int32_t *__restrict__ faces, Mvp M, int W, int H,
+                                                                 const unsigned long long *__restrict__ keys, float *__restrict__ out)
+{
+    const long long pi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= (long long)W * H) return;
+    float4 *o = reinterpret_cast<float4 *>(out) + pi;
+    const unsigned long long key = keys[pi];
+    if (key == 0ull) { *o = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const long long t = (long long)(0xffffffffu - (unsigned)(key & 0xffffffffull));
+    TriP T;
+    load_tri_mvp(verts, faces, t, M, W, H, T);
+    const int a = 0, b = 2, c = 1;
+    const long long area = -edge_fn(T.fx[0], T.fy[0], T.fx[1], T.fy[1], T.fx[2], T.fy[2]);
+    const long long px = pi % W, py = pi / W;
+    const long long sx = px * SUB + SUB / 2, sy = py * SUB + SUB / 2;
+    const float inv = 1.0f / (float)area;
+    const float u0 = (float)edge_fn(T.fx[b], T.fy[b], T.fx[c], T.fy[c], sx, sy) * inv * T.iw[a];
+    const float u1 = (float)edge_fn(T.fx[c], T.fy[c], T.fx[a], T.fy[a], sx, sy) * inv * T.iw[b];
+    const float u2 = (float)edge_fn(T.fx[a], T.fy[a], T.fx[b], T.fy[b], sx, sy) * inv * T.iw[c];
+    const float den = 1.0f / ((u0 + u1) + u2);
+    const float *A = attrs + 3 * (long long)faces[3 * t + a], *B = attrs + 3 * (long long)faces[3 * t + b], *C = attrs + 3 * (long long)faces[3 * t + c];
+    float r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = ((u0 * A[k] + u1 * B[k]) + u2 * C[k]) * den;
+    *o = make_float4(r[0], r[1], r[2], 1.0f);
+}
+
 }  // namespace
 
 int render_cano_maps(avc_ctx *ctx, const float *verts, const float *attrs, const int32_t *faces, int64_t nf, const float center[3],
@@ -136,6 +228,27 @@ int render_cano_maps(avc_ctx *ctx, const float *verts, const float *attrs, const
                            center[0], center[1], center[2], size, keys);
     hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)((2ll * size * size + 255) / 256)), dim3(256), 0, s, verts, attrs, faces,
                        center[0], center[1], center[2], size, keys, front, back);
+    AVC_HIP(hipGetLastError());
+    return AVC_OK;
+}
+
+int render_mesh(avc_ctx *ctx, const float *verts, const float *attrs, const int32_t *faces, int64_t nf, const float mvp[16],
+                int W, int H, float *out, hipStream_t s)
+{
+    const size_t kbytes = sizeof(unsigned long long) * (size_t)W * H;
+    if (kbytes > ctx->raster_scratch_bytes) {
+        if (ctx->raster_scratch) AVC_HIP(hipFree(ctx->raster_scratch));
+        ctx->raster_scratch = nullptr; ctx->raster_scratch_bytes = 0;
+        AVC_HIP(hipMalloc(&ctx->raster_scratch, kbytes));
+        ctx->raster_scratch_bytes = kbytes;
+    }
+    unsigned long long *keys = (unsigned long long *)ctx->raster_scratch;
+    AVC_HIP(hipMemsetAsync(keys, 0, kbytes, s));
+    Mvp M;
+    for (int i = 0; i < 16; ++i) M.m[i] = mvp[i];
+    if (nf > 0) hipLaunchKernelGGL(raster_mvp_depth_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, verts, faces, (long long)nf, M, W, H, keys);
+    hipLaunchKernelGGL(raster_mvp_resolve_kernel, dim3((unsigned)(((long long)W * H + 255) / 256)), dim3(256), 0, s, verts, attrs ? attrs : verts,
+                       faces, M, W, H, keys, out);
     AVC_HIP(hipGetLastError());
     return AVC_OK;
 }

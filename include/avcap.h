@@ -137,6 +137,16 @@ int avc_render_cano_maps(avc_ctx *ctx, const float *verts_dev, const float *attr
                          const int32_t *faces_dev, int64_t nf, const float center[3], int size,
                          float *front_out_dev, float *back_out_dev, avc_stream stream);
 
+/* Renderer.render with the 'position' / 'vertex_attribute' shaders for an arbitrary model-view-projection matrix
+ * (utils/renderer.py:10-51,326-451), as normal_fusion.canonicalize_normal_map uses it with
+ * gl_perspective_projection_matrix to obtain the posed mesh's position map (normal_fusion/normal_fusion.py:14-20).
+ * mvp is row-major (the reference uploads it with transpose = GL_TRUE); attrs_dev == NULL renders the positions.
+ * out_dev (height, width, 4) f32 RGBA = (perspective-correct attribute, 1), background 0, row 0 at ndc.y = +1 (the
+ * reference flips the read-back, renderer.py:449).  Back faces culled, GL_LESS depth test on ndc.z in [-1, 1];
+ * triangles with a vertex at w <= 0 are dropped (not clipped).  OpenGL parity UNPINNED, oracle/raster_oracle.c. */
+int avc_render_mesh(avc_ctx *ctx, const float *verts_dev, const float *attrs_dev, int64_t nv, const int32_t *faces_dev,
+                    int64_t nf, const float mvp[16], int width, int height, float *out_dev, avc_stream stream);
+
 /* ---- SMPL utilities ------------------------------------------------------------------------
  * K nearest of nr reference points per query, squared L2 ascending, ties -> lower index
  * (pytorch3d.ops.knn_points as used at utils/smpl_util.py:33, dataset/avatarcap_dataset.py:114,

@@ -33,3 +33,20 @@ def render_cano_mesh(vertices, attrs, faces, center, size=512):
         _lib.raster_oracle(v.ctypes.data, a.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], c.ctypes.data, size, view, o.ctypes.data)
         outs.append(o)
     return outs[0], outs[1]
+
+
+def render_mesh(vertices, attrs, faces, mvp, width, height):
+    """General MVP view (raster_mvp_oracle): -> (height, width, 4) f32 RGBA = (attribute, 1), background 0.
+    attrs=None renders the vertex positions (the reference's 'position' shader)."""
+    global _lib
+    if _lib is None:
+        render_cano_mesh(np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32), np.zeros((0, 3), np.int32), np.zeros(3, np.float32), 2)
+    _lib.raster_mvp_oracle.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    v = np.ascontiguousarray(vertices, np.float32); f = np.ascontiguousarray(faces, np.int32)
+    a = None if attrs is None else np.ascontiguousarray(attrs, np.float32)
+    m = np.ascontiguousarray(mvp, np.float32).reshape(16)
+    o = np.zeros((height, width, 4), np.float32)
+    _lib.raster_mvp_oracle(v.ctypes.data, None if a is None else a.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], m.ctypes.data,
+                           width, height, o.ctypes.data)
+    return o

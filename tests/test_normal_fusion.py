@@ -1,0 +1,125 @@
+"""Canonical normal fusion (reference normal_fusion/normal_fusion.py).  Parity with the reference is
+UNPINNED (it needs OpenCV, pytorch3d and OpenGL): the oracle's hand-written gradients are pinned against torch.autograd on
+a torch restatement of the same loss, its OpenCV stand-ins against brute-force definitions, and the HIP kernels against it."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import normal_fusion_oracle as nfo
+
+
+def _aa2mat_torch(aa):
+    """pytorch3d.transforms.axis_angle_to_matrix as published (axis_angle_to_quaternion + quaternion_to_matrix)."""
+    angles = torch.norm(aa, p=2, dim=-1, keepdim=True)
+    half = angles * 0.5
+    small = angles.abs() < 1e-6
+    k = torch.empty_like(angles)
+    k[~small] = torch.sin(half[~small]) / angles[~small]
+    k[small] = 0.5 - (angles[small] * angles[small]) / 48
+    q = torch.cat([torch.cos(half), aa * k], dim=-1)
+    r, i, j, kk = torch.unbind(q, -1)
+    two_s = 2.0 / (q * q).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + kk * kk), two_s * (i * j - kk * r), two_s * (i * kk + j * r),
+                     two_s * (i * j + kk * r), 1 - two_s * (i * i + kk * kk), two_s * (j * kk - i * r),
+                     two_s * (i * kk - j * r), two_s * (j * kk + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(q.shape[:-1] + (3, 3))
+
+
+def _loss_torch(rot, src, tar, valid):
+    """One iteration's total_loss written with the reference's torch calls (normal_fusion.py:66-86, 120-133)."""
+    H, W = src.shape[:2]
+    theta = torch.tensor([[1, 0, 0], [0, 1, 0]], dtype=rot.dtype)
+    grid = F.affine_grid(theta[None], torch.Size((1, 1, H, W)), align_corners=True)
+    up = F.grid_sample(rot.permute(2, 0, 1)[None], grid, 'bilinear', 'border', True)[0].permute(1, 2, 0)
+    R = _aa2mat_torch(up)
+    data = torch.square(torch.einsum('ijab,ijb->ija', R, src) - tar)[valid].mean()
+    gh, gw = rot.shape[:2]
+    smooth = 0.
+    for i in (-1, 0, 1):
+        for j in (-1, 0, 1):
+            if i == 0 and j == 0: continue
+            th = torch.tensor([[1, 0, j / (gh / 2)], [0, 1, i / (gw / 2)]], dtype=rot.dtype)
+            g = F.affine_grid(th[None], torch.Size((1, 1, gh, gw)), align_corners=True)
+            nb = F.grid_sample(rot.permute(2, 0, 1)[None], g, mode='nearest', align_corners=True)[0].permute(1, 2, 0)
+            smooth = smooth + torch.square(nb - rot).mean()
+    return data + smooth
+
+
+def _case(seed, H=96, grid=16):
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:H]
+    body = ((yy - H / 2) ** 2 / (0.42 * H) ** 2 + (xx - H / 2) ** 2 / (0.25 * H) ** 2) < 1
+    n = rs.randn(H, H, 3); n[..., 2] += 2; n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    src = n * body[..., None]
+    t = n + 0.3 * rs.randn(H, H, 3); t /= np.linalg.norm(t, axis=-1, keepdims=True)
+    tar = t * (body & (xx > H * 0.3))[..., None]
+    rot = 0.2 * rs.randn(grid, grid, 3); rot[:3] = 0                       # some exactly-zero rotations (norm's subgradient)
+    return rot, src, tar
+
+
+def test_gradients_match_autograd():
+    rot, src, tar = _case(0)
+    valid = (np.linalg.norm(src, axis=-1) > 0) & (np.linalg.norm(tar, axis=-1) > 0)
+    loss, g_rot, g_src = nfo.fusion_loss_and_grads(rot.astype(np.float64), src.astype(np.float64), tar.astype(np.float64), valid)
+    tr = torch.tensor(rot, dtype=torch.float64, requires_grad=True); ts = torch.tensor(src, dtype=torch.float64, requires_grad=True)
+    lt = _loss_torch(tr, ts, torch.tensor(tar, dtype=torch.float64), torch.tensor(valid))
+    lt.backward()
+    assert abs(float(lt) - float(loss)) < 1e-12
+    assert np.abs(tr.grad.numpy() - g_rot).max() < 1e-12 * max(1, np.abs(g_rot).max()) + 1e-14
+    assert np.abs(ts.grad.numpy() - g_src).max() < 1e-13
+    assert np.abs(g_rot).max() > 1e-6 and np.abs(g_src).max() > 1e-6
+    # rotation matrices themselves
+    aa = np.concatenate([rot.reshape(-1, 3), np.zeros((2, 3)), np.float64([[1e-8, 0, 0], [3.0, -1.0, 0.5]])])
+    assert np.abs(_aa2mat_torch(torch.tensor(aa)).numpy() - nfo.axis_angle_to_matrix(aa)).max() < 1e-14
+
+
+def test_all_zero_rotation_start_and_no_valid_pixels():
+    rot, src, tar = _case(1)
+    z = np.zeros_like(rot)
+    valid = (np.linalg.norm(src, axis=-1) > 0) & (np.linalg.norm(tar, axis=-1) > 0)
+    _, g, _ = nfo.fusion_loss_and_grads(z, src, tar, valid)
+    tr = torch.tensor(z, requires_grad=True)
+    _loss_torch(tr, torch.tensor(src), torch.tensor(tar), torch.tensor(valid)).backward()
+    assert np.isfinite(g).all() and np.abs(tr.grad.numpy() - g).max() < 1e-12     # the first Adam step of the reference starts here
+    out = nfo.merge_normal_images(src, np.zeros_like(tar), 6, (40, 60), np.float64, grid=16)
+    assert np.array_equal(out, src)                                                # nothing observed: the avatar map comes back
+
+
+def test_opencv_stand_ins():
+    rs = np.random.RandomState(3)
+    m = rs.rand(40, 50) > 0.12
+    m[10:30, 15:40] = True
+    e = nfo.erode3x3(m, 3)
+    pad = np.ones((46, 56), bool); pad[3:43, 3:53] = m
+    brute = np.array([[pad[y:y + 7, x:x + 7].all() for x in range(50)] for y in range(40)])
+    assert np.array_equal(e.astype(bool), brute) and e.dtype == np.uint8
+    d = nfo.distance_transform_l1(e)
+    zy, zx = np.nonzero(e == 0)
+    yy, xx = np.mgrid[0:40, 0:50]
+    ref = (np.abs(yy[..., None] - zy) + np.abs(xx[..., None] - zx)).min(-1)
+    assert np.array_equal(d, ref.astype(np.float32)) and d.dtype == np.float32
+    assert np.all(nfo.distance_transform_l1(np.ones((5, 5), np.uint8)) == nfo.DT_CAP)
+
+
+def test_merge_runs_and_blends():
+    rot, src, tar = _case(2)
+    neck = (70, 50)                                                                # face rectangle rows [-40, 50) -> empty wrap, see below
+    out = nfo.merge_normal_images(src, tar, 20, neck, np.float64, grid=16)
+    out32 = nfo.merge_normal_images(src, tar, 20, neck, np.float32, grid=16)
+    assert np.isfinite(out).all() and np.abs(out - out32).max() < 2e-3            # fp32 run stays near the fp64 run
+    body = np.linalg.norm(src, axis=-1) > 0
+    obs = nfo.erode3x3(np.linalg.norm(tar, axis=-1) > 0, 3) > 0
+    assert np.array_equal(out[~obs], src[~obs])                                    # dt = 0 outside the eroded observation: avatar normal kept
+    inner = (nfo.distance_transform_l1(obs.astype(np.uint8)) > 5) & body
+    e_before = np.linalg.norm(src - tar, axis=-1)[inner].mean(); e_after = np.linalg.norm(out - tar, axis=-1)[inner].mean()
+    assert e_after < 0.6 * e_before                                                 # the fused map moved towards the observation
+    # the face rectangle [neck_y - 90, neck_y) x [neck_x - 35, neck_x + 35) follows the avatar, with Python's slice semantics:
+    # (70, 50) gives rows [-40:50] = [56:50] = nothing on a 96-row image; (48, 95) gives rows [5:95], columns [13:83]
+    face = nfo.merge_normal_images(src, tar, 20, (48, 95), np.float64, grid=16)
+    assert np.array_equal(face[5:95, 13:83], src[5:95, 13:83]) and not np.array_equal(out[5:95, 13:83], src[5:95, 13:83])
+    keep = np.ones(src.shape[:2], bool); keep[5:95, 13:83] = False
+    assert np.array_equal(face[keep], out[keep])
+    cov = nfo.merge_normal_images_cover(src, tar)
+    m = np.linalg.norm(tar, axis=-1) > 1e-6
+    assert np.array_equal(cov[m], tar[m]) and np.array_equal(cov[~m], src[~m])

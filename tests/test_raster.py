@@ -65,3 +65,69 @@ def test_hip_rasteriser_matches_oracle(size):
     assert np.array_equal(bk.cpu().numpy(), obk)
     e, _ = render_cano_mesh_device(torch.zeros(3, 3).cuda(), torch.zeros(3, 3).cuda(), torch.zeros((0, 3), dtype=torch.int32).cuda(), c, 32)
     assert float(e.abs().max()) == 0.0
+
+
+def _pinhole(W, H, f, tz):
+    from avatarcap_amd.utils.renderer import gl_perspective_projection_matrix
+    mv = np.eye(4, dtype=np.float32); mv[2, 3] = tz
+    return gl_perspective_projection_matrix(f, f, W / 2, H / 2, W, H) @ mv, mv
+
+
+def test_oracle_perspective_position_map():
+    """'position' shader through gl_perspective_projection_matrix (normal_fusion.py:14-20): every covered pixel
+    holds the surface point that projects onto it, the near side wins, inside-out meshes show their far side."""
+    v, f, nrm = _sphere_mesh()
+    W, H, fo = 320, 240, 300.0
+    mvp, mv = _pinhole(W, H, fo, 3.0)
+    img = raster.render_mesh(v, None, f, mvp, W, H)
+    m = img[..., 3] > 0
+    assert np.array_equal(np.unique(img[..., 3]), [0.0, 1.0]) and np.all(img[~m] == 0)
+    assert abs(m.sum() / (np.pi * (0.6 / np.sqrt(9 - 0.36) * fo) ** 2) - 1) < 0.01
+    rr, cc = np.nonzero(m)
+    p = img[m][:, :3]; pc = p @ mv[:3, :3].T + mv[:3, 3]
+    assert np.abs(pc[:, 0] / pc[:, 2] * fo + W / 2 - (cc + 0.5)).max() < 0.01      # perspective-correct interpolation
+    assert np.abs(pc[:, 1] / pc[:, 2] * fo + H / 2 - (rr + 0.5)).max() < 0.01
+    assert np.all(p[:, 2] < 0) and np.abs(np.linalg.norm(p, axis=1) - 0.6).max() < 3e-3
+    far = raster.render_mesh(v, None, f[:, ::-1].copy(), mvp, W, H)
+    assert np.mean(far[far[..., 3] > 0][:, 2] > 0) > 0.9
+    behind = raster.render_mesh(v, None, f, _pinhole(W, H, fo, -3.0)[0], W, H)       # camera inside-out: w <= 0 -> nothing
+    assert not behind.any()
+    att = raster.render_mesh(v, nrm, f, mvp, W, H)                                    # 'vertex_attribute' shader
+    assert np.abs(att[m][:, :3] - p / 0.6).max() < 0.02
+
+
+def test_oracle_orthographic_mvp_equals_cano_front_view():
+    """The general view with the reference's orthographic front matrix (visualize_util.py:15-22) reproduces the
+    dedicated front map."""
+    from avatarcap_amd.utils.renderer import gl_orthographic_projection_matrix
+    v, f, nrm = _sphere_mesh()
+    c = np.float32([0.05, -0.02, 0.1])
+    model = np.eye(4, dtype=np.float32); model[:3, 3] = -c; model[2, 3] -= 10
+    img = raster.render_mesh(v, nrm, f, gl_orthographic_projection_matrix() @ model, 256, 256)
+    fr, _ = raster.render_cano_mesh(v, nrm, f, c, 256)
+    assert np.array_equal(img[..., 3] > 0, np.linalg.norm(fr, axis=-1) > 0)
+    assert np.abs(img[..., :3] - fr).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_mvp_rasteriser_matches_oracle():
+    import torch
+    from avatarcap_amd.utils.renderer import Renderer, render_mesh_device
+    from avatarcap_amd import config
+    config.device = torch.device('cuda')
+    v, f, nrm = _sphere_mesh(48)
+    v2 = np.concatenate([v, 0.4 * v + np.float32([0.3, 0.2, -0.5])]).astype(np.float32)
+    f2 = np.concatenate([f, f + v.shape[0]]).astype(np.int32)
+    a2 = np.concatenate([nrm, -nrm]).astype(np.float32)
+    for (W, H, fo, tz) in ((320, 240, 300.0, 3.0), (512, 512, 900.0, 2.0), (64, 48, 40.0, 0.9)):     # the last one: camera close, parts off screen
+        mvp, _ = _pinhole(W, H, fo, tz)
+        for attrs in (None, a2):
+            o = raster.render_mesh(v2, attrs, f2, mvp, W, H)
+            d = render_mesh_device(torch.from_numpy(v2).cuda(), None if attrs is None else torch.from_numpy(attrs).cuda(),
+                                   torch.from_numpy(f2).cuda(), mvp, W, H)
+            assert np.array_equal(d.cpu().numpy(), o)
+    r = Renderer(320, 240, shader_name='position')                                   # reference call surface, triangle soup
+    r.set_model(v2[f2.reshape(-1)]); r.set_mvp_mat(_pinhole(320, 240, 300.0, 3.0)[0])
+    assert np.array_equal(r.render(), raster.render_mesh(v2, None, f2, _pinhole(320, 240, 300.0, 3.0)[0], 320, 240))
+    with pytest.raises(ValueError):
+        Renderer(8, 8, shader_name='phong_color')
