@@ -47,6 +47,10 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_render_mesh': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p]),
+    'avc_canonicalize_normals': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'avc_merge_normal_images': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'avc_merge_normal_images_cover': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'avc_knn': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_calculate_lbs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'avc_skinning': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

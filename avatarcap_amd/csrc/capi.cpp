@@ -45,6 +45,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->raster_scratch) hipFree(ctx->raster_scratch);
     if (ctx->knn_scratch) hipFree(ctx->knn_scratch);
     if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
+    if (ctx->fusion_scratch) hipFree(ctx->fusion_scratch);
     for (int w = 0; w < 2; ++w)
         for (auto &pr : ctx->timing.pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     delete ctx;
@@ -211,6 +212,34 @@ int avc_render_mesh(avc_ctx *ctx, const float *verts, const float *attrs, int64_
     AVC_REQUIRE(nf < ((int64_t)1 << 32) - 1, AVC_ERR_ARG, "avc_render_mesh: too many faces for 32-bit triangle ids");
     AVC_HIP(hipSetDevice(ctx->device));
     return render_mesh(ctx, verts, attrs, faces, nf, mvp, width, height, out, (hipStream_t)stream);
+}
+
+int avc_canonicalize_normals(avc_ctx *ctx, const float *live_v, const float *vert_mats, int64_t nv, const float *pos_map, const float *normal_map,
+                             int height, int width, const float mv[16], float fx, float fy, float cx, float cy, float *out, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && mv && nv >= 0 && (nv == 0 || (live_v && vert_mats && pos_map && normal_map && out)), AVC_ERR_ARG,
+                "avc_canonicalize_normals: NULL argument");
+    AVC_REQUIRE(height >= 1 && width >= 1, AVC_ERR_ARG, "avc_canonicalize_normals: empty image");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return canonicalize_normals(live_v, vert_mats, nv, pos_map, normal_map, height, width, mv, fx, fy, cx, cy, out, (hipStream_t)stream);
+}
+
+int avc_merge_normal_images(avc_ctx *ctx, const float *src, const float *tar, int height, int width, int iter_num, int neck_x, int neck_y,
+                            float *out, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && src && tar && out, AVC_ERR_ARG, "avc_merge_normal_images: NULL argument");
+    AVC_REQUIRE(height >= 2 && width >= 2 && (int64_t)height * width < ((int64_t)1 << 28), AVC_ERR_ARG,
+                "avc_merge_normal_images: image must be at least 2x2 and smaller than 2^28 pixels");
+    AVC_REQUIRE(iter_num >= 0, AVC_ERR_ARG, "avc_merge_normal_images: iter_num < 0");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return merge_normal_images(ctx, src, tar, height, width, iter_num, neck_x, neck_y, out, (hipStream_t)stream);
+}
+
+int avc_merge_normal_images_cover(avc_ctx *ctx, const float *src, const float *tar, int64_t npix, float *out, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && npix >= 0 && (npix == 0 || (src && tar && out)), AVC_ERR_ARG, "avc_merge_normal_images_cover: NULL argument");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return merge_normal_images_cover(src, tar, npix, out, (hipStream_t)stream);
 }
 
 int avc_knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, avc_stream stream)

@@ -88,6 +88,257 @@ static bool inv4_upper3(const float m[16], float out9[9])
     return true;
 }
 
+
+// ---- merge_normal_images (normal_fusion.py:89-155) ------------------------------------------------------------------
+// The reference runs 100 autograd iterations of two Adam optimisers (a 64x64 axis-angle grid, then the normal map itself)
+// from Python; here every iteration is one or two launches with the gradients written out by hand (oracle/
+// normal_fusion_oracle.py holds the same formulas, pinned against torch.autograd), and the OpenCV pre-processing
+// (3x3 erosion x3, L1 distance transform) runs on the device too.  Everything is fp32, deterministic (gathers, no atomics
+// in the iteration), HBM/latency-bound and tiny next to the two network passes it sits between.
+constexpr int GRID = 64;            // rot_aa_img is (64, 64, 3), normal_fusion.py:114
+constexpr float DT_CAP = 8192.0f;   // OpenCV's chamfer saturates there when the image holds no zero pixel
+
+__global__ void fus_masks_kernel(const float *__restrict__ src, const float *__restrict__ tar, int n, uint8_t *__restrict__ smask, uint8_t *__restrict__ tmask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *s = src + 3 * (size_t)i, *t = tar + 3 * (size_t)i;
+    smask[i] = sqrtf((s[0] * s[0] + s[1] * s[1]) + s[2] * s[2]) > 0.f;
+    tmask[i] = sqrtf((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]) > 0.f;
+}
+
+// cv.erode(3x3 rectangle, iterations = 3) == all set in the 7x7 window; pixels outside the image never erode
+__global__ void fus_erode_kernel(const uint8_t *__restrict__ in, int H, int W, int r, uint8_t *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i % W;
+    bool all = true;
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) all = all && in[yy * W + xx];
+        }
+    out[i] = all;
+}
+
+// cv.distanceTransform(DIST_L1, 3): the city-block distance is separable -- along rows first (one thread per row) ...
+__global__ void fus_dt_rows_kernel(const uint8_t *__restrict__ mask, int H, int W, float *__restrict__ g)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= H) return;
+    float d = 1e18f;
+    for (int x = 0; x < W; ++x) { d = mask[y * W + x] ? d + 1.f : 0.f; g[y * W + x] = d; }
+    d = 1e18f;
+    for (int x = W - 1; x >= 0; --x) { d = mask[y * W + x] ? d + 1.f : 0.f; g[y * W + x] = fminf(g[y * W + x], d); }
+}
+// ... then down the columns
+__global__ void fus_dt_cols_kernel(const float *__restrict__ g, int H, int W, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i % W;
+    float d = 1e18f;
+    for (int yy = 0; yy < H; ++yy) d = fminf(d, g[yy * W + x] + fabsf((float)(y - yy)));
+    out[i] = fminf(d, DT_CAP);
+}
+
+__global__ void fus_valid_kernel(const uint8_t *__restrict__ smask, const uint8_t *__restrict__ emask, int n, uint8_t *__restrict__ valid, int *__restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool v = i < n && smask[i] && emask[i];
+    if (i < n) valid[i] = v;
+    const unsigned long long b = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, __popcll(b));
+}
+
+struct Rot { float r, i, j, k, s2, sh, ch, kf, dk, th; };
+
+// pytorch3d axis_angle_to_matrix = axis_angle_to_quaternion + quaternion_to_matrix, with what the backward needs
+__device__ __forceinline__ void aa_forward(const float aa[3], float R[9], Rot &q)
+{
+    const float th = sqrtf((aa[0] * aa[0] + aa[1] * aa[1]) + aa[2] * aa[2]);
+    const float half = th * 0.5f;
+    const bool small = th < 1e-6f;
+    q.th = th; q.sh = sinf(half); q.ch = cosf(half);
+    q.kf = small ? 0.5f - th * th / 48.f : q.sh / th;
+    q.dk = small ? -th / 24.f : (q.ch * 0.5f * th - q.sh) / (th * th);
+    q.r = q.ch; q.i = aa[0] * q.kf; q.j = aa[1] * q.kf; q.k = aa[2] * q.kf;
+    const float N = (q.r * q.r + q.i * q.i) + (q.j * q.j + q.k * q.k);
+    q.s2 = 2.f / N;
+    const float s2 = q.s2, r = q.r, i = q.i, j = q.j, k = q.k;
+    R[0] = 1.f - s2 * (j * j + k * k); R[1] = s2 * (i * j - k * r); R[2] = s2 * (i * k + j * r);
+    R[3] = s2 * (i * j + k * r); R[4] = 1.f - s2 * (i * i + k * k); R[5] = s2 * (j * k - i * r);
+    R[6] = s2 * (i * k - j * r); R[7] = s2 * (j * k + i * r); R[8] = 1.f - s2 * (i * i + j * j);
+}
+
+// dL/daa from G = dL/dR (oracle: axis_angle_to_matrix_backward)
+__device__ __forceinline__ void aa_backward(const float aa[3], const Rot &q, const float G[9], float g[3])
+{
+    const float r = q.r, i = q.i, j = q.j, k = q.k, s2 = q.s2;
+    const float N = 2.f / s2;
+    const float P[9] = {-(j * j + k * k), i * j - k * r, i * k + j * r, i * j + k * r, -(i * i + k * k), j * k - i * r, i * k - j * r, j * k + i * r, -(i * i + j * j)};
+    float gp = 0.f;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) gp += G[e] * P[e];
+    const float dN = gp * (-s2 / N);
+    const float dr = s2 * (-k * G[1] + j * G[2] + k * G[3] - i * G[5] - j * G[6] + i * G[7]) + dN * 2.f * r;
+    const float di = s2 * (-2.f * i * (G[4] + G[8]) + j * (G[1] + G[3]) + k * (G[2] + G[6]) + r * (G[7] - G[5])) + dN * 2.f * i;
+    const float dj = s2 * (-2.f * j * (G[0] + G[8]) + i * (G[1] + G[3]) + k * (G[5] + G[7]) + r * (G[2] - G[6])) + dN * 2.f * j;
+    const float dkk = s2 * (-2.f * k * (G[0] + G[4]) + i * (G[2] + G[6]) + j * (G[5] + G[7]) + r * (G[3] - G[1])) + dN * 2.f * k;
+    const float dth = dr * (-q.sh * 0.5f) + ((di * aa[0] + dj * aa[1]) + dkk * aa[2]) * q.dk;
+    const float inv = q.th > 0.f ? 1.f / q.th : 0.f;       // the norm's gradient at the zero vector is 0 (torch)
+    g[0] = di * q.kf + dth * aa[0] * inv;
+    g[1] = dj * q.kf + dth * aa[1] * inv;
+    g[2] = dkk * q.kf + dth * aa[2] * inv;
+}
+
+struct AdamK { float step, bc2s; };     // lr / (1 - beta1^t), sqrt(1 - beta2^t)
+__device__ __forceinline__ float adam_update(float p, float g, float &m, float &v, AdamK a)
+{
+    m = m * 0.9f + g * (1.f - 0.9f);
+    v = v * 0.999f + g * g * (1.f - 0.999f);
+    return p - a.step * (m / (sqrtf(v) / a.bc2s + 1e-8f));
+}
+
+// one pixel of one iteration: rotation field sample -> residual -> gradient w.r.t. the sampled axis-angle (first half,
+// UPDATE_SRC = false) or Adam step of the normal itself (second half)
+template <bool UPDATE_SRC>
+__global__ __launch_bounds__(256) void fus_pixel_kernel(const float *__restrict__ rot, float *__restrict__ src, const float *__restrict__ tar,
+                                                        const uint8_t *__restrict__ valid, const int *__restrict__ count, int H, int W,
+                                                        float *__restrict__ g_up, float *__restrict__ am, float *__restrict__ av, AdamK ak)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    if (!valid[p]) {
+        if (!UPDATE_SRC) { g_up[3 * (size_t)p] = 0.f; g_up[3 * (size_t)p + 1] = 0.f; g_up[3 * (size_t)p + 2] = 0.f; }
+        return;
+    }
+    const int y = p / W, x = p % W;
+    // resize_img: bilinear, align_corners=True
+    const float py = (float)y * ((float)(GRID - 1) / (float)(H - 1)), px = (float)x * ((float)(GRID - 1) / (float)(W - 1));
+    const int y0 = min((int)floorf(py), GRID - 1), x0 = min((int)floorf(px), GRID - 1);
+    const int y1 = min(y0 + 1, GRID - 1), x1 = min(x0 + 1, GRID - 1);
+    const float ty = py - (float)y0, tx = px - (float)x0;
+    float aa[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a00 = rot[(y0 * GRID + x0) * 3 + c], a01 = rot[(y0 * GRID + x1) * 3 + c];
+        const float a10 = rot[(y1 * GRID + x0) * 3 + c], a11 = rot[(y1 * GRID + x1) * 3 + c];
+        aa[c] = (1.f - ty) * ((1.f - tx) * a00 + tx * a01) + ty * ((1.f - tx) * a10 + tx * a11);
+    }
+    float R[9]; Rot q;
+    aa_forward(aa, R, q);
+    float s[3] = {src[3 * (size_t)p], src[3 * (size_t)p + 1], src[3 * (size_t)p + 2]};
+    const float *t = tar + 3 * (size_t)p;
+    const float sc = 2.f / (3.f * (float)*count);
+    float gr[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gr[a] = (((R[3 * a] * s[0] + R[3 * a + 1] * s[1]) + R[3 * a + 2] * s[2]) - t[a]) * sc;
+    if (!UPDATE_SRC) {
+        float G[9], g[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) G[3 * a + b] = gr[a] * s[b];
+        aa_backward(aa, q, G, g);
+        g_up[3 * (size_t)p] = g[0]; g_up[3 * (size_t)p + 1] = g[1]; g_up[3 * (size_t)p + 2] = g[2];
+    } else {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float gs = (R[b] * gr[0] + R[3 + b] * gr[1]) + R[6 + b] * gr[2];
+            float m = am[3 * (size_t)p + b], v = av[3 * (size_t)p + b];
+            src[3 * (size_t)p + b] = adam_update(s[b], gs, m, v, ak);
+            am[3 * (size_t)p + b] = m; av[3 * (size_t)p + b] = v;
+        }
+    }
+}
+
+// one node of the rotation grid: gather the transposed bilinear footprint of g_up, add the smoothness gradient, Adam
+__global__ __launch_bounds__(64) void fus_grid_kernel(const float *__restrict__ rot_in, float *__restrict__ rot_out, const float *__restrict__ g_up,
+                                                      int H, int W, float *__restrict__ am, float *__restrict__ av, AdamK ak)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= GRID * GRID) return;
+    const int Y = n / GRID, X = n % GRID;
+    const float sy = (float)(GRID - 1) / (float)(H - 1), sx = (float)(GRID - 1) / (float)(W - 1);
+    const int ya = max(0, (int)ceilf((float)(Y - 1) / sy) - 1), yb = min(H - 1, (int)floorf((float)(Y + 1) / sy) + 1);
+    const int xa = max(0, (int)ceilf((float)(X - 1) / sx) - 1), xb = min(W - 1, (int)floorf((float)(X + 1) / sx) + 1);
+    float g[3] = {0.f, 0.f, 0.f};
+    for (int y = ya; y <= yb; ++y) {
+        const float py = (float)y * sy;
+        const int y0 = min((int)floorf(py), GRID - 1), y1 = min(y0 + 1, GRID - 1);
+        const float ty = py - (float)y0;
+        const float wy = (y0 == Y ? 1.f - ty : 0.f) + (y1 == Y ? ty : 0.f);
+        if (wy == 0.f) continue;
+        for (int x = xa; x <= xb; ++x) {
+            const float px = (float)x * sx;
+            const int x0 = min((int)floorf(px), GRID - 1), x1 = min(x0 + 1, GRID - 1);
+            const float tx = px - (float)x0;
+            const float wx = (x0 == X ? 1.f - tx : 0.f) + (x1 == X ? tx : 0.f);
+            if (wx == 0.f) continue;
+            const float w = wy * wx;
+            const float *gp = g_up + 3 * ((size_t)y * W + x);
+            g[0] += w * gp[0]; g[1] += w * gp[1]; g[2] += w * gp[2];
+        }
+    }
+    // smoothness: sum over the 8 neighbour images of mean((shift(rot) - rot)^2), zero padding (normal_fusion.py:66-78,127-131)
+    const float cM = 2.f / (float)(GRID * GRID * 3);
+    const float *c = rot_in + 3 * n;
+    for (int di = -1; di <= 1; ++di)
+        for (int dj = -1; dj <= 1; ++dj) {
+            if (di == 0 && dj == 0) continue;
+            const int yp = Y + di, xp = X + dj, ym = Y - di, xm = X - dj;
+            const bool inp = yp >= 0 && yp < GRID && xp >= 0 && xp < GRID, inm = ym >= 0 && ym < GRID && xm >= 0 && xm < GRID;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float fwd = c[k] - (inp ? rot_in[(yp * GRID + xp) * 3 + k] : 0.f);
+                const float bwd = inm ? c[k] - rot_in[(ym * GRID + xm) * 3 + k] : 0.f;
+                g[k] += cM * (fwd + bwd);
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float m = am[3 * n + k], v = av[3 * n + k];
+        rot_out[3 * n + k] = adam_update(c[k], g[k], m, v, ak);
+        am[3 * n + k] = m; av[3 * n + k] = v;
+    }
+}
+
+// merge_normal_images_cover (normal_fusion.py:158-167): the observed normal wherever there is one
+__global__ void fus_cover_kernel(const float *__restrict__ src, const float *__restrict__ tar, int64_t n, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *t = tar + 3 * i, *a = src + 3 * i;
+    const bool m = sqrtf((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]) > 1e-6f;
+    out[3 * i] = m ? t[0] : a[0]; out[3 * i + 1] = m ? t[1] : a[1]; out[3 * i + 2] = m ? t[2] : a[2];
+}
+
+// Python's slice(start, stop) on an axis of length n
+__host__ __device__ inline void py_slice(int start, int stop, int n, int &lo, int &hi)
+{
+    lo = start < 0 ? start + n : start; hi = stop < 0 ? stop + n : stop;
+    lo = lo < 0 ? 0 : (lo > n ? n : lo); hi = hi < 0 ? 0 : (hi > n ? n : hi);
+}
+
+// distance-transform blend and the face rectangle (normal_fusion.py:143-153)
+__global__ void fus_blend_kernel(const float *__restrict__ src, const float *__restrict__ init, const float *__restrict__ dtm, int H, int W,
+                                 int r0, int r1, int c0, int c1, float *__restrict__ out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, x = p % W;
+    const float d = dtm[p] / 5.f;
+    const float w0 = d > 1.f ? 0.f : 1.f;
+    const bool face = y >= r0 && y < r1 && x >= c0 && x < c1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float a = init[3 * (size_t)p + k];
+        out[3 * (size_t)p + k] = face ? a : (src[3 * (size_t)p + k] * d + a * w0) / (d + w0);
+    }
+}
+
 }  // namespace
 
 int canonicalize_normals(const float *live_v, const float *vert_mats, int64_t nv, const float *pos_map, const float *nrm_map, int H, int W,
@@ -99,6 +350,72 @@ int canonicalize_normals(const float *live_v, const float *vert_mats, int64_t nv
     AVC_REQUIRE(inv4_upper3(mv, a.Ri), AVC_ERR_ARG, "avc_canonicalize_normals: the model-view matrix is singular");
     a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.H = H; a.W = W;
     hipLaunchKernelGGL(canonicalize_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, live_v, vert_mats, nv, pos_map, nrm_map, a, out);
+    AVC_HIP(hipGetLastError());
+    return AVC_OK;
+}
+
+
+int merge_normal_images(avc_ctx *ctx, const float *src_in, const float *tar, int H, int W, int iter_num, int neck_x, int neck_y,
+                        float *out, hipStream_t s)
+{
+    const size_t np = (size_t)H * W;
+    // scratch: src work copy, Adam moments of src, g_up, dt (2 buffers), masks (4), rot ping-pong + moments, counter
+    const size_t fbytes = sizeof(float) * (3 * np * 4 + 2 * np + 4 * GRID * GRID * 3) + 4 * np + 256;
+    if (ctx->fusion_scratch_bytes < fbytes) {
+        if (ctx->fusion_scratch) AVC_HIP(hipFree(ctx->fusion_scratch));
+        ctx->fusion_scratch = nullptr; ctx->fusion_scratch_bytes = 0;
+        AVC_HIP(hipMalloc(&ctx->fusion_scratch, fbytes));
+        ctx->fusion_scratch_bytes = fbytes;
+    }
+    float *f = static_cast<float *>(ctx->fusion_scratch);
+    float *src = f; f += 3 * np;
+    float *sm = f; f += 3 * np;
+    float *sv = f; f += 3 * np;
+    float *g_up = f; f += 3 * np;
+    float *dt_g = f; f += np;
+    float *dtm = f; f += np;
+    float *rot_a = f; f += GRID * GRID * 3;
+    float *rot_b = f; f += GRID * GRID * 3;
+    float *rm = f; f += GRID * GRID * 3;
+    float *rv = f; f += GRID * GRID * 3;
+    int *count = reinterpret_cast<int *>(f); f += 64;
+    uint8_t *smask = reinterpret_cast<uint8_t *>(f), *tmask = smask + np, *emask = tmask + np, *valid = emask + np;
+    AVC_HIP(hipMemcpyAsync(src, src_in, sizeof(float) * 3 * np, hipMemcpyDeviceToDevice, s));
+    AVC_HIP(hipMemsetAsync(sm, 0, sizeof(float) * 6 * np, s));                                  // sm, sv
+    AVC_HIP(hipMemsetAsync(rot_a, 0, sizeof(float) * 4 * GRID * GRID * 3 + 256, s));            // rot_a, rot_b, rm, rv, count
+    const dim3 blk(256), grd((unsigned)((np + 255) / 256));
+    hipLaunchKernelGGL(fus_masks_kernel, grd, blk, 0, s, src_in, tar, (int)np, smask, tmask);
+    hipLaunchKernelGGL(fus_erode_kernel, grd, blk, 0, s, tmask, H, W, 3, emask);
+    hipLaunchKernelGGL(fus_dt_rows_kernel, dim3((H + 63) / 64), dim3(64), 0, s, emask, H, W, dt_g);
+    hipLaunchKernelGGL(fus_dt_cols_kernel, grd, blk, 0, s, dt_g, H, W, dtm);
+    hipLaunchKernelGGL(fus_valid_kernel, grd, blk, 0, s, smask, emask, (int)np, valid, count);
+    float *rin = rot_a, *rout = rot_b;
+    int t_rot = 0, t_src = 0;
+    for (int it = 0; it < iter_num; ++it) {
+        if (it < iter_num / 2.0) {                                                               // normal_fusion.py:134
+            ++t_rot;
+            const AdamK ak{(float)(1e-2 / (1.0 - std::pow(0.9, t_rot))), (float)std::sqrt(1.0 - std::pow(0.999, t_rot))};
+            hipLaunchKernelGGL(fus_pixel_kernel<false>, grd, blk, 0, s, rin, src, tar, valid, count, H, W, g_up, sm, sv, ak);
+            hipLaunchKernelGGL(fus_grid_kernel, dim3(GRID * GRID / 64), dim3(64), 0, s, rin, rout, g_up, H, W, rm, rv, ak);
+            std::swap(rin, rout);
+        } else {
+            ++t_src;
+            const AdamK ak{(float)(1e-1 / (1.0 - std::pow(0.9, t_src))), (float)std::sqrt(1.0 - std::pow(0.999, t_src))};
+            hipLaunchKernelGGL(fus_pixel_kernel<true>, grd, blk, 0, s, rin, src, tar, valid, count, H, W, g_up, sm, sv, ak);
+        }
+    }
+    int r0, r1, c0, c1;
+    py_slice(neck_y - 90, neck_y, H, r0, r1);
+    py_slice(neck_x - 35, neck_x + 35, W, c0, c1);
+    hipLaunchKernelGGL(fus_blend_kernel, grd, blk, 0, s, src, src_in, dtm, H, W, r0, r1, c0, c1, out);
+    AVC_HIP(hipGetLastError());
+    return AVC_OK;
+}
+
+int merge_normal_images_cover(const float *src, const float *tar, int64_t npix, float *out, hipStream_t s)
+{
+    if (npix == 0) return AVC_OK;
+    hipLaunchKernelGGL(fus_cover_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, src, tar, npix, out);
     AVC_HIP(hipGetLastError());
     return AVC_OK;
 }

@@ -89,3 +89,26 @@ def to_cuda(items: dict, add_batch=False):
         if add_batch and isinstance(out[key], torch.Tensor):
             out[key] = out[key].unsqueeze(0)
     return out
+
+
+def synthetic_camera(img_size=512, distance=2.6, focal=None):
+    """A pinhole in front of the body for the synthetic stand-in of the captured view (the reference reads `w2c_RT` and the
+    intrinsics from the sequence's camera file): x right, y down, z forward, looking down the world's -z at the origin."""
+    focal = float(focal if focal is not None else 1.1 * img_size)
+    w2c = np.diag(np.float32([1, -1, -1, 1])); w2c[2, 3] = distance
+    return w2c, {'fx': focal, 'fy': focal, 'cx': img_size / 2.0, 'cy': img_size / 2.0, 'img_w': img_size, 'img_h': img_size}
+
+
+def synthetic_observed_normals(live_v, live_vn, faces, w2c, cam, wobble=0.25, seed=0):
+    """What a normal-estimation network would hand over for the posed mesh, synthesised: the posed normals, bent by a smooth
+    random rotation field, in the image convention the reference undoes (camera frame with y and z negated), (H,W,3)."""
+    from .utils.renderer import gl_perspective_projection_matrix, render_mesh_device
+    g = torch.Generator().manual_seed(seed)
+    ax = torch.randn(3, 3, generator=g).to(live_v.device)
+    bend = wobble * torch.sin(live_v @ ax * 4.0)                                     # smooth axis-angle field over space
+    n = live_vn + torch.cross(bend, live_vn, dim=-1)
+    n = n / torch.linalg.norm(n, dim=-1, keepdim=True).clamp_min(1e-12)
+    R = torch.from_numpy(np.asarray(w2c, np.float32)[:3, :3]).to(live_v.device)
+    ncam = (n @ R.T) * torch.tensor([1., -1., -1.], device=live_v.device)
+    mvp = gl_perspective_projection_matrix(cam['fx'], cam['fy'], cam['cx'], cam['cy'], cam['img_w'], cam['img_h']) @ np.asarray(w2c, np.float32)
+    return render_mesh_device(live_v, ncam.contiguous(), faces, mvp, cam['img_w'], cam['img_h'])[..., :3].contiguous()

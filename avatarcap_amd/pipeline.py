@@ -78,6 +78,28 @@ class FramePipeline:
         return fr.permute(2, 0, 1)[None].contiguous(), bk.permute(2, 0, 1)[None].contiguous()
 
     @torch.no_grad()
+    def fuse_normals(self, avatar: dict, observed_normal: torch.Tensor, w2c_RT, cam: dict, integrate_manner: str = 'merge', iter_num: int = 100):
+        """2. canonical normal fusion (main.py:405-429): the image-observed normal map (H,W,3, device) is carried to the
+        canonical pose through the posed avatar mesh (`avatar` = the dict avatar_frame returned, with live_v / vert_mats)
+        and fused into the avatar's front map; the back map is the avatar's own (:427).  Returns (1,3,512,512) tensors."""
+        from .normal_fusion.normal_fusion import canonicalize_normal_map_device, merge_normal_images_device, merge_normal_images_cover_device
+        from .utils.visualize_util import render_cano_mesh_device
+        center = self.ds.cano_smpl_center
+        front_avatar, back_avatar = render_cano_mesh_device(avatar['cano_v'], avatar['cano_vn'], avatar['f'], center, 512)           # :369
+        front_image, _ = canonicalize_normal_map_device(avatar['cano_v'], avatar['live_v'], avatar['f'], observed_normal, avatar['vert_mats'],
+                                                        np.asarray(w2c_RT, np.float32), cam['fx'], cam['fy'], cam['cx'], cam['cy'], center)   # :413-415
+        if integrate_manner == 'merge':
+            neck_vert = smpl_util.cano_smpl_vertices[3068].cpu().numpy() - np.asarray(center, np.float32)                               # :418
+            neck_y = int((1. - neck_vert[1]) / 2. * 512)                                                                                # :419
+            neck_x = int((neck_vert[0] - 1) / 2. * 512)                                                                                 # :420 (negative: wraps, like the reference's slice)
+            front = merge_normal_images_device(front_avatar, front_image, iter_num, (neck_x, neck_y))                                   # :421
+        elif integrate_manner == 'cover':
+            front = merge_normal_images_cover_device(front_avatar, front_image)                                                          # :423
+        else:
+            raise ValueError('Invalid integration manner!')                                                                              # :425
+        return front.permute(2, 0, 1)[None].contiguous(), back_avatar.permute(2, 0, 1)[None].contiguous(), front_image
+
+    @torch.no_grad()
     def full_frame(self, items: dict):
         """Steps 1 and 3 chained on the device: avatar geometry -> its normal maps -> reconstruction.
         Step 2 of the reference (fusion with image-observed normals, normal_fusion.py) needs a captured

@@ -147,6 +147,35 @@ int avc_render_cano_maps(avc_ctx *ctx, const float *verts_dev, const float *attr
 int avc_render_mesh(avc_ctx *ctx, const float *verts_dev, const float *attrs_dev, int64_t nv, const int32_t *faces_dev,
                     int64_t nf, const float mvp[16], int width, int height, float *out_dev, avc_stream stream);
 
+/* ---- canonical normal fusion (normal_fusion/normal_fusion.py) ---------------------------------------------------------
+ * Parity with the reference UNPINNED (it needs OpenCV, pytorch3d and OpenGL); oracle/normal_fusion_oracle.py is pinned
+ * against torch.autograd.
+ *
+ * canonicalize_normal_map's per-vertex part (:27-62): project each posed vertex with mv (row-major 4x4, world -> camera:
+ * x right, y down, z forward) and the pinhole (fx, fy, cx, cy); sample the position map (the 'position' render of the
+ * posed mesh, avc_render_mesh) and the observed normal map at the nearest pixel (grid_sample nearest / border /
+ * align_corners=True); a vertex is visible if the rendered point lies within 0.05 of it; the observed normal has y, z
+ * negated, is rotated by inv(mv)[:3,:3] and by the inverse of the vertex's cano2live matrix (vert_mats, (nv,4,4), upper
+ * left 3x3), and is zeroed when the vertex is occluded or unobserved.  A singular vertex matrix gives 0 (the reference's
+ * torch.linalg.inv raises).  pos_map_dev (H,W,4), normal_map_dev (H,W,3), normals_out_dev (nv,3). */
+int avc_canonicalize_normals(avc_ctx *ctx, const float *live_v_dev, const float *vert_mats_dev, int64_t nv,
+                             const float *pos_map_dev, const float *normal_map_dev, int height, int width,
+                             const float mv[16], float fx, float fy, float cx, float cy, float *normals_out_dev,
+                             avc_stream stream);
+
+/* merge_normal_images (:89-155): src = avatar normal map, tar = image-observed canonical normal map, both (H,W,3);
+ * 3x3 erosion x3 and L1 distance transform of the observation mask, iter_num iterations (the first half: Adam(lr 1e-2)
+ * on a 64x64 axis-angle rotation grid, the second half: Adam(lr 1e-1) on the normals) of
+ * mean|R(x) src - tar|^2 over observed pixels + the 8-neighbour smoothness of the grid, distance-transform blend with
+ * the input, face rectangle [neck_y - 90, neck_y) x [neck_x - 35, neck_x + 35) (Python slice semantics) reset to the
+ * input.  out_dev (H,W,3), may not alias src_dev's scratch but may equal src_dev. */
+int avc_merge_normal_images(avc_ctx *ctx, const float *src_dev, const float *tar_dev, int height, int width, int iter_num,
+                            int neck_x, int neck_y, float *out_dev, avc_stream stream);
+
+/* merge_normal_images_cover (:158-167): out = tar where |tar| > 1e-6, src elsewhere; (npix,3) each */
+int avc_merge_normal_images_cover(avc_ctx *ctx, const float *src_dev, const float *tar_dev, int64_t npix, float *out_dev,
+                                  avc_stream stream);
+
 /* ---- SMPL utilities ------------------------------------------------------------------------
  * K nearest of nr reference points per query, squared L2 ascending, ties -> lower index
  * (pytorch3d.ops.knn_points as used at utils/smpl_util.py:33, dataset/avatarcap_dataset.py:114,

@@ -20,7 +20,7 @@ import torch
 
 
 def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w_nerf=False, frame_idx=None, interval=1,
-                  synthetic=False, n_frames=2, valid='band'):
+                  synthetic=False, n_frames=2, valid='band', integrate_manner='merge'):
     from avatarcap_amd import config, synthetic as syn
     from avatarcap_amd.dataset import SyntheticTestDataset, to_cuda
     from avatarcap_amd.network.arch_avatar import GeoTexAvatar
@@ -55,9 +55,15 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
         a = pipe.avatar_frame(items)                                              # step 1
         save = {'cano_v': a['cano_v'], 'cano_vn': a['cano_vn'], 'f': a['f'], 'live_v': a.get('live_v'), 'live_vn': a.get('live_vn')}
         if w_recon:
-            # step 2 (fusion with image-observed normals) needs a captured image; the avatar's own canonical normal
-            # maps (visualize_util.render_cano_mesh, main.py:369) go to the reconstruction network unchanged
-            items['front_normal'], items['back_normal'] = pipe.cano_normal_maps(a['cano_v'], a['cano_vn'], a['f'])
+            # step 2: canonical normal fusion (main.py:405-429).  The captured image's normal map is synthesised here
+            # (dataset.synthetic_observed_normals); with a real sequence it is read from normal_%04d.exr
+            if a['cano_v'].shape[0] > 0:
+                from avatarcap_amd.dataset import synthetic_camera, synthetic_observed_normals
+                w2c, cam = synthetic_camera()
+                observed = synthetic_observed_normals(a['live_v'], a['live_vn'], a['f'], w2c, cam, seed=i)
+                items['front_normal'], items['back_normal'], _ = pipe.fuse_normals(a, observed, w2c, cam, integrate_manner)
+            else:
+                items['front_normal'], items['back_normal'] = pipe.cano_normal_maps(a['cano_v'], a['cano_vn'], a['f'])
             r = pipe.recon_frame(items)                                           # step 3
             save.update({'recon_' + k: v for k, v in r.items() if k != 'occ_volume'})
         if w_nerf:                                                                # step 4 (main.py:464-477)
@@ -90,6 +96,7 @@ if __name__ == '__main__':
     arg_parser.add_argument('--valid', type=str, default='band', choices=['band', 'dense'])
     arg_parser.add_argument('--save-ply', action='store_true', help='write the live avatar / recon meshes as PLY (obj_io layout)')
     arg_parser.add_argument('--nerf', action='store_true', help='also evaluate vertex colours (w_nerf)')
+    arg_parser.add_argument('--integrate', type=str, default='merge', choices=['merge', 'cover'], help='normal fusion manner (main.py:281)')
     args = arg_parser.parse_args()
 
     from avatarcap_amd import config
@@ -97,4 +104,4 @@ if __name__ == '__main__':
     if args.mode == 'train':
         raise SystemExit('-m train is out of scope for the MI355X hot-path build (SURVEY.md section 2, row 12)')
     run_avatarcap(w_recon=True, save_avatar_mesh=args.save_ply, save_final_mesh=args.save_ply, w_nerf=args.nerf,
-                  synthetic=args.synthetic, n_frames=args.frames, valid=args.valid)
+                  synthetic=args.synthetic, n_frames=args.frames, valid=args.valid, integrate_manner=args.integrate)

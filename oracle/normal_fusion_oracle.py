@@ -133,12 +133,14 @@ def _lin_weights(n_in, n_out, dt):
 
 def resize_bilinear(img, shape):
     Wy, Wx = _lin_weights(img.shape[0], shape[0], img.dtype), _lin_weights(img.shape[1], shape[1], img.dtype)
-    return np.einsum('yY,xX,YXc->yxc', Wy, Wx, img)
+    t = np.tensordot(Wy, img, axes=(1, 0))                     # (y, X, c)
+    return np.tensordot(Wx, t, axes=(1, 1)).transpose(1, 0, 2)  # (x, y, c) -> (y, x, c)
 
 
 def resize_bilinear_backward(g, shape_in):
     Wy, Wx = _lin_weights(shape_in[0], g.shape[0], g.dtype), _lin_weights(shape_in[1], g.shape[1], g.dtype)
-    return np.einsum('yY,xX,yxc->YXc', Wy, Wx, g)
+    t = np.tensordot(Wy.T, g, axes=(1, 0))                     # (Y, x, c)
+    return np.tensordot(Wx.T, t, axes=(1, 1)).transpose(1, 0, 2)
 
 
 # ---- smoothness term (normal_fusion.py:66-78, 127-131) ----------------------------------------------------------------

@@ -201,3 +201,28 @@ def test_colour_transfer_to_recon_vertices(pipe64):
     _, idx = orc.knn(r['cano_v'][:500].cpu().numpy(), a['cano_v'].cpu().numpy(), 1)
     assert torch.equal(out[:500], col[torch.from_numpy(idx[:, 0]).cuda()])
     assert out.shape == (r['cano_v'].shape[0], 3)
+
+
+def test_normal_fusion_step_in_the_frame_loop(pipe64):
+    """Steps 1 -> 2 -> 3 of main.py on the device: avatar, canonical normal fusion with a (synthesised) observed normal
+    map, reconstruction.  The fused front map must differ from the avatar's where the body is observed, equal it elsewhere,
+    the back map is the avatar's own (main.py:427), and 'cover' is the observed map where it exists."""
+    from avatarcap_amd.dataset import to_cuda, synthetic_camera, synthetic_observed_normals
+    items = to_cuda(pipe64.ds[0], add_batch=True)
+    a = pipe64.avatar_frame(items)
+    w2c, cam = synthetic_camera()
+    obs = synthetic_observed_normals(a['live_v'], a['live_vn'], a['f'], w2c, cam, seed=1)
+    assert obs.shape == (512, 512, 3) and 0.01 < float((obs.abs().sum(-1) > 0).float().mean()) < 0.6
+    front, back, front_image = pipe64.fuse_normals(a, obs, w2c, cam, 'merge', iter_num=20)
+    fa, ba = pipe64.cano_normal_maps(a['cano_v'], a['cano_vn'], a['f'])
+    assert torch.equal(back, ba) and front.shape == (1, 3, 512, 512)
+    seen = front_image.abs().sum(-1) > 0
+    assert 0.005 < float(seen.float().mean()) < 0.5
+    changed = (front[0].permute(1, 2, 0) - fa[0].permute(1, 2, 0)).abs().sum(-1) > 1e-4
+    assert bool((changed & ~seen).sum() == 0) and int(changed.sum()) > 100
+    cover, _, _ = pipe64.fuse_normals(a, obs, w2c, cam, 'cover')
+    cm = front_image.pow(2).sum(-1).sqrt() > 1e-6
+    assert torch.equal(cover[0].permute(1, 2, 0)[cm], front_image[cm]) and torch.equal(cover[0].permute(1, 2, 0)[~cm], fa[0].permute(1, 2, 0)[~cm])
+    items['front_normal'], items['back_normal'] = front, back
+    r = pipe64.recon_frame(items)
+    assert r['cano_v'].shape[0] > 0
