@@ -63,8 +63,10 @@ def test_gradients_match_autograd():
     valid = (np.linalg.norm(src, axis=-1) > 0) & (np.linalg.norm(tar, axis=-1) > 0)
     loss, g_rot, g_src = nfo.fusion_loss_and_grads(rot.astype(np.float64), src.astype(np.float64), tar.astype(np.float64), valid)
     tr = torch.tensor(rot, dtype=torch.float64, requires_grad=True); ts = torch.tensor(src, dtype=torch.float64, requires_grad=True)
-    lt = _loss_torch(tr, ts, torch.tensor(tar, dtype=torch.float64), torch.tensor(valid))
-    lt.backward()
+    with torch.enable_grad():                                   # (other test modules switch autograd off globally)
+        lt = _loss_torch(tr, ts, torch.tensor(tar, dtype=torch.float64), torch.tensor(valid))
+        lt.backward()
+    lt = lt.detach()
     assert abs(float(lt) - float(loss)) < 1e-12
     assert np.abs(tr.grad.numpy() - g_rot).max() < 1e-12 * max(1, np.abs(g_rot).max()) + 1e-14
     assert np.abs(ts.grad.numpy() - g_src).max() < 1e-13
@@ -80,7 +82,8 @@ def test_all_zero_rotation_start_and_no_valid_pixels():
     valid = (np.linalg.norm(src, axis=-1) > 0) & (np.linalg.norm(tar, axis=-1) > 0)
     _, g, _ = nfo.fusion_loss_and_grads(z, src, tar, valid)
     tr = torch.tensor(z, requires_grad=True)
-    _loss_torch(tr, torch.tensor(src), torch.tensor(tar), torch.tensor(valid)).backward()
+    with torch.enable_grad():
+        _loss_torch(tr, torch.tensor(src), torch.tensor(tar), torch.tensor(valid)).backward()
     assert np.isfinite(g).all() and np.abs(tr.grad.numpy() - g).max() < 1e-12     # the first Adam step of the reference starts here
     out = nfo.merge_normal_images(src, np.zeros_like(tar), 6, (40, 60), np.float64, grid=16)
     assert np.array_equal(out, src)                                                # nothing observed: the avatar map comes back
