@@ -41,6 +41,21 @@ __global__ __launch_bounds__(THREADS, THREADS / 256) void bench(float *out, long
             }
         }
         for (int i = 0; i < 4; ++i) sum += acc[i][0] + acc[i][3];
+    } else if (MODE == 2) {     // 32x32x16, operands stay in registers: what do the LDS reads cost in clock?
+        f32x16 acc[2] = {{0}, {0}};
+        half8 ah = *reinterpret_cast<const half8 *>(smem + addr), al = *reinterpret_cast<const half8 *>(smem + addr + 1024);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[u & 1], 0, 0, 0);
+                acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[u & 1], 0, 0, 0);
+                acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[u & 1], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < F; ++k) f[k & 7] = __builtin_fmaf(f[k & 7], 1.0001f, 0.5f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        for (int i = 0; i < 2; ++i) sum += acc[i][0] + acc[i][15];
     } else {                    // 32x32x16, 2 accumulators (the shipped kernel's shape)
         f32x16 acc[2] = {{0}, {0}};
         half8 ah[2], al[2];
@@ -97,5 +112,6 @@ int main()
     run<1, 0, 256>("32x32x16 4 waves/CU"); run<1, 6, 256>("32x32x16 4 waves/CU"); run<1, 12, 256>("32x32x16 4 waves/CU"); run<1, 24, 256>("32x32x16 4 waves/CU");
     run<0, 0, 512>("16x16x32 8 waves/CU"); run<0, 3, 512>("16x16x32 8 waves/CU"); run<0, 6, 512>("16x16x32 8 waves/CU"); run<0, 12, 512>("16x16x32 8 waves/CU");
     run<0, 0, 256>("16x16x32 4 waves/CU"); run<0, 6, 256>("16x16x32 4 waves/CU");
+    run<2, 0, 256>("32x32x16 regs only"); run<2, 6, 256>("32x32x16 regs only");
     return 0;
 }
