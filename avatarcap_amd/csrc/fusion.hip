@@ -254,34 +254,35 @@ __global__ __launch_bounds__(256) void fus_pixel_kernel(const float *__restrict_
     }
 }
 
-// one node of the rotation grid: gather the transposed bilinear footprint of g_up, add the smoothness gradient, Adam
+// one node of the rotation grid per wave: the lanes share the node's transposed-bilinear footprint of g_up (up to
+// ~17 x 17 pixels), a fixed-order butterfly sums them (deterministic), lane 0 adds the smoothness gradient and takes the
+// Adam step
 __global__ __launch_bounds__(64) void fus_grid_kernel(const float *__restrict__ rot_in, float *__restrict__ rot_out, const float *__restrict__ g_up,
                                                       int H, int W, float *__restrict__ am, float *__restrict__ av, AdamK ak)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= GRID * GRID) return;
+    const int n = blockIdx.x, lane = threadIdx.x;
     const int Y = n / GRID, X = n % GRID;
     const float sy = (float)(GRID - 1) / (float)(H - 1), sx = (float)(GRID - 1) / (float)(W - 1);
     const int ya = max(0, (int)ceilf((float)(Y - 1) / sy) - 1), yb = min(H - 1, (int)floorf((float)(Y + 1) / sy) + 1);
     const int xa = max(0, (int)ceilf((float)(X - 1) / sx) - 1), xb = min(W - 1, (int)floorf((float)(X + 1) / sx) + 1);
+    const int nx = xb - xa + 1, cnt = nx * (yb - ya + 1);
     float g[3] = {0.f, 0.f, 0.f};
-    for (int y = ya; y <= yb; ++y) {
-        const float py = (float)y * sy;
+    for (int e = lane; e < cnt; e += 64) {
+        const int y = ya + e / nx, x = xa + e % nx;
+        const float py = (float)y * sy, px = (float)x * sx;
         const int y0 = min((int)floorf(py), GRID - 1), y1 = min(y0 + 1, GRID - 1);
-        const float ty = py - (float)y0;
+        const int x0 = min((int)floorf(px), GRID - 1), x1 = min(x0 + 1, GRID - 1);
+        const float ty = py - (float)y0, tx = px - (float)x0;
         const float wy = (y0 == Y ? 1.f - ty : 0.f) + (y1 == Y ? ty : 0.f);
-        if (wy == 0.f) continue;
-        for (int x = xa; x <= xb; ++x) {
-            const float px = (float)x * sx;
-            const int x0 = min((int)floorf(px), GRID - 1), x1 = min(x0 + 1, GRID - 1);
-            const float tx = px - (float)x0;
-            const float wx = (x0 == X ? 1.f - tx : 0.f) + (x1 == X ? tx : 0.f);
-            if (wx == 0.f) continue;
-            const float w = wy * wx;
-            const float *gp = g_up + 3 * ((size_t)y * W + x);
-            g[0] += w * gp[0]; g[1] += w * gp[1]; g[2] += w * gp[2];
-        }
+        const float wx = (x0 == X ? 1.f - tx : 0.f) + (x1 == X ? tx : 0.f);
+        const float w = wy * wx;
+        if (w == 0.f) continue;
+        const float *gp = g_up + 3 * ((size_t)y * W + x);
+        g[0] += w * gp[0]; g[1] += w * gp[1]; g[2] += w * gp[2];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { g[0] += __shfl_xor(g[0], o); g[1] += __shfl_xor(g[1], o); g[2] += __shfl_xor(g[2], o); }
+    if (lane != 0) return;
     // smoothness: sum over the 8 neighbour images of mean((shift(rot) - rot)^2), zero padding (normal_fusion.py:66-78,127-131)
     const float cM = 2.f / (float)(GRID * GRID * 3);
     const float *c = rot_in + 3 * n;
@@ -396,7 +397,7 @@ int merge_normal_images(avc_ctx *ctx, const float *src_in, const float *tar, int
             ++t_rot;
             const AdamK ak{(float)(1e-2 / (1.0 - std::pow(0.9, t_rot))), (float)std::sqrt(1.0 - std::pow(0.999, t_rot))};
             hipLaunchKernelGGL(fus_pixel_kernel<false>, grd, blk, 0, s, rin, src, tar, valid, count, H, W, g_up, sm, sv, ak);
-            hipLaunchKernelGGL(fus_grid_kernel, dim3(GRID * GRID / 64), dim3(64), 0, s, rin, rout, g_up, H, W, rm, rv, ak);
+            hipLaunchKernelGGL(fus_grid_kernel, dim3(GRID * GRID), dim3(64), 0, s, rin, rout, g_up, H, W, rm, rv, ak);
             std::swap(rin, rout);
         } else {
             ++t_src;
