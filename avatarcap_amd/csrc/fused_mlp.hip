@@ -46,12 +46,6 @@
 #ifndef AVC_DBG_TIMING
 #define AVC_DBG_TIMING 0
 #endif
-#ifndef AVC_DBG_PF_LOAD_ONLY
-#define AVC_DBG_PF_LOAD_ONLY 0
-#endif
-#ifndef AVC_DBG_PF_STORE_ONLY
-#define AVC_DBG_PF_STORE_ONLY 0
-#endif
 #ifndef AVC_DBG_PF_SAME
 #define AVC_DBG_PF_SAME 0
 #endif
@@ -209,19 +203,11 @@ __device__ __forceinline__ void pf_step(u32x4 (&st)[RING], const char *src, unsi
     constexpr PfPlan P = pf_plan(KS, NEXT_BYTES);
     static_for<P.npw>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
-#if AVC_DBG_PF_LOAD_ONLY
-        if constexpr (pf_load_slot(P, n) + P.dist == SLOT) asm volatile("" :: "v"(st[n % RING]));   // keep the load alive
-#else
         if constexpr (pf_load_slot(P, n) + P.dist == SLOT) pf_store<NEXT_BYTES, pf_nth(NEXT_BYTES, n)>(dst, lane16, wave, st[n % RING]);
-#endif
     });
     static_for<P.npw>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
-#if AVC_DBG_PF_STORE_ONLY
-        if constexpr (pf_load_slot(P, n) == SLOT) asm volatile("" : "=v"(st[n % RING]));
-#else
         if constexpr (pf_load_slot(P, n) == SLOT) st[n % RING] = pf_load<NEXT_BYTES, pf_nth(NEXT_BYTES, n)>(src, lane16, wave);
-#endif
     });
 #endif
 }
