@@ -65,6 +65,8 @@ struct avc_ctx {
     uint32_t *mc_tables_dev = nullptr;
     void *raster_scratch = nullptr; size_t raster_scratch_bytes = 0;
     void *fusion_scratch = nullptr; size_t fusion_scratch_bytes = 0;   // normal-fusion work buffers
+    void *fusion_graph = nullptr, *fusion_graph_exec = nullptr;        // hipGraph_t / hipGraphExec_t of the fusion iterations
+    int fusion_graph_H = 0, fusion_graph_W = 0, fusion_graph_iters = 0;
     void *gn_scratch = nullptr; size_t gn_scratch_bytes = 0;       // GroupNorm slice sums
     void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
     avc::Timing timing;
@@ -97,6 +99,7 @@ int canonicalize_normals(const float *live_v, const float *vert_mats, int64_t nv
                          const float mv[16], float fx, float fy, float cx, float cy, float *out, hipStream_t s);
 int merge_normal_images(avc_ctx *ctx, const float *src, const float *tar, int H, int W, int iter_num, int neck_x, int neck_y, float *out, hipStream_t s);
 int merge_normal_images_cover(const float *src, const float *tar, int64_t npix, float *out, hipStream_t s);
+void release_fusion_graph(avc_ctx *ctx);
 // knn_lbs.hip
 int knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, hipStream_t s);
 int calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s);

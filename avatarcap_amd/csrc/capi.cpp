@@ -45,6 +45,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->raster_scratch) hipFree(ctx->raster_scratch);
     if (ctx->knn_scratch) hipFree(ctx->knn_scratch);
     if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
+    release_fusion_graph(ctx);
     if (ctx->fusion_scratch) hipFree(ctx->fusion_scratch);
     for (int w = 0; w < 2; ++w)
         for (auto &pr : ctx->timing.pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 
 #include "avcap_internal.h"
@@ -356,59 +357,126 @@ int canonicalize_normals(const float *live_v, const float *vert_mats, int64_t nv
 }
 
 
-int merge_normal_images(avc_ctx *ctx, const float *src_in, const float *tar, int H, int W, int iter_num, int neck_x, int neck_y,
+// The iteration loop is launch-bound (150 dependent launches of a few microseconds each): it is built once per
+// (image size, iteration count, scratch allocation) as a hipGraph of kernel nodes whose arguments only reference the
+// context's scratch, cached in the context and replayed with one hipGraphLaunch per call.
+namespace {
+struct FusionBuffers { float *src, *tar, *sm, *sv, *g_up, *dt_g, *dtm, *rot_a, *rot_b, *rm, *rv; int *count; uint8_t *smask, *tmask, *emask, *valid; };
+
+template <typename... Args>
+int add_kernel_node(hipGraph_t g, hipGraphNode_t &prev, bool &has_prev, const void *func, dim3 grid, dim3 block, Args... args)
+{
+    void *params[] = {(void *)&args...};
+    hipKernelNodeParams p{};
+    p.func = const_cast<void *>(func); p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0; p.kernelParams = params; p.extra = nullptr;
+    hipGraphNode_t node;
+    AVC_HIP(hipGraphAddKernelNode(&node, g, has_prev ? &prev : nullptr, has_prev ? 1 : 0, &p));
+    prev = node; has_prev = true;
+    return AVC_OK;
+}
+
+// enqueue (graph == nullptr) or record (graph != nullptr) the iterations
+int fusion_iterations(const FusionBuffers &B, int H, int W, int iter_num, hipStream_t s, hipGraph_t graph)
+{
+    const dim3 blk(256), grd((unsigned)(((size_t)H * W + 255) / 256));
+    float *rin = B.rot_a, *rout = B.rot_b;
+    int t_rot = 0, t_src = 0;
+    hipGraphNode_t prev{}; bool has_prev = false;
+    for (int it = 0; it < iter_num; ++it) {
+        if (it < iter_num / 2.0) {                                                               // normal_fusion.py:134
+            ++t_rot;
+            const AdamK ak{(float)(1e-2 / (1.0 - std::pow(0.9, t_rot))), (float)std::sqrt(1.0 - std::pow(0.999, t_rot))};
+            if (graph) {
+                if (int rc = add_kernel_node(graph, prev, has_prev, (const void *)fus_pixel_kernel<false>, grd, blk, (const float *)rin, B.src, (const float *)B.tar,
+                                             (const uint8_t *)B.valid, (const int *)B.count, H, W, B.g_up, B.sm, B.sv, ak)) return rc;
+                if (int rc = add_kernel_node(graph, prev, has_prev, (const void *)fus_grid_kernel, dim3(GRID * GRID), dim3(64), (const float *)rin, rout,
+                                             (const float *)B.g_up, H, W, B.rm, B.rv, ak)) return rc;
+            } else {
+                hipLaunchKernelGGL(fus_pixel_kernel<false>, grd, blk, 0, s, rin, B.src, B.tar, B.valid, B.count, H, W, B.g_up, B.sm, B.sv, ak);
+                hipLaunchKernelGGL(fus_grid_kernel, dim3(GRID * GRID), dim3(64), 0, s, rin, rout, B.g_up, H, W, B.rm, B.rv, ak);
+            }
+            std::swap(rin, rout);
+        } else {
+            ++t_src;
+            const AdamK ak{(float)(1e-1 / (1.0 - std::pow(0.9, t_src))), (float)std::sqrt(1.0 - std::pow(0.999, t_src))};
+            if (graph) {
+                if (int rc = add_kernel_node(graph, prev, has_prev, (const void *)fus_pixel_kernel<true>, grd, blk, (const float *)rin, B.src, (const float *)B.tar,
+                                             (const uint8_t *)B.valid, (const int *)B.count, H, W, B.g_up, B.sm, B.sv, ak)) return rc;
+            } else {
+                hipLaunchKernelGGL(fus_pixel_kernel<true>, grd, blk, 0, s, rin, B.src, B.tar, B.valid, B.count, H, W, B.g_up, B.sm, B.sv, ak);
+            }
+        }
+    }
+    return AVC_OK;
+}
+}  // namespace
+
+void release_fusion_graph(avc_ctx *ctx)
+{
+    if (ctx->fusion_graph_exec) hipGraphExecDestroy(static_cast<hipGraphExec_t>(ctx->fusion_graph_exec));
+    if (ctx->fusion_graph) hipGraphDestroy(static_cast<hipGraph_t>(ctx->fusion_graph));
+    ctx->fusion_graph_exec = nullptr; ctx->fusion_graph = nullptr;
+}
+
+int merge_normal_images(avc_ctx *ctx, const float *src_in, const float *tar_in, int H, int W, int iter_num, int neck_x, int neck_y,
                         float *out, hipStream_t s)
 {
     const size_t np = (size_t)H * W;
-    // scratch: src work copy, Adam moments of src, g_up, dt (2 buffers), masks (4), rot ping-pong + moments, counter
-    const size_t fbytes = sizeof(float) * (3 * np * 4 + 2 * np + 4 * GRID * GRID * 3) + 4 * np + 256;
+    // scratch: working copies of both maps, Adam moments of src, g_up, dt (2 buffers), rot ping-pong + moments, counter, masks (4)
+    const size_t fbytes = sizeof(float) * (3 * np * 5 + 2 * np + 4 * GRID * GRID * 3) + 4 * np + 256;
     if (ctx->fusion_scratch_bytes < fbytes) {
+        release_fusion_graph(ctx);
         if (ctx->fusion_scratch) AVC_HIP(hipFree(ctx->fusion_scratch));
         ctx->fusion_scratch = nullptr; ctx->fusion_scratch_bytes = 0;
         AVC_HIP(hipMalloc(&ctx->fusion_scratch, fbytes));
         ctx->fusion_scratch_bytes = fbytes;
     }
+    FusionBuffers B;
     float *f = static_cast<float *>(ctx->fusion_scratch);
-    float *src = f; f += 3 * np;
-    float *sm = f; f += 3 * np;
-    float *sv = f; f += 3 * np;
-    float *g_up = f; f += 3 * np;
-    float *dt_g = f; f += np;
-    float *dtm = f; f += np;
-    float *rot_a = f; f += GRID * GRID * 3;
-    float *rot_b = f; f += GRID * GRID * 3;
-    float *rm = f; f += GRID * GRID * 3;
-    float *rv = f; f += GRID * GRID * 3;
-    int *count = reinterpret_cast<int *>(f); f += 64;
-    uint8_t *smask = reinterpret_cast<uint8_t *>(f), *tmask = smask + np, *emask = tmask + np, *valid = emask + np;
-    AVC_HIP(hipMemcpyAsync(src, src_in, sizeof(float) * 3 * np, hipMemcpyDeviceToDevice, s));
-    AVC_HIP(hipMemsetAsync(sm, 0, sizeof(float) * 6 * np, s));                                  // sm, sv
-    AVC_HIP(hipMemsetAsync(rot_a, 0, sizeof(float) * 4 * GRID * GRID * 3 + 256, s));            // rot_a, rot_b, rm, rv, count
+    B.src = f; f += 3 * np;
+    B.tar = f; f += 3 * np;
+    B.sm = f; f += 3 * np;
+    B.sv = f; f += 3 * np;
+    B.g_up = f; f += 3 * np;
+    B.dt_g = f; f += np;
+    B.dtm = f; f += np;
+    B.rot_a = f; f += GRID * GRID * 3;
+    B.rot_b = f; f += GRID * GRID * 3;
+    B.rm = f; f += GRID * GRID * 3;
+    B.rv = f; f += GRID * GRID * 3;
+    B.count = reinterpret_cast<int *>(f); f += 64;
+    B.smask = reinterpret_cast<uint8_t *>(f); B.tmask = B.smask + np; B.emask = B.tmask + np; B.valid = B.emask + np;
+    AVC_HIP(hipMemcpyAsync(B.src, src_in, sizeof(float) * 3 * np, hipMemcpyDeviceToDevice, s));
+    AVC_HIP(hipMemcpyAsync(B.tar, tar_in, sizeof(float) * 3 * np, hipMemcpyDeviceToDevice, s));
+    AVC_HIP(hipMemsetAsync(B.sm, 0, sizeof(float) * 6 * np, s));                                  // sm, sv
+    AVC_HIP(hipMemsetAsync(B.rot_a, 0, sizeof(float) * 4 * GRID * GRID * 3 + 256, s));            // rot_a, rot_b, rm, rv, count
     const dim3 blk(256), grd((unsigned)((np + 255) / 256));
-    hipLaunchKernelGGL(fus_masks_kernel, grd, blk, 0, s, src_in, tar, (int)np, smask, tmask);
-    hipLaunchKernelGGL(fus_erode_kernel, grd, blk, 0, s, tmask, H, W, 3, emask);
-    hipLaunchKernelGGL(fus_dt_rows_kernel, dim3((H + 63) / 64), dim3(64), 0, s, emask, H, W, dt_g);
-    hipLaunchKernelGGL(fus_dt_cols_kernel, grd, blk, 0, s, dt_g, H, W, dtm);
-    hipLaunchKernelGGL(fus_valid_kernel, grd, blk, 0, s, smask, emask, (int)np, valid, count);
-    float *rin = rot_a, *rout = rot_b;
-    int t_rot = 0, t_src = 0;
-    for (int it = 0; it < iter_num; ++it) {
-        if (it < iter_num / 2.0) {                                                               // normal_fusion.py:134
-            ++t_rot;
-            const AdamK ak{(float)(1e-2 / (1.0 - std::pow(0.9, t_rot))), (float)std::sqrt(1.0 - std::pow(0.999, t_rot))};
-            hipLaunchKernelGGL(fus_pixel_kernel<false>, grd, blk, 0, s, rin, src, tar, valid, count, H, W, g_up, sm, sv, ak);
-            hipLaunchKernelGGL(fus_grid_kernel, dim3(GRID * GRID), dim3(64), 0, s, rin, rout, g_up, H, W, rm, rv, ak);
-            std::swap(rin, rout);
+    hipLaunchKernelGGL(fus_masks_kernel, grd, blk, 0, s, src_in, tar_in, (int)np, B.smask, B.tmask);
+    hipLaunchKernelGGL(fus_erode_kernel, grd, blk, 0, s, B.tmask, H, W, 3, B.emask);
+    hipLaunchKernelGGL(fus_dt_rows_kernel, dim3((H + 63) / 64), dim3(64), 0, s, B.emask, H, W, B.dt_g);
+    hipLaunchKernelGGL(fus_dt_cols_kernel, grd, blk, 0, s, B.dt_g, H, W, B.dtm);
+    hipLaunchKernelGGL(fus_valid_kernel, grd, blk, 0, s, B.smask, B.emask, (int)np, B.valid, B.count);
+    if (iter_num > 0) {
+        if (getenv("AVC_FUSION_NO_GRAPH")) {                                                     // A/B knob: plain launches
+            if (int rc = fusion_iterations(B, H, W, iter_num, s, nullptr)) return rc;
         } else {
-            ++t_src;
-            const AdamK ak{(float)(1e-1 / (1.0 - std::pow(0.9, t_src))), (float)std::sqrt(1.0 - std::pow(0.999, t_src))};
-            hipLaunchKernelGGL(fus_pixel_kernel<true>, grd, blk, 0, s, rin, src, tar, valid, count, H, W, g_up, sm, sv, ak);
+            if (!ctx->fusion_graph_exec || ctx->fusion_graph_H != H || ctx->fusion_graph_W != W || ctx->fusion_graph_iters != iter_num) {
+                release_fusion_graph(ctx);
+                hipGraph_t g;
+                AVC_HIP(hipGraphCreate(&g, 0));
+                ctx->fusion_graph = g;
+                if (int rc = fusion_iterations(B, H, W, iter_num, s, g)) { release_fusion_graph(ctx); return rc; }
+                hipGraphExec_t ex;
+                AVC_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+                ctx->fusion_graph_exec = ex; ctx->fusion_graph_H = H; ctx->fusion_graph_W = W; ctx->fusion_graph_iters = iter_num;
+            }
+            AVC_HIP(hipGraphLaunch(static_cast<hipGraphExec_t>(ctx->fusion_graph_exec), s));
         }
     }
     int r0, r1, c0, c1;
     py_slice(neck_y - 90, neck_y, H, r0, r1);
     py_slice(neck_x - 35, neck_x + 35, W, c0, c1);
-    hipLaunchKernelGGL(fus_blend_kernel, grd, blk, 0, s, src, src_in, dtm, H, W, r0, r1, c0, c1, out);
+    hipLaunchKernelGGL(fus_blend_kernel, grd, blk, 0, s, B.src, src_in, B.dtm, H, W, r0, r1, c0, c1, out);
     AVC_HIP(hipGetLastError());
     return AVC_OK;
 }
