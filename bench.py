@@ -61,7 +61,9 @@ def build_pipeline(res, valid, n_frames, device):
     config.cfg = config.default_cfg()
     config.cfg['testing']['vol_res'] = [res, res, res]
     ds = SyntheticTestDataset([res, res, res], valid=valid, n_frames=n_frames, device=device)
-    net = GeoTexAvatar(base_weight_volume=np.zeros((2, 2, 2, 24), np.float32)).to(device).eval()
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # the reference's constructors announce themselves on stdout; this script prints ONE line there
+        net = GeoTexAvatar(base_weight_volume=np.zeros((2, 2, 2, 24), np.float32)).to(device).eval()
     sd = syn.synth_state_dict(syn.module_shapes(net), syn.SEED)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return FramePipeline(net, ds), sd
