@@ -131,3 +131,77 @@ def test_ply_writer_is_byte_identical_to_reference(golden, tmp_path):
         fn = tmp_path / f'{tag}.ply'
         save_mesh_as_ply(str(fn), v, f, **kw)
         assert np.array_equal(np.frombuffer(fn.read_bytes(), np.uint8), golden['G14_ply_' + tag]), tag
+
+
+def _write_exr(path, img, names, pixel_type, compression):
+    """An independent writer of the OpenEXR scanline layout (header, offset table, chunks; RLE / ZIPS / ZIP with the
+    byte split + delta predictor) -- test-side only."""
+    import struct, zlib
+    H, W, C = img.shape
+    dt = {1: '<f2', 2: '<f4', 0: '<u4'}[pixel_type]
+    order = sorted(range(C), key=lambda i: names[i])                      # channels are stored alphabetically
+    def attr(name, typ, val): return name.encode() + b'\0' + typ.encode() + b'\0' + struct.pack('<i', len(val)) + val
+    ch = b''.join(names[i].encode() + b'\0' + struct.pack('<iB3xii', pixel_type, 0, 1, 1) for i in order) + b'\0'
+    box = struct.pack('<4i', 0, 0, W - 1, H - 1)
+    hdr = struct.pack('<ii', 20000630, 2) + attr('channels', 'chlist', ch) + attr('compression', 'compression', bytes([compression])) + \
+        attr('dataWindow', 'box2i', box) + attr('displayWindow', 'box2i', box) + attr('lineOrder', 'lineOrder', b'\0') + \
+        attr('pixelAspectRatio', 'float', struct.pack('<f', 1.0)) + attr('screenWindowCenter', 'v2f', struct.pack('<2f', 0, 0)) + \
+        attr('screenWindowWidth', 'float', struct.pack('<f', 1.0)) + b'\0'
+    lines = {0: 1, 1: 1, 2: 1, 3: 16}[compression]
+    chunks = []
+    for y in range(0, H, lines):
+        raw = b''.join(img[r, :, i].astype(dt).tobytes() for r in range(y, min(y + lines, H)) for i in order)
+        data = raw
+        if compression:
+            t = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]]).astype(np.int64)
+            d = t.copy(); d[1:] = (t[1:] - t[:-1] + 128 + 256) & 0xff
+            pre = d.astype(np.uint8).tobytes()
+            if compression == 1:                                           # RLE: runs of >= 3 as (count - 1, byte), literals as (-n, bytes)
+                out, i = bytearray(), 0
+                while i < len(pre):
+                    j = i
+                    while j + 1 < len(pre) and pre[j + 1] == pre[i] and j - i < 126: j += 1
+                    if j - i >= 2: out += bytes([j - i, pre[i]]); i = j + 1
+                    else:
+                        k = i
+                        while k < len(pre) and k - i < 127 and not (k + 2 < len(pre) and pre[k] == pre[k + 1] == pre[k + 2]): k += 1
+                        out += bytes([256 - (k - i)]) + pre[i:k]; i = k
+                comp = bytes(out)
+            else:
+                comp = zlib.compress(pre)
+            data = comp if len(comp) < len(raw) else raw
+        chunks.append(struct.pack('<ii', y, len(data)) + data)
+    pos = len(hdr) + 8 * len(chunks)
+    table = b''
+    for c in chunks: table += struct.pack('<Q', pos); pos += len(c)
+    open(path, 'wb').write(hdr + table + b''.join(chunks))
+
+
+def test_exr_reader_round_trip(tmp_path):
+    """utils/exr_io.read_exr (stands in for cv.imread(..., IMREAD_UNCHANGED) of the image-normal EXR files, main.py:408-410)."""
+    from avatarcap_amd.utils.exr_io import read_exr
+    rs = np.random.RandomState(0)
+    img = rs.randn(37, 29, 3).astype(np.float32); img[5:20, 3:25] = 0          # flat regions exercise RLE runs
+    for comp in (0, 1, 2, 3):
+        for ptype in (2, 1):
+            p = str(tmp_path / f'n_{comp}_{ptype}.exr')
+            _write_exr(p, img, 'RGB', ptype, comp)
+            got = read_exr(p)
+            want = img if ptype == 2 else img.astype(np.float16).astype(np.float32)
+            assert got.dtype == np.float32 and got.shape == (37, 29, 3)
+            assert np.array_equal(got, want[..., ::-1])                       # cv.imread order: B, G, R
+            assert np.array_equal(read_exr(p, order='RGB'), want)
+    p = str(tmp_path / 'rgba.exr')
+    rgba = rs.rand(8, 8, 4).astype(np.float32)
+    _write_exr(p, rgba, 'RGBA', 2, 3)
+    assert np.array_equal(read_exr(p), rgba[..., [2, 1, 0, 3]])
+    bad = str(tmp_path / 'piz.exr')
+    _write_exr(bad, img, 'RGB', 2, 0)
+    raw = bytearray(open(bad, 'rb').read()); i = raw.index(b'compression\0compression\0') + 24 + 4; raw[i] = 4
+    open(bad, 'wb').write(raw)
+    with pytest.raises(NotImplementedError, match='PIZ'):
+        read_exr(bad)
+    open(bad, 'wb').write(b'not an exr file at all')
+    with pytest.raises(ValueError):
+        read_exr(bad)
