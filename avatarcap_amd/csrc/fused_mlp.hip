@@ -22,6 +22,7 @@
 //   * fused prologue: bilinear gather of the channel-last feature map, positional encoding
 //     (accurate sincosf), the p + offset hand-off in fp32.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include <utility>
@@ -875,7 +876,8 @@ int launch_avatar(avc_ctx *ctx, const float *pts, int64_t n, const float center[
     p.out0 = occ; p.out1 = offset; p.out2 = rgba; p.sigmoid_occ = occ_sigmoid;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;
     p.stream_bytes = bytes_until(net, net.chunks.size());
-    const int grid = (int)std::min<int64_t>(p.ntiles, ctx->num_cus);
+    const char *gb = getenv("AVC_MLP_BLOCKS");           // experiment knob: persistent workgroups (default: one per CU)
+    const int grid = (int)std::min<int64_t>(p.ntiles, gb && atoi(gb) > 0 ? atoi(gb) : ctx->num_cus);
     hipEvent_t e0, e1;
     timing_begin(ctx, 0, s, e0, e1);
     int rc = AVC_OK;
