@@ -30,16 +30,13 @@
 #include "avcap_internal.h"
 #include "mlp_layout.h"
 
-// Compile-time ablation knobs for kernel A/B timing (tools/ablate.sh).  All default to 0; any other
+// Compile-time ablation knobs for kernel A/B timing (tools/ablate_build.sh, tools/ablate_run.sh).  All default to 0; any other
 // setting produces WRONG results and exists only to attribute time.
 #ifndef AVC_DBG_NO_PREFETCH
 #define AVC_DBG_NO_PREFETCH 0
 #endif
 #ifndef AVC_DBG_NO_BARRIER
 #define AVC_DBG_NO_BARRIER 0
-#endif
-#ifndef AVC_DBG_NO_SIDE
-#define AVC_DBG_NO_SIDE 0
 #endif
 #ifndef AVC_DBG_OCML_SINCOS
 #define AVC_DBG_OCML_SINCOS 0
@@ -279,11 +276,7 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
         __builtin_amdgcn_sched_barrier(0);
         // ---- slot 2
         pf_step<KS, NEXT_BYTES, 3 * k + 2, P.ring>(st, src, dst, s.lane_off, s.wave);
-#if AVC_DBG_NO_SIDE
-        if constexpr (k == 0) side(kc);
-#else
         side(kc);
-#endif
 #pragma unroll
         for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
