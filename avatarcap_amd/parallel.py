@@ -48,10 +48,12 @@ def all_gather_meshes(meshes: list[dict], n_frames: int, group=None, force: bool
     fmax = int(all_counts[:, :, 1].sum(1).max()) * 3
     vpad = torch.zeros(max(vmax, 1), dtype=torch.float32, device=device); vpad[:vbuf.numel()] = vbuf
     fpad = torch.zeros(max(fmax, 1), dtype=torch.int32, device=device); fpad[:fbuf.numel()] = fbuf
-    all_v = [torch.empty_like(vpad) for _ in range(world)]
-    all_f = [torch.empty_like(fpad) for _ in range(world)]
-    dist.all_gather(all_v, vpad, group=group)
-    dist.all_gather(all_f, fpad, group=group)
+    # one flat receive buffer per collective (no per-rank staging copies); the per-rank pieces below are views of it
+    flat_v = torch.empty(world * vpad.numel(), dtype=vpad.dtype, device=device)
+    flat_f = torch.empty(world * fpad.numel(), dtype=fpad.dtype, device=device)
+    dist.all_gather_into_tensor(flat_v, vpad, group=group)
+    dist.all_gather_into_tensor(flat_f, fpad, group=group)
+    all_v, all_f = flat_v.reshape(world, -1), flat_f.reshape(world, -1)
     out = [None] * n_frames
     for r in range(world):
         vo = fo = 0
