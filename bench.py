@@ -52,6 +52,23 @@ HBM_TRAFFIC_BYTES_256 = 1.98e9      # per dense 256^3 launch: 2 x FETCH_SIZE (gf
                                     # that falls out of L2 varies, the writes are exact)
 
 
+class _stdout_to_stderr:
+    """Route the process's fd 1 to fd 2 for a while: RCCL prints a banner from C on its first use, the reference's module
+    constructors print from Python -- and this script owes the driver exactly ONE line on stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def build_pipeline(res, valid, n_frames, device):
     from avatarcap_amd import config, synthetic as syn
     from avatarcap_amd.dataset import SyntheticTestDataset
@@ -121,7 +138,8 @@ def main():
     force_dist = os.environ.get('AVC_FORCE_DIST') == '1' and 'RANK' in os.environ    # exercise the RCCL path with a single rank
     if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        with _stdout_to_stderr():
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from avatarcap_amd import _lib
@@ -144,7 +162,9 @@ def main():
     for s in range(W):
         out = pipe.avatar_frame(my[s])
     if world > 1 or force_dist:   # warm the collective too
-        all_gather_meshes([{'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']}], world, force=force_dist)
+        with _stdout_to_stderr():
+            all_gather_meshes([{'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']}], world, force=force_dist)
+            torch.cuda.synchronize()
     barrier()
     _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
     t0 = time.perf_counter()
