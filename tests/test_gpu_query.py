@@ -170,3 +170,30 @@ def test_avatar_query_other_weights(seed, gain):
     print(f'seed {seed} gain {gain}: scale {scale:.1f}, err {err:.3e}, fp32-oracle slack {slack:.3e}')
     assert err < TOL + 2 * slack      # 1e-4, plus what the reference's own fp32 arithmetic loses on an ill-conditioned network (2.6e-3 at gain 2.2)
     assert maxabs(out['nonrigid_offset'][0].cpu().numpy(), ref64['nonrigid_offset']) < TOL
+
+
+def test_error_paths_of_the_side_entries():
+    """Bad arguments come back as AVC_ERR_ARG with a message (the reference would raise ValueError / shape errors)."""
+    from avatarcap_amd import _lib
+    from avatarcap_amd.utils.renderer import render_mesh_device
+    from avatarcap_amd.normal_fusion.normal_fusion import merge_normal_images_device
+    config.device = torch.device('cuda')
+    x = torch.randn(1, 48, 4, 4, device='cuda'); y = torch.empty_like(x)
+    h = _lib.ctx(x.device)
+    with pytest.raises(_lib.AvcapError, match='divisible'):
+        _lib.check(_lib.lib().avc_group_norm(h, x.data_ptr(), 1, 48, 16, 32, None, None, 1e-5, 1, y.data_ptr(), None))
+    v = torch.zeros(3, 3, device='cuda'); f = torch.zeros((1, 3), dtype=torch.int32, device='cuda')
+    with pytest.raises(_lib.AvcapError, match='image size'):
+        render_mesh_device(v, None, f, np.eye(4, dtype=np.float32), 20000, 4)
+    assert float(render_mesh_device(v, None, f[:0], np.eye(4, dtype=np.float32), 8, 8).abs().max()) == 0.0      # no faces: background
+    with pytest.raises(ValueError):
+        merge_normal_images_device(torch.zeros(8, 8, 3, device='cuda'), torch.zeros(8, 9, 3, device='cuda'), 2, (0, 0))
+    with pytest.raises(_lib.AvcapError, match='iter_num'):
+        merge_normal_images_device(torch.zeros(8, 8, 3, device='cuda'), torch.zeros(8, 8, 3, device='cuda'), -1, (0, 0))
+    out = torch.empty(0, 3, device='cuda')
+    _lib.check(_lib.lib().avc_canonicalize_normals(h, None, None, 0, None, None, 4, 4, _lib.f3(np.eye(4, dtype=np.float32).reshape(16)), 1.0, 1.0, 0.0, 0.0,
+                                                   None, None))                                                   # nv = 0 is a no-op
+    sing = np.zeros(16, np.float32)
+    with pytest.raises(_lib.AvcapError, match='singular'):
+        _lib.check(_lib.lib().avc_canonicalize_normals(h, v.data_ptr(), torch.zeros(3, 4, 4, device='cuda').data_ptr(), 3, torch.zeros(4, 4, 4, device='cuda').data_ptr(),
+                                                       torch.zeros(4, 4, 3, device='cuda').data_ptr(), 4, 4, _lib.f3(sing), 1.0, 1.0, 0.0, 0.0, torch.zeros(3, 3, device='cuda').data_ptr(), None))
