@@ -14,7 +14,8 @@
  *     four face values -- Lewiner's face test -- so neighbouring cells always agree and the
  *     surface is watertight;
  *   - NOT restated: Lewiner's interior (tunnel) tests and his hand-tuned tilings; each boundary
- *     loop of a cell is fan-triangulated instead.  The surface topology can therefore differ from
+ *     loop of a cell is triangulated without extra vertices instead, avoiding chords that lie inside a cube face
+ *     wherever the loop allows it (triangulate_loop).  The surface topology can therefore differ from
  *     scikit-image inside cells of cases 4/6/7/10/12/13, and triangle diagonals can differ anywhere.
  *   - degenerate triangles are kept (allow_degenerate=True is the library default).
  *
@@ -25,7 +26,7 @@
  * Canonical output order (shared with the HIP kernel, include/avcap.h):
  *   vertices: ascending (voxel linear index i = x*Y*Z + y*Z + z, then axis 0,1,2) of the owning
  *             edge (the edge from voxel i towards +axis);
- *   faces:    ascending cell linear index, then loop order (by smallest cube-edge id), then fan order.
+ *   faces:    ascending cell linear index, then loop order (by smallest cube-edge id), then triangulate_loop's order.
  *   winding:  right-hand normal points towards HIGHER values (the reference then flips,
  *             recon_util.py:69).
  *
@@ -52,6 +53,56 @@ static int edge_between(int a, int b)
     if (d == 1) return 0 + dy + 2 * dz;
     if (d == 2) return 4 + dx + 2 * dz;
     return 8 + dx + 2 * dy;
+}
+
+/* the two cube faces a cube edge lies on, as a 6-bit mask */
+static int edge_face_mask(int e)
+{
+    const int axis = e >> 2, j = e & 3;
+    const int a = axis == 0 ? 2 * (j & 1) + 4 * (j >> 1) : (axis == 1 ? (j & 1) + 4 * (j >> 1) : (j & 1) + 2 * (j >> 1));
+    const int b = a | (1 << axis);
+    int f, k, m = 0;
+    for (f = 0; f < 6; ++f) {
+        int ha = 0, hb = 0;
+        for (k = 0; k < 4; ++k) { ha |= FACE_CORNERS[f][k] == a; hb |= FACE_CORNERS[f][k] == b; }
+        if (ha && hb) m |= 1 << f;
+    }
+    return m;
+}
+
+/* Triangulate the polygon loop[0..n-1] without new vertices, with as few chords inside a cube face as possible (such a
+ * chord can coincide with one drawn by the neighbouring cell in the same face, which would make an edge shared by four
+ * triangles); ties -> the largest split index, i.e. a fan from loop[0] when nothing else matters. */
+static int tri_cost[12][12], tri_split[12][12];
+static int emit_tris(const int *loop, int i, int j, int *tri, int nt)
+{
+    int k;
+    if (j - i < 2) return nt;
+    k = tri_split[i][j];
+    nt = emit_tris(loop, i, k, tri, nt);
+    tri[3 * nt] = loop[i]; tri[3 * nt + 1] = loop[k]; tri[3 * nt + 2] = loop[j]; ++nt;
+    return emit_tris(loop, k, j, tri, nt);
+}
+static int triangulate_loop(const int *loop, int n, int *tri, int nt)
+{
+    int span, i, j, k, fm[12];
+    for (i = 0; i < n; ++i) fm[i] = edge_face_mask(loop[i]);
+    for (i = 0; i < n; ++i) for (j = 0; j < n; ++j) { tri_cost[i][j] = 0; tri_split[i][j] = -1; }
+    for (span = 2; span < n; ++span)
+        for (i = 0; i + span < n; ++i) {
+            int best = -1;
+            j = i + span;
+            for (k = j - 1; k > i; --k) {
+                /* a face is the + side of one cell and the - side of its neighbour: chords in + faces (mask 0x2a) cost 1000,
+                 * so the two cells can only ever draw the same chord when one of them has no other choice */
+                const int cik = (k - i != 1 && k - i != n - 1) ? (fm[i] & fm[k]) : 0, ckj = (j - k != 1 && j - k != n - 1) ? (fm[k] & fm[j]) : 0;
+                const int wik = !cik ? 0 : ((cik & 0x2a) ? 1000 : 1), wkj = !ckj ? 0 : ((ckj & 0x2a) ? 1000 : 1);
+                const int c = tri_cost[i][k] + tri_cost[k][j] + wik + wkj;
+                if (best < 0 || c < best) { best = c; tri_split[i][j] = k; }
+            }
+            tri_cost[i][j] = best;
+        }
+    return emit_tris(loop, 0, n - 1, tri, nt);
 }
 
 /* trace the oriented boundary loops of one cell.  val[c] = sample - iso.  Returns the number
@@ -94,7 +145,7 @@ static int cell_triangles(const float val[8], int tri[36])
             if (nxt[e] < 0 || visited[e]) continue;
             cur = e;
             do { loop[n++] = cur; visited[cur] = 1; cur = nxt[cur]; } while (cur != e && n < 12);
-            for (i = 1; i + 1 < n; ++i) { tri[3 * nt] = loop[0]; tri[3 * nt + 1] = loop[i]; tri[3 * nt + 2] = loop[i + 1]; ++nt; }
+            nt = triangulate_loop(loop, n, tri, nt);
         }
         return nt;
     }

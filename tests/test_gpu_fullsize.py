@@ -92,3 +92,52 @@ def test_lbs_at_full_vertex_count(frame, monkeypatch):
     same = smpl_util.skinning(v[None], lbs, eye)[0]
     assert float((same[near] - v[near]).abs().max()) < 2e-6
     assert torch.equal(out['live_v'], smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'])[0])
+
+
+def test_full_avatarcap_frame_at_256_band():
+    """BASELINE configs[2] at its full size: steps 1-3 chained on a band-masked 256^3 grid.  Sampled oracle parity of the
+    reconstruction decoder on the fused maps' image features, untouched fill values outside the band, a closed manifold mesh."""
+    from avatarcap_amd.dataset import SyntheticTestDataset, to_cuda, synthetic_camera, synthetic_observed_normals
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar
+    from avatarcap_amd.network.arch_recon import ReconNetwork
+    from avatarcap_amd.pipeline import FramePipeline
+    from common import recon_sd
+    from oracle import avatarcap_oracle as orc
+    config.cfg = config.default_cfg()
+    config.cfg['testing']['vol_res'] = RES
+    config.device = torch.device('cuda')
+    ds = SyntheticTestDataset(RES, valid='band', n_frames=1)
+    net = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume()).to('cuda').eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in geotex_sd().items()})
+    rn = ReconNetwork().to('cuda').eval()
+    rn.load_state_dict({k: torch.from_numpy(v) for k, v in recon_sd().items()})
+    pipe = FramePipeline(net, ds, rn)
+    items = to_cuda(ds[0], add_batch=True)
+    a = pipe.avatar_frame(items)
+    w2c, cam = synthetic_camera()
+    obs = synthetic_observed_normals(a['live_v'], a['live_vn'], a['f'], w2c, cam, seed=3)
+    items['front_normal'], items['back_normal'], _ = pipe.fuse_normals(a, obs, w2c, cam, 'merge', iter_num=100)
+    r = pipe.recon_frame(items)
+    vol = r['occ_volume']
+    flag = ds.infer_pts_flag
+    assert 0.1 < float(flag.float().mean()) < 0.3
+    assert torch.equal(vol[~flag], ds.invalid_pts_ov)                                 # main.py:443
+    with torch.no_grad():
+        imap = rn.get_feat_maps(torch.cat([items['front_normal'], items['back_normal']], 1))[-1][0].cpu().numpy()
+    rs = np.random.RandomState(2)
+    sel = np.sort(rs.choice(ds.infer_pts.shape[0], 1500, replace=False))
+    ref = orc.recon_infer(ds.infer_pts[torch.from_numpy(sel).cuda()].cpu().numpy(), imap, ds.cano_smpl_center, recon_sd())
+    assert maxabs(vol[flag][torch.from_numpy(sel).cuda()].cpu().numpy(), ref) < 1e-4
+    v, f = r['cano_v'], r['f'].long()
+    assert v.shape[0] > 10000
+    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    key = torch.minimum(e[:, 0], e[:, 1]) * v.shape[0] + torch.maximum(e[:, 0], e[:, 1])
+    uniq, cnt = torch.unique(key, return_counts=True)
+    hist = {int(c): int((cnt == c).sum()) for c in torch.unique(cnt)}
+    assert int(cnt.max()) == 2, hist                                                  # manifold: no edge shared by 3+ faces
+    b0, b1 = torch.from_numpy(ds.cano_bounds[0]).cuda(), torch.from_numpy(ds.cano_bounds[1]).cuda()
+    voxel = (b1 - b0) / 256
+    border = ((v - b0 < 1.01 * voxel) | (b1 - v < 1.01 * voxel)).any(1)
+    open_e = uniq[cnt == 1]
+    assert bool(border[open_e // v.shape[0]].all() and border[open_e % v.shape[0]].all()), hist   # open only where the body leaves the volume
+    assert r['live_v'].shape == v.shape and bool(torch.isfinite(r['live_v']).all())

@@ -78,6 +78,21 @@ def test_noise_is_watertight(seed):
     assert np.array_equal(v, v2) and np.array_equal(f, f2)                    # deterministic
 
 
+def test_edges_are_manifold():
+    """Loops are triangulated so that chords inside a cube face are avoided (a fan from a fixed vertex puts ~0.7 % of the
+    edges of a white-noise field on four triangles): a smooth field must give none, white noise at most a few per million
+    (the loops of 8, 9 and 12 vertices that cannot avoid such a chord, meeting a neighbour that draws the same one)."""
+    from scipy.ndimage import gaussian_filter
+    rs = np.random.RandomState(5)
+    noise = rs.randn(56, 56, 56).astype(np.float32)
+    for vol, allowed in ((noise, 2e-5), (gaussian_filter(noise, 0.7).astype(np.float32), 0.0)):
+        v, f = mc.marching_cubes(vol, 0.0, [1, 1, 1])
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        key = np.minimum(e[:, 0], e[:, 1]).astype(np.int64) * v.shape[0] + np.maximum(e[:, 0], e[:, 1])
+        cnt = np.unique(key, return_counts=True)[1]
+        assert cnt.max() <= 4 and (cnt > 2).sum() <= allowed * cnt.size, np.unique(cnt, return_counts=True)
+
+
 def test_vertex_is_linear_root_and_canonical_order():
     vol = np.random.RandomState(3).randn(6, 5, 7).astype(np.float32)
     iso = 0.2

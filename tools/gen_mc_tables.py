@@ -3,8 +3,10 @@
 
 Independent (Python) implementation of the cell rule that oracle/mc_oracle.c states in C:
 oriented boundary-loop tracing on the 6 cube faces, ambiguous faces resolved by a per-face
-"above corners connected" bit (the kernel evaluates the asymptotic decider at run time), loops
-fan-triangulated from their smallest cube-edge id.  tests/test_mc_tables.py checks the generated
+"above corners connected" bit (the kernel evaluates the asymptotic decider at run time), every loop
+triangulated without new vertices so that as few triangle edges as possible lie inside a cube face (such a chord can
+coincide with one the neighbouring cell draws in the same face -> an edge shared by four triangles); among the
+triangulations with the fewest such chords the one closest to a fan from the loop's smallest cube-edge id is taken.  tests/test_mc_tables.py checks the generated
 tables against the C oracle cell by cell, for all 256 configurations and all decider outcomes.
 
 Table layout (all uint32 words, copied into LDS by the kernel):
@@ -42,6 +44,52 @@ def ambiguous_faces(cfg):
     return [f for f in range(6) if face_state(cfg, f)[2] == 4]
 
 
+def edge_corners(e):
+    axis, j = divmod(e, 4)
+    a = (2 * (j & 1) + 4 * (j >> 1), (j & 1) + 4 * (j >> 1), (j & 1) + 2 * (j >> 1))[axis]
+    return a, a | (1 << axis)
+
+
+EDGE_FACES = [frozenset(f for f in range(6) if all(c in FACE_CORNERS[f] for c in edge_corners(e))) for e in range(12)]
+
+
+PLUS_FACE_COST = 1000
+
+
+def triangulate(loop):
+    """Triangles (index triples into `loop`) of the polygon 0..n-1: dynamic programme over (i, j) chains, cost = number of
+    chords whose two cube edges share a cube face; ties -> the largest split index (a fan from vertex 0 when nothing else matters)."""
+    n = len(loop)
+
+    def w(i, j):
+        common = EDGE_FACES[loop[i]] & EDGE_FACES[loop[j]] if (j - i) not in (1, n - 1) else ()
+        # a face is the + side of one cell and the - side of its neighbour: chords in + faces are (all but) forbidden, so the
+        # two cells can only ever draw the same chord when one of them has no other choice
+        return 0 if not common else (PLUS_FACE_COST if any(f & 1 for f in common) else 1)
+    cost = [[0] * n for _ in range(n)]
+    split = [[-1] * n for _ in range(n)]
+    for span in range(2, n):
+        for i in range(0, n - span):
+            j = i + span
+            best = None
+            for k in range(j - 1, i, -1):
+                c = cost[i][k] + cost[k][j] + w(i, k) + w(k, j)
+                if best is None or c < best:
+                    best, split[i][j] = c, k
+            cost[i][j] = best
+    out = []
+
+    def emit(i, j):
+        if j - i < 2:
+            return
+        k = split[i][j]
+        emit(i, k)
+        out.append((i, k, j))
+        emit(k, j)
+    emit(0, n - 1)
+    return out
+
+
 def triangles(cfg, connected_by_face):
     nxt = {}
     for f in range(6):
@@ -66,8 +114,8 @@ def triangles(cfg, connected_by_face):
                 loop.append(cur); seen.add(cur); cur = nxt[cur]
                 if cur == e:
                     break
-            for i in range(1, len(loop) - 1):
-                tris.append((loop[0], loop[i], loop[i + 1]))
+            for (a, b, c) in triangulate(loop):
+                tris.append((loop[a], loop[b], loop[c]))
     return tris
 
 
