@@ -148,8 +148,8 @@ int avc_render_mesh(avc_ctx *ctx, const float *verts_dev, const float *attrs_dev
                     int64_t nf, const float mvp[16], int width, int height, float *out_dev, avc_stream stream);
 
 /* ---- canonical normal fusion (normal_fusion/normal_fusion.py) ---------------------------------------------------------
- * Parity with the reference UNPINNED (it needs OpenCV, pytorch3d and OpenGL); oracle/normal_fusion_oracle.py is pinned
- * against torch.autograd.
+ * The oracle (oracle/normal_fusion_oracle.py) is pinned against a run of the reference's own module with stand-ins for its
+ * OpenCV / pytorch3d / OpenGL calls (tests/golden/make_golden_fusion.py) and against torch.autograd.
  *
  * canonicalize_normal_map's per-vertex part (:27-62): project each posed vertex with mv (row-major 4x4, world -> camera:
  * x right, y down, z forward) and the pinhole (fx, fy, cx, cy); sample the position map (the 'position' render of the

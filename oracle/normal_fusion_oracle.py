@@ -1,11 +1,13 @@
 """CPU restatement of the reference's canonical normal fusion (normal_fusion/normal_fusion.py) -- TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: the reference module imports OpenCV, pytorch3d and an OpenGL renderer, none of which exist in this
-image, and the reference holds no fixture for it; what is pinned is (i) the analytic gradients below against
-torch.autograd on a torch restatement of the same loss (tests/test_normal_fusion.py), (ii) the HIP kernels against
-this file.  Third-party algorithms restated here: pytorch3d.transforms.axis_angle_to_matrix (requirements.txt: pytorch3d,
-via axis_angle_to_quaternion + quaternion_to_matrix as published), cv2.erode with a 3x3 rectangle (border = +inf),
-cv2.distanceTransform(DIST_L1, 3) (exact city-block distance to the nearest zero pixel).
+PINNED against the reference's own code: tests/golden/make_golden_fusion.py runs /root/reference/normal_fusion/
+normal_fusion.py itself (its autograd + torch.optim.Adam loop, its resize / neighbour / blend / face-rectangle code, its
+per-vertex canonicalisation and render_cano_mesh's matrices) on the tests' synthetic inputs and stores the results in
+tests/golden/fusion_golden.npz; tests/test_normal_fusion.py holds this file to them.  Because OpenCV, pytorch3d and OpenGL
+do not exist offline, that run uses stand-ins for exactly those calls -- so what stays UNPINNED is: cv2.erode /
+cv2.distanceTransform (restated below from their definitions; checked against brute force), pytorch3d's
+axis_angle_to_matrix (restated as published: axis_angle_to_quaternion + quaternion_to_matrix), and the OpenGL
+rasterisation (oracle/raster_oracle.c).  The hand-written gradients are also checked against torch.autograd to 1e-12.
 Every function cites the reference line it follows.
 """
 import numpy as np
