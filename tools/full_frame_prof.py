@@ -9,6 +9,8 @@ from avatarcap_amd.dataset import SyntheticTestDataset, to_cuda, synthetic_camer
 from avatarcap_amd.network.arch_avatar import GeoTexAvatar
 from avatarcap_amd.network.arch_recon import ReconNetwork
 from avatarcap_amd.pipeline import FramePipeline
+import os
+if os.environ.get('CUDNN_BENCH'): torch.backends.cudnn.benchmark = True      # MIOpen exhaustive search instead of the immediate-mode pick
 dev = torch.device('cuda'); config.device = dev; config.cfg = config.default_cfg()
 net = GeoTexAvatar(base_weight_volume=np.zeros((2, 2, 2, 24), np.float32)).to(dev).eval(); syn.load_synth(net, syn.SEED)
 rn = ReconNetwork().to(dev).eval(); syn.load_synth(rn, syn.SEED)
