@@ -56,6 +56,30 @@ class FramePipeline:
         return res
 
     @torch.no_grad()
+    def avatar_frame_sharded(self, items: dict, group=None, skin=True):
+        """Latency mode (optional): ONE frame across the ranks of `group`.  Every rank evaluates the fused
+        query on its slab of the valid points, the occupancy slabs are all-gathered once (67 MB at 256^3), and every rank
+        extracts the same mesh.  The throughput path (frames sharded, parallel.shard_frames) is what bench.py measures."""
+        import torch.distributed as dist
+        from .parallel import shard_range, all_gather_slabs
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.network.warping_field.precompute_conv(items)
+        n = items['cano_pts'].shape[1]
+        lo, hi = shard_range(n, rank, world)
+        sub = dict(items); sub['cano_pts'] = items['cano_pts'][:, lo:hi].contiguous()
+        local = self.occ_net.query(sub)['cano_pts_ov'][0, :, 0] if hi > lo else torch.empty(0, device=items['cano_pts'].device)
+        values = all_gather_slabs(local, n, group)
+        vol = fill_volume(values, self.ds.valid_u8, self.ds.invalid_pts_ov)
+        v, f, nrm = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds, iso_value=config.iso_value)
+        res = {'cano_v': v, 'cano_vn': nrm, 'f': f, 'occ_volume': vol}
+        if skin and v.shape[0] > 0:
+            lbs = smpl_util.calculate_lbs(v[None])
+            live_v, mats = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'], True)
+            res.update({'live_v': live_v[0], 'live_vn': smpl_util.skinning_normal(nrm[None], lbs, items['cano2live_jnt_mats'])[0], 'vert_mats': mats[0]})
+        return res
+
+    @torch.no_grad()
     def recon_frame(self, items: dict):
         """3. reconstruction network (main.py:438-453); items must hold front_normal / back_normal."""
         out = self.recon_net.infer(items)                                    # :440

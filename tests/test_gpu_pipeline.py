@@ -226,3 +226,19 @@ def test_normal_fusion_step_in_the_frame_loop(pipe64):
     items['front_normal'], items['back_normal'] = front, back
     r = pipe64.recon_frame(items)
     assert r['cano_v'].shape[0] > 0
+
+
+def test_latency_mode_single_rank_equals_throughput_mode(pipe64):
+    """avatar_frame_sharded with one rank (no process group) must reproduce avatar_frame bit for bit; the multi-rank exchange
+    itself is covered by the gloo test of parallel.all_gather_slabs."""
+    from avatarcap_amd.dataset import to_cuda
+    items = to_cuda(pipe64.ds[0], add_batch=True)
+    a = pipe64.avatar_frame(items)
+    wf = pipe64.network.warping_field
+    keep = wf.precompute_conv
+    wf.precompute_conv = lambda batch: None          # reuse the cached pose feature map (MIOpen's U-Net is not bitwise repeatable)
+    try:
+        b = pipe64.avatar_frame_sharded(items)
+    finally:
+        wf.precompute_conv = keep
+    assert torch.equal(a['occ_volume'], b['occ_volume']) and torch.equal(a['f'], b['f']) and torch.equal(a['live_v'], b['live_v'])

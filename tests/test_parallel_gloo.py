@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from avatarcap_amd.parallel import all_gather_meshes, shard_frames
+from avatarcap_amd.parallel import all_gather_meshes, all_gather_slabs, shard_frames, shard_range
 
 
 def _mesh(frame):
@@ -64,3 +64,39 @@ def test_all_gather_meshes_world2(n_frames):
 def test_all_gather_single_process_is_identity():
     m = [_mesh(0), _mesh(1)]
     assert all_gather_meshes(m, 2) is not m and len(all_gather_meshes(m, 2)) == 2
+
+
+def _slab_worker(rank, world, port, n, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        full = torch.arange(n, dtype=torch.float32) * 0.5 - 3
+        lo, hi = shard_range(n, rank, world)
+        got = all_gather_slabs(full[lo:hi].clone(), n)
+        q.put((rank, bool(torch.equal(got, full))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range():
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert [shard_range(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    assert shard_range(16777216, 7, 8) == (14680064, 16777216)
+    assert torch.equal(all_gather_slabs(torch.arange(5.), 5), torch.arange(5.))          # no process group: identity
+
+
+@pytest.mark.parametrize('n', [1001, 3])
+def test_all_gather_slabs_world2(n):
+    """Latency mode's one exchange: the occupancy slabs of a frame split over the ranks come back as the whole volume."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slab_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
