@@ -122,3 +122,22 @@ def test_G13_geotex_forward_posed(golden, body):
     assert maxabs(raw, golden['G13_raw']) < 2e-4
     assert maxabs(occ, golden['G13_occ']) < 2e-4
     assert maxabs(off, golden['G13_off']) < 1e-4
+
+
+def test_torch_cpu_restatement_matches_numpy_oracle():
+    """oracle/torch_cpu.py (what bench.py's cpu_baseline times) against the NumPy oracle on the golden inputs."""
+    import torch
+    from oracle import avatarcap_oracle as orc, torch_cpu
+    from common import geotex_sd
+    sd = geotex_sd()
+    tsd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items() if v.dtype == np.float32}
+    pts, fmap, c = gi.query_points(104, 1500), gi.pose_feat_map(), gi.center()
+    ref = orc.occupancy_query(pts, fmap, c, sd)
+    for if_type in ('sdf', 'occupancy'):
+        occ, off = torch_cpu.occupancy_query(torch.from_numpy(pts), torch.from_numpy(fmap), torch.from_numpy(c), tsd, if_type, chunk=700)
+        want = ref['cano_pts_ov'] if if_type == 'sdf' else 1 / (1 + np.exp(-ref['cano_pts_ov']))
+        assert np.abs(occ.numpy() - want).max() < 2e-5 and np.abs(off.numpy() - ref['nonrigid_offset']).max() < 1e-5
+    body = syn.synthetic_body()
+    vp = gi.surface_points(105, 500, body)
+    lbs = torch_cpu.calculate_lbs(torch.from_numpy(vp), torch.from_numpy(body['cano_smpl_v']), torch.from_numpy(body['skin_weights']))
+    assert np.abs(lbs.numpy() - orc.calculate_lbs(vp, body['cano_smpl_v'], body['skin_weights'])).max() < 1e-6
