@@ -62,6 +62,7 @@ struct avc_ctx {
     float *img_feat_hwc = nullptr;  int img_C = 0, img_H = 0, img_W = 0;
     // scratch for meshing
     void *mc_scratch = nullptr; size_t mc_scratch_bytes = 0;
+    void *mc_cells = nullptr; size_t mc_cells_bytes = 0;           // one record per crossed cell (mesh.hip)
     uint32_t *mc_tables_dev = nullptr;
     void *raster_scratch = nullptr; size_t raster_scratch_bytes = 0;
     void *fusion_scratch = nullptr; size_t fusion_scratch_bytes = 0;   // normal-fusion work buffers

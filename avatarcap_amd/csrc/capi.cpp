@@ -41,6 +41,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->pose_feat_hwc) hipFree(ctx->pose_feat_hwc);
     if (ctx->img_feat_hwc) hipFree(ctx->img_feat_hwc);
     if (ctx->mc_scratch) hipFree(ctx->mc_scratch);
+    if (ctx->mc_cells) hipFree(ctx->mc_cells);
     if (ctx->mc_tables_dev) hipFree(ctx->mc_tables_dev);
     if (ctx->raster_scratch) hipFree(ctx->raster_scratch);
     if (ctx->knn_scratch) hipFree(ctx->knn_scratch);

@@ -1,19 +1,30 @@
 // Device-resident replacement of utils/recon_util.py:51-70 (recon_mesh):
-//   marching cubes (the reference's skimage call, :64)  +  vertex offset/scale (:62,65)
+//   marching cubes (the reference's skimage.measure.marching_cubes call, :64)  +  vertex offset/scale (:62,65)
 //   + Sobel-gradient normals sampled trilinearly at the vertices (:9-48, :66-68) + face flip (:69)
-// with the occupancy volume never leaving HBM (the reference copies it to the host, runs
-// single-thread Cython, and copies the vertices back).
+// with the occupancy volume never leaving HBM (the reference copies it to the host, runs single-thread
+// Cython, and copies the vertices back).
 //
-// Algorithm = oracle/mc_oracle.c (PARITY UNPINNED against scikit-image):
-//   pass A  count   : per 1024-voxel tile, #owned cut edges (vertices) and #triangles   -> tile sums
-//   scan            : exclusive scan of the tile sums (one workgroup)
-//   pass B  vertices: recount, in-tile scan, emit position + normal; record the first vertex id
-//                     of every voxel that owns one (sparse writes into a 4 B / voxel array)
-//   pass C  faces   : recount, in-tile scan, emit triangles; a triangle corner on cube edge e is
-//                     vertex  first_id[owner voxel] + rank of e's axis among the owner's cut edges
-// Output order is canonical and deterministic: vertices by (voxel index, axis), faces by cell index.
-// HBM-bound: the volume is read once per pass (3 x 4 B/voxel; passes B/C mostly hit the 256 MiB
-// Infinity Cache at 256^3) plus 24 B/vertex + 12 B/face of output.  Case tables live in LDS.
+// Marching cubes = scikit-image's Lewiner implementation (method='lewiner', the library default), restated:
+// 15 base cases, face tests, interior tests, sub-case tilings with the optional centre vertex, the library's
+// 1/(eps+|v|) edge interpolation in double, AND the library's output order, so that vertices, faces and their
+// numbering are identical to what the reference's call returns (oracle/mc_oracle.c is the sequential
+// restatement, pinned against the real library: tests/golden/mc_golden.npz).
+//
+// The library is sequential: cells in (axis0, axis1, axis2) order, a vertex is appended the first time a
+// triangle refers to its grid edge.  Parallel form of the same order:
+//   * every cut edge of a cell appears in the cell's tiling, so the vertex of a grid edge is created by the
+//     FIRST cell in traversal order among the (up to 4) cells around it -- a function of the cell's position
+//     only (creator_mask);  inside a cell new vertices are numbered by first appearance in its triangle list;
+//   pass A  count  : per 1024-point tile: #vertices created, #triangles, #crossed cells        -> tile sums
+//   scan           : exclusive scan of the tile sums (one workgroup), totals to the host
+//   pass B  verts  : per non-empty tile: resolve the cells again, in-tile scan, number the new vertices, record
+//                    their ids in the edge map (3 ints per grid point, sparsely written), write one 16-byte
+//                    record per crossed cell {cell, table row, first face, centre-vertex id}; then the whole
+//                    workgroup evaluates positions + normals, one vertex per thread
+//   pass C  faces  : one thread per crossed cell: ids from the edge map -> triangles
+// HBM-bound: the volume is read twice (passes A, B; B skips empty tiles) + 24 B/vertex + 12 B/face written.
+// The 18 KB of look-up tables live in LDS.  Face / interior tests and the interpolation run in fp64 exactly as
+// the library's C code does (translation unit built with -ffp-contract=off).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -23,107 +34,219 @@
 namespace avc {
 namespace {
 
-constexpr int TILE = 1024;          // voxels per tile: 256 threads x 4 consecutive voxels
-constexpr int TABLE_WORDS = 512 + mc::N_ROWS * 4;
+constexpr int TILE = 1024;          // grid points per tile: 256 threads x 4 consecutive points
+constexpr double LIB_EPS = 2.220446049250313e-16;   // the library's "FLT_EPSILON" = numpy.spacing(1.0)
 
 struct McArgs {
     const float *vol;
-    int X, Y, Z;
+    int n0, n1, n2;                 // volume shape (axis 0 slowest); the library calls the axes z, y, x
     int64_t N;
-    float iso;
+    float iso_f;
+    double iso;
     int ntiles;
-    const uint32_t *tables;         // CFG_INFO then ROWS, device copy
+    const uint32_t *tables;         // mc::BLOB, device copy
 };
 
 __device__ __forceinline__ void load_tables(const uint32_t *__restrict__ g, uint32_t *lds)
 {
-    for (int i = threadIdx.x; i < TABLE_WORDS; i += blockDim.x) lds[i] = g[i];
+    for (int i = threadIdx.x; i < mc::BLOB_WORDS; i += blockDim.x) lds[i] = g[i];
     __syncthreads();
 }
-
-// cube-edge e -> owner voxel offset (dx,dy,dz) and axis
-__device__ __forceinline__ void edge_owner(int e, int &dx, int &dy, int &dz, int &axis)
+__device__ __forceinline__ int tab_i8(const uint32_t *lds, int byte_off) { return (int)reinterpret_cast<const int8_t *>(lds)[byte_off]; }
+__device__ __forceinline__ int tab_u8(const uint32_t *lds, int byte_off) { return (int)reinterpret_cast<const uint8_t *>(lds)[byte_off]; }
+__device__ __forceinline__ int row_ntri(const uint32_t *lds, int row) { return tab_u8(lds, mc::OFF_ROWS + row * mc::ROW_BYTES); }
+__device__ __forceinline__ unsigned row_mask(const uint32_t *lds, int row)
 {
-    axis = e >> 2;
-    const int j = e & 3;
-    if (axis == 0) { dx = 0; dy = j & 1; dz = j >> 1; }
-    else if (axis == 1) { dx = j & 1; dy = 0; dz = j >> 1; }
-    else { dx = j & 1; dy = j >> 1; dz = 0; }
+    return (unsigned)tab_u8(lds, mc::OFF_ROWS + row * mc::ROW_BYTES + 1) | ((unsigned)tab_u8(lds, mc::OFF_ROWS + row * mc::ROW_BYTES + 2) << 8);
+}
+__device__ __forceinline__ int row_edge(const uint32_t *lds, int row, int k)   // k-th edge id of the row's triangle list
+{
+    return (tab_u8(lds, mc::OFF_ROWS + row * mc::ROW_BYTES + 4 + (k >> 1)) >> (4 * (k & 1))) & 0xf;
 }
 
-struct Voxel {
-    int x, y, z;
-    float v0;              // vol - iso at the voxel
-    float v[3];            // vol - iso at the +x, +y, +z neighbours (0 when absent)
-    unsigned cut;          // bit a: the edge towards +axis a exists and changes sign
-    int nv;
+// ---- the library's tests, in double (oracle/mc_oracle.c test_face / test_internal) ----
+__device__ __forceinline__ double sel8(const double *v, int i)
+{
+    double r = v[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) r = (i == c) ? v[c] : r;
+    return r;
+}
+
+__device__ bool test_face(const double *v, int face)
+{
+    const int af = face < 0 ? -face : face;
+    // corners A B C D of faces 1..6, 3 bits each
+    const unsigned FC[6] = {0u | 4u << 3 | 5u << 6 | 1u << 9, 1u | 5u << 3 | 6u << 6 | 2u << 9, 2u | 6u << 3 | 7u << 6 | 3u << 9,
+                            3u | 7u << 3 | 4u << 6 | 0u << 9, 0u | 3u << 3 | 2u << 6 | 1u << 9, 4u | 7u << 3 | 6u << 6 | 5u << 9};
+    const unsigned pc = FC[af - 1];
+    const double A = sel8(v, pc & 7), B = sel8(v, (pc >> 3) & 7), C = sel8(v, (pc >> 6) & 7), D = sel8(v, (pc >> 9) & 7);
+    const double acbd = A * C - B * D;
+    if (acbd > -LIB_EPS && acbd < LIB_EPS) return face >= 0;
+    return (double)face * A * acbd >= 0;
+}
+
+__device__ bool test_internal(const double *v, int kase, int edge, int s)
+{
+    double t, At = 0, Bt = 0, Ct = 0, Dt = 0;
+    if (kase == 4 || kase == 10) {
+        const double a = (v[4] - v[0]) * (v[6] - v[2]) - (v[7] - v[3]) * (v[5] - v[1]);
+        const double b = v[2] * (v[4] - v[0]) + v[0] * (v[6] - v[2]) - v[1] * (v[7] - v[3]) - v[3] * (v[5] - v[1]);
+        t = -b / (2 * a + LIB_EPS);
+        if (t < 0 || t > 1) return s > 0;
+        At = v[0] + (v[4] - v[0]) * t;
+        Bt = v[3] + (v[7] - v[3]) * t;
+        Ct = v[2] + (v[6] - v[2]) * t;
+        Dt = v[1] + (v[5] - v[1]) * t;
+    } else {
+        // reference edge -> corner indices {p, q, b0, b1, c0, c1, d0, d1}, 3 bits each
+        const unsigned TI[12] = {
+            0u | 1u << 3 | 3u << 6 | 2u << 9 | 7u << 12 | 6u << 15 | 4u << 18 | 5u << 21, 1u | 2u << 3 | 0u << 6 | 3u << 9 | 4u << 12 | 7u << 15 | 5u << 18 | 6u << 21,
+            2u | 3u << 3 | 1u << 6 | 0u << 9 | 5u << 12 | 4u << 15 | 6u << 18 | 7u << 21, 3u | 0u << 3 | 2u << 6 | 1u << 9 | 6u << 12 | 5u << 15 | 7u << 18 | 4u << 21,
+            4u | 5u << 3 | 7u << 6 | 6u << 9 | 3u << 12 | 2u << 15 | 0u << 18 | 1u << 21, 5u | 6u << 3 | 4u << 6 | 7u << 9 | 0u << 12 | 3u << 15 | 1u << 18 | 2u << 21,
+            6u | 7u << 3 | 5u << 6 | 4u << 9 | 1u << 12 | 0u << 15 | 2u << 18 | 3u << 21, 7u | 4u << 3 | 6u << 6 | 5u << 9 | 2u << 12 | 1u << 15 | 3u << 18 | 0u << 21,
+            0u | 4u << 3 | 3u << 6 | 7u << 9 | 2u << 12 | 6u << 15 | 1u << 18 | 5u << 21, 1u | 5u << 3 | 0u << 6 | 4u << 9 | 3u << 12 | 7u << 15 | 2u << 18 | 6u << 21,
+            2u | 6u << 3 | 1u << 6 | 5u << 9 | 0u << 12 | 4u << 15 | 3u << 18 | 7u << 21, 3u | 7u << 3 | 2u << 6 | 6u << 9 | 1u << 12 | 5u << 15 | 0u << 18 | 4u << 21};
+        if (edge >= 0 && edge < 12) {
+            const unsigned q = TI[edge];
+            const double vp = sel8(v, q & 7), vq = sel8(v, (q >> 3) & 7);
+            t = vp / (vp - vq + LIB_EPS);
+            const double b0 = sel8(v, (q >> 6) & 7), b1 = sel8(v, (q >> 9) & 7), c0 = sel8(v, (q >> 12) & 7), c1 = sel8(v, (q >> 15) & 7);
+            const double d0 = sel8(v, (q >> 18) & 7), d1 = sel8(v, (q >> 21) & 7);
+            Bt = b0 + (b1 - b0) * t; Ct = c0 + (c1 - c0) * t; Dt = d0 + (d1 - d0) * t;
+        }
+    }
+    const int test = (At >= 0 ? 1 : 0) + (Bt >= 0 ? 2 : 0) + (Ct >= 0 ? 4 : 0) + (Dt >= 0 ? 8 : 0);
+    switch (test) {
+    case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 12: return s > 0;
+    // the library's if-chain returns 0 when the inner condition of 5 / 10 fails (Lewiner's original falls through to s < 0)
+    case 5: return (At * Ct - Bt * Dt < LIB_EPS) ? s > 0 : false;
+    case 10: return (At * Ct - Bt * Dt >= LIB_EPS) ? s > 0 : false;
+    default: return s < 0;      // 7, 11, 13, 14, 15
+    }
+}
+
+// the big switch: cube index -> row of the tiling table (oracle/mc_oracle.c resolve); -1 = nothing to add
+__device__ int resolve_row(const float *val, const McArgs &a, int idx, const uint32_t *lds)
+{
+    const int kase = tab_u8(lds, mc::OFF_CASES + 2 * idx), cf = tab_i8(lds, mc::OFF_CASES + 2 * idx + 1);
+    switch (kase) {         // cases without tests need no arithmetic at all
+    case 1: return mc::ROW_TILING1 + cf;
+    case 2: return mc::ROW_TILING2 + cf;
+    case 5: return mc::ROW_TILING5 + cf;
+    case 8: return mc::ROW_TILING8 + cf;
+    case 9: return mc::ROW_TILING9 + cf;
+    case 11: return mc::ROW_TILING11 + cf;
+    case 14: return mc::ROW_TILING14 + cf;
+    default: break;
+    }
+    double v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = (double)val[c] - a.iso;
+    int sub = 0;
+    switch (kase) {
+    case 3:
+        return test_face(v, tab_i8(lds, mc::OFF_TEST3 + cf)) ? mc::ROW_TILING3_2 + cf : mc::ROW_TILING3_1 + cf;
+    case 4:
+        return test_internal(v, 4, -1, tab_i8(lds, mc::OFF_TEST4 + cf)) ? mc::ROW_TILING4_1 + cf : mc::ROW_TILING4_2 + cf;
+    case 6:
+        if (test_face(v, tab_i8(lds, mc::OFF_TEST6 + 3 * cf))) return mc::ROW_TILING6_2 + cf;
+        return test_internal(v, 6, tab_i8(lds, mc::OFF_TEST6 + 3 * cf + 2), tab_i8(lds, mc::OFF_TEST6 + 3 * cf + 1)) ? mc::ROW_TILING6_1_1 + cf
+                                                                                                                       : mc::ROW_TILING6_1_2 + cf;
+    case 7:
+        for (int k = 0; k < 3; ++k) if (test_face(v, tab_i8(lds, mc::OFF_TEST7 + 5 * cf + k))) sub |= 1 << k;
+        switch (sub) {
+        case 0: return mc::ROW_TILING7_1 + cf;
+        case 1: return mc::ROW_TILING7_2 + 3 * cf + 0;
+        case 2: return mc::ROW_TILING7_2 + 3 * cf + 1;
+        case 3: return mc::ROW_TILING7_3 + 3 * cf + 0;
+        case 4: return mc::ROW_TILING7_2 + 3 * cf + 2;
+        case 5: return mc::ROW_TILING7_3 + 3 * cf + 1;
+        case 6: return mc::ROW_TILING7_3 + 3 * cf + 2;
+        default:
+            return test_internal(v, 7, tab_i8(lds, mc::OFF_TEST7 + 5 * cf + 4), tab_i8(lds, mc::OFF_TEST7 + 5 * cf + 3)) ? mc::ROW_TILING7_4_2 + cf
+                                                                                                                           : mc::ROW_TILING7_4_1 + cf;
+        }
+    case 10:
+    case 12: {
+        const bool is10 = kase == 10;
+        const int toff = is10 ? mc::OFF_TEST10 + 3 * cf : mc::OFF_TEST12 + 4 * cf;
+        const bool f0 = test_face(v, tab_i8(lds, toff)), f1 = test_face(v, tab_i8(lds, toff + 1));
+        if (f0 && f1) return (is10 ? mc::ROW_TILING10_1_1_ : mc::ROW_TILING12_1_1_) + cf;
+        if (f0) return (is10 ? mc::ROW_TILING10_2 : mc::ROW_TILING12_2) + cf;
+        if (f1) return (is10 ? mc::ROW_TILING10_2_ : mc::ROW_TILING12_2_) + cf;
+        const bool in = test_internal(v, kase, is10 ? -1 : tab_i8(lds, toff + 3), tab_i8(lds, toff + 2));
+        if (in) return (is10 ? mc::ROW_TILING10_1_1 : mc::ROW_TILING12_1_1) + cf;
+        return (is10 ? mc::ROW_TILING10_1_2 : mc::ROW_TILING12_1_2) + cf;
+    }
+    case 13: {
+        for (int k = 0; k < 6; ++k) if (test_face(v, tab_i8(lds, mc::OFF_TEST13 + 7 * cf + k))) sub |= 1 << k;
+        const int sc = tab_i8(lds, mc::OFF_SUBCONFIG13 + sub);
+        if (sc == 0) return mc::ROW_TILING13_1 + cf;
+        if (sc >= 1 && sc <= 6) return mc::ROW_TILING13_2 + 6 * cf + sc - 1;
+        if (sc >= 7 && sc <= 18) return mc::ROW_TILING13_3 + 12 * cf + sc - 7;
+        if (sc >= 19 && sc <= 22) return mc::ROW_TILING13_4 + 4 * cf + sc - 19;
+        if (sc >= 23 && sc <= 26) {
+            const int r51 = mc::ROW_TILING13_5_1 + 4 * cf + sc - 23;
+            return test_internal(v, 13, row_edge(lds, r51, 0), tab_i8(lds, mc::OFF_TEST13 + 7 * cf + 6)) ? r51 : mc::ROW_TILING13_5_2 + 4 * cf + sc - 23;
+        }
+        if (sc >= 27 && sc <= 38) return mc::ROW_TILING13_3_ + 12 * cf + sc - 27;
+        if (sc >= 39 && sc <= 44) return mc::ROW_TILING13_2_ + 6 * cf + sc - 39;
+        if (sc == 45) return mc::ROW_TILING13_1_ + cf;
+        return -1;      // combination of face tests the tables mark impossible: the library adds nothing
+    }
+    default: return -1;
+    }
+}
+
+struct Cell {
+    int z, y, x;           // library naming: z = axis 0, x = axis 2
+    int row;               // tiling row, -1 = not crossed (or not a cell)
+    float val[8];
 };
 
-__device__ __forceinline__ Voxel load_voxel(const McArgs &a, int64_t li)
+// which of the cell's 13 possible vertices it is the FIRST cell (in traversal order) to refer to: edges 5, 6, 10 and the centre
+// always; the others only when the earlier neighbours that share them do not exist (see the header)
+__device__ __forceinline__ unsigned creator_mask(int z, int y, int x)
 {
-    Voxel q;
-    const int yz = a.Y * a.Z;
-    q.x = (int)(li / yz);
-    const int r = (int)(li - (int64_t)q.x * yz);
-    q.y = r / a.Z;
-    q.z = r - q.y * a.Z;
-    q.v0 = a.vol[li] - a.iso;
-    const bool s0 = q.v0 > 0.0f;
-    q.cut = 0;
-    q.v[0] = q.v[1] = q.v[2] = 0.0f;
-    if (q.x + 1 < a.X) { q.v[0] = a.vol[li + yz] - a.iso; if ((q.v[0] > 0.0f) != s0) q.cut |= 1u; }
-    if (q.y + 1 < a.Y) { q.v[1] = a.vol[li + a.Z] - a.iso; if ((q.v[1] > 0.0f) != s0) q.cut |= 2u; }
-    if (q.z + 1 < a.Z) { q.v[2] = a.vol[li + 1] - a.iso; if ((q.v[2] > 0.0f) != s0) q.cut |= 4u; }
-    q.nv = __popc(q.cut);
-    return q;
+    unsigned m = (1u << 5) | (1u << 6) | (1u << 10) | (1u << 12);
+    if (z == 0) m |= (1u << 1) | (1u << 2);
+    if (y == 0) m |= (1u << 4) | (1u << 9);
+    if (x == 0) m |= (1u << 7) | (1u << 11);
+    if (y == 0 && z == 0) m |= 1u << 0;
+    if (x == 0 && z == 0) m |= 1u << 3;
+    if (x == 0 && y == 0) m |= 1u << 8;
+    return m;
 }
 
-// table row of the cell whose min corner is voxel q (caller guarantees the cell exists); returns
-// the row index or -1 when the cell is not crossed.  val[] receives the 8 corner values - iso.
-__device__ __forceinline__ int cell_row(const McArgs &a, const Voxel &q, int64_t li, const uint32_t *lds, float val[8])
+__device__ __forceinline__ void load_cell(const McArgs &a, int64_t li, const uint32_t *lds, Cell &c)
 {
-    const int yz = a.Y * a.Z;
-    val[0] = q.v0; val[1] = q.v[0]; val[2] = q.v[1]; val[4] = q.v[2];
-    val[3] = a.vol[li + yz + a.Z] - a.iso;
-    val[5] = a.vol[li + yz + 1] - a.iso;
-    val[6] = a.vol[li + a.Z + 1] - a.iso;
-    val[7] = a.vol[li + yz + a.Z + 1] - a.iso;
-    unsigned cfg = 0;
+    const int yx = a.n1 * a.n2;
+    c.z = (int)(li / yx);
+    const int r = (int)(li - (int64_t)c.z * yx);
+    c.y = r / a.n2;
+    c.x = r - c.y * a.n2;
+    c.row = -1;
+    if (c.z + 1 >= a.n0 || c.y + 1 >= a.n1 || c.x + 1 >= a.n2) return;
+    const float *p = a.vol + li;
+    c.val[0] = p[0]; c.val[1] = p[1]; c.val[2] = p[a.n2 + 1]; c.val[3] = p[a.n2];
+    c.val[4] = p[yx]; c.val[5] = p[yx + 1]; c.val[6] = p[yx + a.n2 + 1]; c.val[7] = p[yx + a.n2];
+    unsigned idx = 0;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) cfg |= (val[c] > 0.0f ? 1u : 0u) << c;
-    if (cfg == 0u || cfg == 255u) return -1;
-    const uint32_t i0 = lds[2 * cfg], faces = lds[2 * cfg + 1];
-    const int namb = (i0 >> 16) & 7;
-    unsigned variant = 0;
-    for (int i = 0; i < namb; ++i) {
-        const int f = (faces >> (3 * i)) & 7;
-        // face corners counter-clockwise seen from outside (oracle/mc_oracle.c FACE_CORNERS), packed 3 bits each
-        const unsigned FC[6] = {0 | 4 << 3 | 6 << 6 | 2 << 9, 1 | 3 << 3 | 7 << 6 | 5 << 9, 0 | 1 << 3 | 5 << 6 | 4 << 9,
-                                2 | 6 << 3 | 7 << 6 | 3 << 9, 0 | 2 << 3 | 3 << 6 | 1 << 9, 4 | 5 << 3 | 7 << 6 | 6 << 9};
-        const unsigned pc = FC[f];
-        float fv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = (pc >> (3 * k)) & 7;
-            float t = val[0];
-#pragma unroll
-            for (int cc = 1; cc < 8; ++cc) t = (c == cc) ? val[cc] : t;
-            fv[k] = t;
-        }
-        // asymptotic decider with separately rounded products (matches the oracle's -ffp-contract=off)
-        const float pp = __fmul_rn(fv[0], fv[2]), qq = __fmul_rn(fv[1], fv[3]);
-        const bool connected = (fv[0] > 0.0f) ? (pp > qq) : (qq > pp);
-        variant |= (connected ? 1u : 0u) << i;
-    }
-    return (int)(i0 & 0xffffu) + (int)variant;
+    for (int k = 0; k < 8; ++k) idx |= (c.val[k] > a.iso_f ? 1u : 0u) << k;     // == ((double)val - iso > 0), the library's test
+    if (idx == 0u || idx == 255u) return;
+    c.row = resolve_row(c.val, a, (int)idx, lds);
 }
 
-__device__ __forceinline__ int row_ntri(const uint32_t *lds, int row) { return (int)(lds[512 + 4 * row] & 0xffu); }
-__device__ __forceinline__ int row_edge(const uint32_t *lds, int row, int k)   // k-th nibble (0..29)
+// cube edge e -> base grid point offset (dx, dy, dz) and axis (0 = x, 1 = y, 2 = z), packed 5 bits per edge
+__device__ __forceinline__ void edge_base(int e, int &dx, int &dy, int &dz, int &axis)
 {
-    const int byte = 1 + (k >> 1);
-    const uint32_t w = lds[512 + 4 * row + (byte >> 2)];
-    return (int)((w >> (8 * (byte & 3) + 4 * (k & 1))) & 0xfu);
+    //            e:  0  1  2  3  4  5  6  7  8  9 10 11      bits: dx | dy<<1 | dz<<2 | axis<<3
+    const unsigned long long T = 0ull | (1ull | 1ull << 3) << 5 | (2ull) << 10 | (0ull | 1ull << 3) << 15 | (4ull) << 20 | (5ull | 1ull << 3) << 25 |
+                                 (6ull) << 30 | (4ull | 1ull << 3) << 35 | (0ull | 2ull << 3) << 40 | (1ull | 2ull << 3) << 45 | (3ull | 2ull << 3) << 50 |
+                                 (2ull | 2ull << 3) << 55;
+    const unsigned q = (unsigned)(T >> (5 * e)) & 31u;
+    dx = q & 1; dy = (q >> 1) & 1; dz = (q >> 2) & 1; axis = q >> 3;
 }
 
 // exclusive prefix sum of one value per thread across a 256-thread block; returns the block total in `total`
@@ -143,59 +266,63 @@ __device__ __forceinline__ unsigned block_exclusive(unsigned v, unsigned *lds4, 
 }
 
 // ---------------- pass A ----------------
-__global__ __launch_bounds__(256) void mc_count_kernel(McArgs a, unsigned *__restrict__ tile_v, unsigned *__restrict__ tile_t)
+__global__ __launch_bounds__(256) void mc_count_kernel(McArgs a, unsigned *__restrict__ tile_v, unsigned *__restrict__ tile_t, unsigned *__restrict__ tile_c)
 {
-    __shared__ uint32_t tab[TABLE_WORDS];
-    __shared__ unsigned red[8];
+    __shared__ uint32_t tab[mc::BLOB_WORDS];
+    __shared__ unsigned red[12];
     load_tables(a.tables, tab);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        unsigned nv = 0, nt = 0;
-#pragma unroll
+        unsigned nv = 0, nt = 0, nc = 0;
+#pragma unroll 1
         for (int k = 0; k < 4; ++k) {
             const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
-            if (li < a.N) {
-                const Voxel q = load_voxel(a, li);
-                nv += q.nv;
-                if (q.x + 1 < a.X && q.y + 1 < a.Y && q.z + 1 < a.Z) {
-                    float val[8];
-                    const int row = cell_row(a, q, li, tab, val);
-                    if (row >= 0) nt += row_ntri(tab, row);
-                }
+            if (li >= a.N) break;
+            Cell c;
+            load_cell(a, li, tab, c);
+            if (c.row >= 0) {
+                nt += row_ntri(tab, c.row);
+                nv += __popc(row_mask(tab, c.row) & creator_mask(c.z, c.y, c.x));
+                nc += 1;
             }
         }
-        for (int o = 32; o > 0; o >>= 1) { nv += __shfl_down(nv, o, 64); nt += __shfl_down(nt, o, 64); }
+        for (int o = 32; o > 0; o >>= 1) { nv += __shfl_down(nv, o, 64); nt += __shfl_down(nt, o, 64); nc += __shfl_down(nc, o, 64); }
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = nv; red[4 + (threadIdx.x >> 6)] = nt; }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = nv; red[4 + (threadIdx.x >> 6)] = nt; red[8 + (threadIdx.x >> 6)] = nc; }
         __syncthreads();
-        if (threadIdx.x == 0) { tile_v[tile] = red[0] + red[1] + red[2] + red[3]; tile_t[tile] = red[4] + red[5] + red[6] + red[7]; }
+        if (threadIdx.x == 0) {
+            tile_v[tile] = red[0] + red[1] + red[2] + red[3];
+            tile_t[tile] = red[4] + red[5] + red[6] + red[7];
+            tile_c[tile] = red[8] + red[9] + red[10] + red[11];
+        }
     }
 }
 
-// exclusive scan of two arrays (one workgroup of 1024); totals written to totals[0..1]
-__global__ void mc_scan_kernel(unsigned *__restrict__ tv, unsigned *__restrict__ tt, int n, unsigned long long *__restrict__ totals)
+// exclusive scan of three arrays (one workgroup of 1024); totals written to totals[0..2]
+__global__ void mc_scan_kernel(unsigned *__restrict__ t0, unsigned *__restrict__ t1, unsigned *__restrict__ t2, int n, unsigned long long *__restrict__ totals)
 {
-    __shared__ unsigned buf[2][1024];
-    __shared__ unsigned carry[2];
-    if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+    __shared__ unsigned buf[3][1024];
+    __shared__ unsigned carry[3];
+    unsigned *arr[3] = {t0, t1, t2};
+    if (threadIdx.x < 3) carry[threadIdx.x] = 0;
     __syncthreads();
     for (int b0 = 0; b0 < n; b0 += 1024) {
         const int i = b0 + threadIdx.x;
-        const unsigned v0 = i < n ? tv[i] : 0u, v1 = i < n ? tt[i] : 0u;
-        buf[0][threadIdx.x] = v0; buf[1][threadIdx.x] = v1;
+        unsigned v[3];
+        for (int q = 0; q < 3; ++q) { v[q] = i < n ? arr[q][i] : 0u; buf[q][threadIdx.x] = v[q]; }
         __syncthreads();
         for (int o = 1; o < 1024; o <<= 1) {
-            const unsigned a0 = threadIdx.x >= o ? buf[0][threadIdx.x - o] : 0u;
-            const unsigned a1 = threadIdx.x >= o ? buf[1][threadIdx.x - o] : 0u;
+            unsigned add[3];
+            for (int q = 0; q < 3; ++q) add[q] = threadIdx.x >= o ? buf[q][threadIdx.x - o] : 0u;
             __syncthreads();
-            buf[0][threadIdx.x] += a0; buf[1][threadIdx.x] += a1;
+            for (int q = 0; q < 3; ++q) buf[q][threadIdx.x] += add[q];
             __syncthreads();
         }
-        if (i < n) { tv[i] = carry[0] + buf[0][threadIdx.x] - v0; tt[i] = carry[1] + buf[1][threadIdx.x] - v1; }
+        if (i < n) for (int q = 0; q < 3; ++q) arr[q][i] = carry[q] + buf[q][threadIdx.x] - v[q];
         __syncthreads();
-        if (threadIdx.x == 1023) { carry[0] += buf[0][1023]; carry[1] += buf[1][1023]; }
+        if (threadIdx.x == 1023) for (int q = 0; q < 3; ++q) carry[q] += buf[q][1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { totals[0] = carry[0]; totals[1] = carry[1]; }
+    if (threadIdx.x < 3) totals[threadIdx.x] = carry[threadIdx.x];
 }
 
 // ---------------- pass B: vertices + normals ----------------
@@ -236,7 +363,7 @@ __device__ __forceinline__ void axis_weights(float pix, int n, int &ibase, float
 __device__ __forceinline__ void vertex_normal(const McArgs &a, const EmitArgs &e, const float vidx[3], float nrm[3])
 {
     // reference arithmetic, in its order (recon_util.py:65-66, F.grid_sample unnormalise)
-    const int dim[3] = {a.X, a.Y, a.Z};
+    const int dim[3] = {a.n0, a.n1, a.n2};
     int ib[3];
     float wS[3][4], wD[3][4];
 #pragma unroll
@@ -248,19 +375,19 @@ __device__ __forceinline__ void vertex_normal(const McArgs &a, const EmitArgs &e
         axis_weights(pix, dim[c], ib[c], wS[c], wD[c]);
     }
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    const int yz = a.Y * a.Z;
+    const int yz = a.n1 * a.n2;
     for (int i = 0; i < 4; ++i) {
         const int xi = ib[0] + i;
-        if (xi < 0 || xi >= a.X) continue;
+        if (xi < 0 || xi >= a.n0) continue;
         for (int j = 0; j < 4; ++j) {
             const int yj = ib[1] + j;
-            if (yj < 0 || yj >= a.Y) continue;
+            if (yj < 0 || yj >= a.n1) continue;
             float sS = 0.f, sD = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int zk = ib[2] + k;
-                if (zk < 0 || zk >= a.Z) continue;
-                const float val = a.vol[(int64_t)xi * yz + yj * a.Z + zk];
+                if (zk < 0 || zk >= a.n2) continue;
+                const float val = a.vol[(int64_t)xi * yz + yj * a.n2 + zk];
                 sS += val * wS[2][k];
                 sD += val * wD[2][k];
             }
@@ -274,55 +401,123 @@ __device__ __forceinline__ void vertex_normal(const McArgs &a, const EmitArgs &e
     nrm[0] = -(gx / nn); nrm[1] = -(gy / nn); nrm[2] = -(gz / nn);                // :68
 }
 
-// Owners only describe their vertices (voxel, axis, interpolation parameter) in LDS, in output order; then the
-// whole workgroup shares the position / normal evaluation, one vertex per thread per round: the 64-tap normal
-// stencil is by far the most expensive part, and vertices cluster in few voxels of a tile.
-__global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, const unsigned *__restrict__ tile_voff,
-                                                       unsigned *__restrict__ first_id, float *__restrict__ verts, float *__restrict__ normals)
+
+// The library's vertex of cube edge e (or the centre, e == 12) of cell (z, y, x), in index units (axis0, axis1, axis2),
+// computed in double and rounded to float exactly as its C code does.
+__device__ __forceinline__ void vertex_position(const McArgs &a, int z, int y, int x, int e, float vidx[3])
 {
+    const int yx = a.n1 * a.n2;
+    const float *p = a.vol + ((int64_t)z * yx + (int64_t)y * a.n2 + x);
+    if (e < 12) {
+        int dx, dy, dz, axis;
+        edge_base(e, dx, dy, dz, axis);
+        const float *q = p + dz * yx + dy * a.n2 + dx;
+        const int step = axis == 0 ? 1 : (axis == 1 ? a.n2 : yx);
+        const double w_lo = 1.0 / (LIB_EPS + fabs((double)q[0] - a.iso));
+        const double w_hi = 1.0 / (LIB_EPS + fabs((double)q[step] - a.iso));
+        const double t = w_hi / (w_lo + w_hi);
+        const int bz = z + dz, by = y + dy, bx = x + dx;
+        vidx[0] = axis == 2 ? (float)((double)bz + t) : (float)bz;
+        vidx[1] = axis == 1 ? (float)((double)by + t) : (float)by;
+        vidx[2] = axis == 0 ? (float)((double)bx + t) : (float)bx;
+    } else {
+        double w[8];
+        w[0] = 1.0 / (LIB_EPS + fabs((double)p[0] - a.iso));
+        w[1] = 1.0 / (LIB_EPS + fabs((double)p[1] - a.iso));
+        w[2] = 1.0 / (LIB_EPS + fabs((double)p[a.n2 + 1] - a.iso));
+        w[3] = 1.0 / (LIB_EPS + fabs((double)p[a.n2] - a.iso));
+        w[4] = 1.0 / (LIB_EPS + fabs((double)p[yx] - a.iso));
+        w[5] = 1.0 / (LIB_EPS + fabs((double)p[yx + 1] - a.iso));
+        w[6] = 1.0 / (LIB_EPS + fabs((double)p[yx + a.n2 + 1] - a.iso));
+        w[7] = 1.0 / (LIB_EPS + fabs((double)p[yx + a.n2] - a.iso));
+        const double fx = ((w[1] + w[2]) + w[5]) + w[6];
+        const double fy = ((w[2] + w[3]) + w[6]) + w[7];
+        const double fz = ((w[4] + w[5]) + w[6]) + w[7];
+        const double ff = ((((((w[0] + w[1]) + w[2]) + w[3]) + w[4]) + w[5]) + w[6]) + w[7];
+        vidx[0] = (float)((double)z + fz / ff);
+        vidx[1] = (float)((double)y + fy / ff);
+        vidx[2] = (float)((double)x + fx / ff);
+    }
+}
+
+struct CellRec { uint32_t li, row, face0; int32_t cvid; };     // one per crossed cell, in traversal order
+
+// Creators only describe their vertices (cell, edge) in LDS, in output order; then the whole workgroup shares the
+// position / normal evaluation, one vertex per thread per round: the 64-tap normal stencil is by far the most
+// expensive part, and vertices cluster in few cells of a tile.
+__global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, const unsigned *__restrict__ tile_voff, const unsigned *__restrict__ tile_toff,
+                                                       const unsigned *__restrict__ tile_coff, unsigned total_v, unsigned total_t,
+                                                       int32_t *__restrict__ edge_map, CellRec *__restrict__ cells,
+                                                       float *__restrict__ verts, float *__restrict__ normals)
+{
+    __shared__ uint32_t tab[mc::BLOB_WORDS];
     __shared__ unsigned red[4];
-    __shared__ unsigned v_li[3 * TILE];      // voxel of the vertex (tile-local index) | axis << 16
-    __shared__ float v_t[3 * TILE];          // (iso - v0) / (v1 - v0)
+    __shared__ uint16_t desc[13 * TILE];     // (tile-local cell << 4) | edge id, in output order
+    load_tables(a.tables, tab);
+    const int yx = a.n1 * a.n2;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        Voxel q[4];
-        unsigned nv = 0;
-#pragma unroll
+        const unsigned vbase = tile_voff[tile], tbase = tile_toff[tile], cbase = tile_coff[tile];
+        const unsigned vnext = tile + 1 < a.ntiles ? tile_voff[tile + 1] : total_v;
+        const unsigned tnext = tile + 1 < a.ntiles ? tile_toff[tile + 1] : total_t;
+        if (vnext == vbase && tnext == tbase) continue;          // nothing crosses this tile (block-uniform)
+        int rows[4];
+        int cz[4], cy[4], cx[4];
+        unsigned nv = 0, nt = 0, nc = 0;
+#pragma unroll 1
         for (int k = 0; k < 4; ++k) {
+            rows[k] = -1;
             const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
-            if (li < a.N) { q[k] = load_voxel(a, li); nv += q[k].nv; } else { q[k].nv = 0; q[k].cut = 0; }
-        }
-        unsigned total;
-        const unsigned base = tile_voff[tile];
-        unsigned loc = block_exclusive(nv, red, total);
-        if (total == 0) continue;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (q[k].nv == 0) continue;
-            first_id[(int64_t)tile * TILE + threadIdx.x * 4 + k] = base + loc;
-            for (int ax = 0; ax < 3; ++ax) {
-                if (!(q[k].cut & (1u << ax))) continue;
-                v_li[loc] = (unsigned)(threadIdx.x * 4 + k) | ((unsigned)ax << 16);
-                v_t[loc] = __fdiv_rn(__fsub_rn(0.0f, q[k].v0), __fsub_rn(q[k].v[ax], q[k].v0));   // (iso - v0)/(v1 - v0)
-                ++loc;
+            if (li >= a.N) continue;
+            Cell c;
+            load_cell(a, li, tab, c);
+            rows[k] = c.row; cz[k] = c.z; cy[k] = c.y; cx[k] = c.x;
+            if (c.row >= 0) {
+                nt += row_ntri(tab, c.row);
+                nv += __popc(row_mask(tab, c.row) & creator_mask(c.z, c.y, c.x));
+                nc += 1;
             }
+        }
+        unsigned total, tt, tc;
+        unsigned loc = block_exclusive(nv, red, total);
+        unsigned floc = tbase + block_exclusive(nt, red, tt);
+        unsigned cloc = cbase + block_exclusive(nc, red, tc);
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            if (rows[k] < 0) continue;
+            const int row = rows[k], n = 3 * row_ntri(tab, row);
+            const unsigned creator = creator_mask(cz[k], cy[k], cx[k]);
+            const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
+            unsigned seen = 0;
+            int32_t cvid = -1;
+            for (int i = 0; i < n; ++i) {
+                const int ed = row_edge(tab, row, i);
+                if (seen & (1u << ed)) continue;
+                seen |= 1u << ed;
+                if (!(creator & (1u << ed))) continue;
+                const int32_t id = (int32_t)(vbase + loc);
+                desc[loc] = (uint16_t)(((threadIdx.x * 4 + k) << 4) | ed);
+                ++loc;
+                if (ed == 12) { cvid = id; continue; }
+                int dx, dy, dz, axis;
+                edge_base(ed, dx, dy, dz, axis);
+                edge_map[3 * (li + (int64_t)dz * yx + dy * a.n2 + dx) + axis] = id;
+            }
+            CellRec r;
+            r.li = (uint32_t)li; r.row = (uint32_t)row; r.face0 = floc; r.cvid = cvid;
+            cells[cloc] = r;
+            floc += n / 3; ++cloc;
         }
         __syncthreads();
         for (unsigned j = threadIdx.x; j < total; j += 256) {
-            const unsigned d = v_li[j];
-            const int ax = (int)(d >> 16);
-            const int64_t li = (int64_t)tile * TILE + (d & 0xffffu);
-            const int yz = a.Y * a.Z;
-            const int px = (int)(li / yz), rem = (int)(li - (int64_t)px * yz);
-            const int p[3] = {px, rem / a.Z, rem % a.Z};
-            const float t = v_t[j];
+            const unsigned d = desc[j];
+            const int64_t li = (int64_t)tile * TILE + (d >> 4);
+            const int z = (int)(li / yx), rem = (int)(li - (int64_t)z * yx);
             float vidx[3], out[3];
+            vertex_position(a, z, rem / a.n2, rem % a.n2, (int)(d & 15u), vidx);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                vidx[c] = __fadd_rn((float)p[c], c == ax ? t : 0.0f);
-                // vertices = mc * voxel + b0 + 0.5 * voxel   (recon_util.py:64-65)
+            for (int c = 0; c < 3; ++c)     // vertices = mc * voxel + b0 + 0.5 * voxel   (library: * spacing; recon_util.py:65), float32
                 out[c] = __fadd_rn(__fadd_rn(__fmul_rn(vidx[c], e.vox[c]), e.b0[c]), __fmul_rn(0.5f, e.vox[c]));
-            }
-            const size_t id = (size_t)base + j;
+            const size_t id = (size_t)vbase + j;
             verts[3 * id + 0] = out[0]; verts[3 * id + 1] = out[1]; verts[3 * id + 2] = out[2];
             if (normals) {
                 float n[3];
@@ -335,66 +530,27 @@ __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, con
 }
 
 // ---------------- pass C: faces ----------------
-__device__ __forceinline__ unsigned owner_cut_mask(const McArgs &a, int x, int y, int z)
+__global__ __launch_bounds__(256) void mc_faces_kernel(McArgs a, const CellRec *__restrict__ cells, unsigned ncells,
+                                                       const int32_t *__restrict__ edge_map, int32_t *__restrict__ faces)
 {
-    const int yz = a.Y * a.Z;
-    const int64_t li = (int64_t)x * yz + y * a.Z + z;
-    const bool s0 = (a.vol[li] - a.iso) > 0.0f;
-    unsigned cut = 0;
-    if (x + 1 < a.X && ((a.vol[li + yz] - a.iso) > 0.0f) != s0) cut |= 1u;
-    if (y + 1 < a.Y && ((a.vol[li + a.Z] - a.iso) > 0.0f) != s0) cut |= 2u;
-    if (z + 1 < a.Z && ((a.vol[li + 1] - a.iso) > 0.0f) != s0) cut |= 4u;
-    return cut;
-}
-
-__global__ __launch_bounds__(256) void mc_faces_kernel(McArgs a, const unsigned *__restrict__ tile_toff,
-                                                       const unsigned *__restrict__ first_id, int32_t *__restrict__ faces)
-{
-    __shared__ uint32_t tab[TABLE_WORDS];
-    __shared__ unsigned red[4];
+    __shared__ uint32_t tab[mc::BLOB_WORDS];
     load_tables(a.tables, tab);
-    const int yz = a.Y * a.Z;
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        int rows[4];
-        unsigned nt = 0;
-        int cx[4], cy[4], cz[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            rows[k] = -1;
-            const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
-            if (li < a.N) {
-                const Voxel q = load_voxel(a, li);
-                cx[k] = q.x; cy[k] = q.y; cz[k] = q.z;
-                if (q.x + 1 < a.X && q.y + 1 < a.Y && q.z + 1 < a.Z) {
-                    float val[8];
-                    rows[k] = cell_row(a, q, li, tab, val);
-                    if (rows[k] >= 0) nt += row_ntri(tab, rows[k]);
-                }
+    const int yx = a.n1 * a.n2;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < ncells; i += gridDim.x * 256u) {
+        const CellRec r = cells[i];
+        const int n = 3 * row_ntri(tab, (int)r.row);
+        int32_t *out = faces + 3 * (size_t)r.face0;
+        // the library emits (a, b, c), its wrapper flips for gradient_direction='descent', the reference flips back
+        // (recon_util.py:69: faces[:, [2, 1, 0]]) => the tiling order itself
+        for (int k = 0; k < n; ++k) {
+            const int ed = row_edge(tab, (int)r.row, k);
+            int32_t id = r.cvid;
+            if (ed != 12) {
+                int dx, dy, dz, axis;
+                edge_base(ed, dx, dy, dz, axis);
+                id = edge_map[3 * ((int64_t)r.li + (int64_t)dz * yx + dy * a.n2 + dx) + axis];
             }
-        }
-        unsigned total;
-        unsigned fo = tile_toff[tile] + block_exclusive(nt, red, total);
-        if (total == 0) continue;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (rows[k] < 0) continue;
-            const int n = row_ntri(tab, rows[k]);
-            // vertex id of each of the 12 cube edges, resolved lazily
-            for (int t = 0; t < n; ++t) {
-                int32_t id[3];
-                for (int c = 0; c < 3; ++c) {
-                    const int e = row_edge(tab, rows[k], 3 * t + c);
-                    int dx, dy, dz, axis;
-                    edge_owner(e, dx, dy, dz, axis);
-                    const int ox = cx[k] + dx, oy = cy[k] + dy, oz = cz[k] + dz;
-                    const unsigned cut = owner_cut_mask(a, ox, oy, oz);
-                    const unsigned rank = __popc(cut & ((1u << axis) - 1u));
-                    id[c] = (int32_t)(first_id[(int64_t)ox * yz + oy * a.Z + oz] + rank);
-                }
-                // faces = faces[:, [2, 1, 0]]   (recon_util.py:69)
-                faces[3 * (size_t)fo + 0] = id[2]; faces[3 * (size_t)fo + 1] = id[1]; faces[3 * (size_t)fo + 2] = id[0];
-                ++fo;
-            }
+            out[k] = id;
         }
     }
 }
@@ -405,22 +561,19 @@ int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float
                float *verts, float *normals, int32_t *faces, int64_t cap_v, int64_t cap_f, int64_t counts[2], hipStream_t s)
 {
     McArgs a{};
-    a.vol = vol; a.X = res[0]; a.Y = res[1]; a.Z = res[2];
-    a.N = (int64_t)a.X * a.Y * a.Z; a.iso = iso;
+    a.vol = vol; a.n0 = res[0]; a.n1 = res[1]; a.n2 = res[2];
+    a.N = (int64_t)a.n0 * a.n1 * a.n2; a.iso_f = iso; a.iso = (double)iso;
     a.ntiles = (int)((a.N + TILE - 1) / TILE);
     if (!ctx->mc_tables_dev) {
-        std::vector<uint32_t> host(TABLE_WORDS);
-        for (int i = 0; i < 256; ++i) { host[2 * i] = mc::CFG_INFO[i][0]; host[2 * i + 1] = mc::CFG_INFO[i][1]; }
-        for (int r = 0; r < mc::N_ROWS; ++r) for (int w = 0; w < 4; ++w) host[512 + 4 * r + w] = mc::ROWS[r][w];
-        AVC_HIP(hipMalloc((void **)&ctx->mc_tables_dev, sizeof(uint32_t) * TABLE_WORDS));
-        AVC_HIP(hipMemcpy(ctx->mc_tables_dev, host.data(), sizeof(uint32_t) * TABLE_WORDS, hipMemcpyHostToDevice));
+        AVC_HIP(hipMalloc((void **)&ctx->mc_tables_dev, sizeof(mc::BLOB)));
+        AVC_HIP(hipMemcpy(ctx->mc_tables_dev, mc::BLOB, sizeof(mc::BLOB), hipMemcpyHostToDevice));
     }
     a.tables = ctx->mc_tables_dev;
-    // scratch: tile_v[ntiles], tile_t[ntiles], totals[2] (u64), first_id[N]
-    const size_t off_tt = sizeof(unsigned) * (size_t)a.ntiles;
-    const size_t off_tot = (2 * off_tt + 15) & ~(size_t)15;
-    const size_t off_first = off_tot + 16;
-    const size_t need = off_first + sizeof(unsigned) * (size_t)a.N;
+    // scratch: 3 x tile sums [ntiles], totals[3] (u64), edge map 3 x int32 per grid point (sparsely written, never cleared)
+    const size_t off_t = sizeof(unsigned) * (size_t)a.ntiles;
+    const size_t off_tot = (3 * off_t + 15) & ~(size_t)15;
+    const size_t off_map = off_tot + 32;
+    const size_t need = off_map + sizeof(int32_t) * 3 * (size_t)a.N;
     if (need > ctx->mc_scratch_bytes) {
         if (ctx->mc_scratch) AVC_HIP(hipFree(ctx->mc_scratch));
         ctx->mc_scratch = nullptr; ctx->mc_scratch_bytes = 0;
@@ -428,30 +581,43 @@ int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float
         ctx->mc_scratch_bytes = need;
     }
     char *base = (char *)ctx->mc_scratch;
-    unsigned *tile_v = (unsigned *)base, *tile_t = (unsigned *)(base + off_tt);
+    unsigned *tile_v = (unsigned *)base, *tile_t = (unsigned *)(base + off_t), *tile_c = (unsigned *)(base + 2 * off_t);
     unsigned long long *totals = (unsigned long long *)(base + off_tot);
-    unsigned *first_id = (unsigned *)(base + off_first);
+    int32_t *edge_map = (int32_t *)(base + off_map);
 
     const int grid = std::min(a.ntiles, ctx->num_cus * 8);
-    hipLaunchKernelGGL(mc_count_kernel, dim3(grid), dim3(256), 0, s, a, tile_v, tile_t);
-    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, tile_v, tile_t, a.ntiles, totals);
-    unsigned long long h_tot[2];
+    hipLaunchKernelGGL(mc_count_kernel, dim3(grid), dim3(256), 0, s, a, tile_v, tile_t, tile_c);
+    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, tile_v, tile_t, tile_c, a.ntiles, totals);
+    unsigned long long h_tot[3];
     AVC_HIP(hipMemcpyAsync(h_tot, totals, sizeof h_tot, hipMemcpyDeviceToHost, s));
     AVC_HIP(hipStreamSynchronize(s));
     counts[0] = (int64_t)h_tot[0]; counts[1] = (int64_t)h_tot[1];
     AVC_REQUIRE(counts[0] <= cap_v && counts[1] <= cap_f, AVC_ERR_CAPACITY,
                 "avc_recon_mesh: need capacity for %lld vertices / %lld faces, got %lld / %lld",
                 (long long)counts[0], (long long)counts[1], (long long)cap_v, (long long)cap_f);
-    if (counts[0] == 0) return AVC_OK;
+    if (counts[1] == 0) return AVC_OK;
+    AVC_REQUIRE(counts[0] < ((int64_t)1 << 31) && counts[1] < ((int64_t)1 << 31), AVC_ERR_ARG, "avc_recon_mesh: mesh too large for 32-bit indices");
     AVC_REQUIRE(verts && faces, AVC_ERR_ARG, "avc_recon_mesh: verts/faces output is NULL");
+    const size_t cell_bytes = sizeof(CellRec) * (size_t)h_tot[2];
+    if (cell_bytes > ctx->mc_cells_bytes) {
+        if (ctx->mc_cells) AVC_HIP(hipFree(ctx->mc_cells));
+        ctx->mc_cells = nullptr; ctx->mc_cells_bytes = 0;
+        const size_t want = cell_bytes + cell_bytes / 4 + 4096;
+        AVC_HIP(hipMalloc(&ctx->mc_cells, want));
+        ctx->mc_cells_bytes = want;
+    }
+    CellRec *cells = (CellRec *)ctx->mc_cells;
     EmitArgs e{};
     for (int c = 0; c < 3; ++c) {
         e.b0[c] = bounds[c];
         e.len[c] = bounds[3 + c] - bounds[c];
         e.vox[c] = e.len[c] / (float)res[c];
     }
-    hipLaunchKernelGGL(mc_verts_kernel, dim3(grid), dim3(256), 0, s, a, e, tile_v, first_id, verts, normals);
-    hipLaunchKernelGGL(mc_faces_kernel, dim3(grid), dim3(256), 0, s, a, tile_t, first_id, faces);
+    hipLaunchKernelGGL(mc_verts_kernel, dim3(grid), dim3(256), 0, s, a, e, tile_v, tile_t, tile_c, (unsigned)h_tot[0], (unsigned)h_tot[1],
+                       edge_map, cells, verts, normals);
+    const unsigned ncells = (unsigned)h_tot[2];
+    const int fgrid = (int)std::min<unsigned>((ncells + 255u) / 256u, (unsigned)ctx->num_cus * 8u);
+    hipLaunchKernelGGL(mc_faces_kernel, dim3(fgrid), dim3(256), 0, s, a, cells, ncells, edge_map, faces);
     AVC_HIP(hipGetLastError());
     return AVC_OK;
 }

@@ -1,8 +1,9 @@
 """Host-side mirror of the reference's `utils/recon_util.py` on libavcap_hip.so.
 
-`recon_mesh` keeps the reference signature and host-numpy return (recon_util.py:51-70);
-`recon_mesh_device` is the same computation returning device tensors (no host round trip), which
-is what the frame loop uses.  Marching-cubes parity vs scikit-image is UNPINNED.
+`recon_mesh` keeps the reference signature, host-numpy return and error behaviour (recon_util.py:51-70: the exceptions of
+`skimage.measure.marching_cubes` propagate); `recon_mesh_device` is the same computation returning device tensors (no host
+round trip), which is what the frame loop uses.  The marching cubes is scikit-image's Lewiner algorithm restated on the device:
+vertices, faces and their numbering are those of the library call.
 """
 from __future__ import annotations
 
@@ -49,4 +50,10 @@ def recon_mesh(occ_volume, volume_res, bounds, iso_value=0.5):
     """Reference signature (recon_util.py:51): occ_volume torch.Tensor (device), volume_res list,
     bounds numpy (2,3) -> vertices ndarray (V,3) f32, faces ndarray (F,3) i32, normals ndarray (V,3) f32."""
     v, f, n = recon_mesh_device(occ_volume, volume_res, bounds, iso_value)
+    if v.shape[0] == 0:
+        # what the library raises at recon_util.py:64 (messages: tests/golden/mc_golden.npz err_*)
+        lo, hi = float(occ_volume.min()), float(occ_volume.max())
+        if float(iso_value) < lo or float(iso_value) > hi:
+            raise ValueError('Surface level must be within volume data range.')
+        raise RuntimeError('No surface found at the given iso value.')
     return v.cpu().numpy(), f.cpu().numpy(), n.cpu().numpy()

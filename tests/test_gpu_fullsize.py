@@ -53,7 +53,8 @@ def test_mesh_topology_at_full_size(frame):
     v, f, n, vol = out['cano_v'], out['f'].long(), out['cano_vn'], out['occ_volume'].reshape(RES)
     inside = vol > config.iso_value
     crossings = sum(int((inside.narrow(a, 0, 255) != inside.narrow(a, 1, 255)).sum()) for a in range(3))
-    assert v.shape[0] == crossings                                                    # one vertex per sign-changing grid edge
+    # one vertex per sign-changing grid edge + the centre vertices of the few cells whose Lewiner tiling needs one
+    assert crossings <= v.shape[0] <= crossings + max(64, crossings // 1000), (v.shape[0], crossings)
     assert int(f.min()) == 0 and int(f.max()) == v.shape[0] - 1
     assert bool((f[:, 0] != f[:, 1]).all() and (f[:, 1] != f[:, 2]).all() and (f[:, 0] != f[:, 2]).all())
     e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])

@@ -1,7 +1,9 @@
 """GPU parity of marching cubes + normals (csrc/mesh.hip) and KNN / LBS / skinning (csrc/knn_lbs.hip)
 through the C-ABI against the CPU oracle and the reference goldens.
-Marching-cubes connectivity is compared with oracle/mc_oracle.c (bit-exact faces); parity with
-scikit-image itself is UNPINNED."""
+Marching cubes: vertices, faces and their numbering are compared bit for bit with oracle/mc_oracle.c AND directly with
+outputs of the real scikit-image call (tests/golden/mc_golden.npz)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -37,25 +39,59 @@ def _fields(res, kind, seed=0):
 
 
 @pytest.mark.parametrize('res,kind,iso', [((24, 24, 24), 'sphere', 0.0), ((40, 33, 17), 'torus', 0.0), ((19, 23, 31), 'noise', 0.1),
-                                          ((64, 64, 64), 'blobs', 0.0), ((33, 9, 130), 'noise', 0.5), ((2, 2, 2), 'noise', 0.0)])
+                                          ((64, 64, 64), 'blobs', 0.0), ((33, 9, 130), 'noise', 0.5), ((2, 2, 2), 'noise', 0.0),
+                                          ((48, 40, 56), 'noise', 0.0), ((21, 20, 19), 'ints', 0.0), ((3, 70, 1100), 'noise', 0.0)])
 def test_recon_mesh_matches_oracle(res, kind, iso):
+    """bit-exact: vertex positions (float32), faces, vertex numbering, face order"""
     from avatarcap_amd.utils import recon_util
     from oracle import avatarcap_oracle as orc
-    vol = _fields(res, kind, seed=sum(res))
+    if kind == 'ints':      # ties of the face / interior tests, values equal to iso
+        vol = np.random.RandomState(sum(res)).randint(-2, 3, res).astype(np.float32)
+    else:
+        vol = _fields(res, kind, seed=sum(res))
     v, f, n = recon_util.recon_mesh(_t(vol), list(res), syn.CANO_BOUNDS, iso_value=iso)
     ov, of, on = orc.recon_mesh(vol, list(res), syn.CANO_BOUNDS, iso)
     assert v.dtype == np.float32 and f.dtype == np.int32 and n.dtype == np.float32
     assert f.shape == of.shape and np.array_equal(f, of), 'triangle connectivity differs from the oracle'
-    assert v.shape == ov.shape and maxabs(v, ov) <= 1e-6
-    if kind != 'noise':          # gradients of white noise are ill-conditioned under normalisation
+    assert v.shape == ov.shape and np.array_equal(v, ov)
+    if kind not in ('noise', 'ints'):          # gradients of white noise are ill-conditioned under normalisation
         assert maxabs(n, on) < 1e-4
+
+
+_MC_GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mc_golden.npz'))
+
+
+@pytest.mark.parametrize('k', range(len(_MC_GOLD['names'])), ids=lambda k: f"{k}-{_MC_GOLD['names'][k]}")
+def test_recon_mesh_matches_scikit_image(k):
+    """The device marching cubes against the REAL library (goldens of tests/golden/make_golden_mc.py): identical faces and
+    vertex numbering; positions = library vertices + b0 + voxel/2 in float32 (recon_util.py:64-65) to the last bit."""
+    from avatarcap_amd.utils import recon_util
+    vol, iso, sp = _MC_GOLD[f'vol_{k}'], float(_MC_GOLD[f'iso_{k}']), _MC_GOLD[f'spacing_{k}']
+    res = list(vol.shape)
+    unit = bool(np.all(sp == 1))
+    b0 = np.zeros(3, np.float32) if unit else np.float32([-0.3, 0.1, 0.7])      # unit spacing: (b1 - b0) / res == spacing exactly
+    bounds = np.stack([b0, b0 + sp * np.float32(res)]).astype(np.float32)
+    voxel = ((bounds[1] - bounds[0]) / np.array(res, np.float32)).astype(np.float32)    # recon_util.py:61-62
+    v, f, n = recon_util.recon_mesh(_t(vol), res, bounds, iso_value=iso)
+    assert np.array_equal(f, _MC_GOLD[f'faces_{k}'][:, [2, 1, 0]])                       # :69
+    if unit:
+        assert np.array_equal(voxel, sp)
+        assert np.array_equal(v, _MC_GOLD[f'verts_{k}'] + bounds[0] + np.float32(0.5) * voxel)   # :65, float32 like the reference
+    else:       # the golden's spacing and (b1 - b0) / res differ in the last bit: compare in index units
+        gi_ = _MC_GOLD[f'verts_{k}'].astype(np.float64) / sp
+        vi = (v.astype(np.float64) - bounds[0] - 0.5 * voxel.astype(np.float64)) / voxel
+        assert v.shape == gi_.shape and maxabs(vi, gi_) < 2e-5 * max(res)
 
 
 def test_recon_mesh_empty_and_capacity():
     from avatarcap_amd.utils import recon_util
     vol = np.full((8, 8, 8), -1.0, np.float32)
-    v, f, n = recon_util.recon_mesh(_t(vol), [8, 8, 8], syn.CANO_BOUNDS, 0.0)
+    v, f, n = recon_util.recon_mesh_device(_t(vol), [8, 8, 8], syn.CANO_BOUNDS, 0.0)
     assert v.shape == (0, 3) and f.shape == (0, 3) and n.shape == (0, 3)
+    with pytest.raises(ValueError, match='Surface level must be within volume data range'):      # the library's errors (recon_util.py:64)
+        recon_util.recon_mesh(_t(vol), [8, 8, 8], syn.CANO_BOUNDS, 0.0)
+    with pytest.raises(RuntimeError, match='No surface found'):
+        recon_util.recon_mesh(_t(vol), [8, 8, 8], syn.CANO_BOUNDS, -1.0)
     recon_util._cap.clear(); recon_util._cap[torch.cuda.current_device()] = (16, 16)   # force the grow-and-retry path
     big = _fields((48, 48, 48), 'sphere')
     v, f, n = recon_util.recon_mesh(_t(big), [48, 48, 48], syn.CANO_BOUNDS, 0.0)
