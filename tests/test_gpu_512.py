@@ -1,0 +1,129 @@
+"""BASELINE configs[3] -- 512^3 dense grid + colour MLP + marching cubes on one MI355X -- through the C-ABI:
+sampled oracle parity of the occupancy field and of the colour head (rgba) at this size, the full-size mesh against the
+C oracle BIT FOR BIT (8 M vertices, 17 M faces: 64-bit offsets into the 1.6 GB edge map, capacity regrow), topology of the
+result, and the composited vertex colours against the oracle chain.  Reference sizes: configs/example.yaml:14-17 (vol_res),
+network/arch_avatar.py:320-349 (NerfRenderer), main.py:357-367,464-477."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from avatarcap_amd import config
+from common import geotex_sd, maxabs
+
+pytestmark = pytest.mark.gpu
+RES = [512, 512, 512]
+
+
+@pytest.fixture(scope='module')
+def frame512():
+    from avatarcap_amd.dataset import SyntheticTestDataset, to_cuda
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar
+    from avatarcap_amd.pipeline import FramePipeline
+    from avatarcap_amd.utils import recon_util
+    config.cfg = config.default_cfg()
+    config.cfg['testing']['vol_res'] = RES
+    config.device = torch.device('cuda')
+    config.if_type = 'sdf'
+    ds = SyntheticTestDataset(RES, valid='dense', n_frames=1)
+    net = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume()).to('cuda').eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in geotex_sd().items()})
+    pipe = FramePipeline(net, ds)
+    items = to_cuda(ds[0], add_batch=True)
+    recon_util._cap.clear(); recon_util._cap[torch.cuda.current_device()] = (1 << 16, 1 << 16)     # far too small: forces AVC_ERR_CAPACITY + regrow
+    out = pipe.avatar_frame(items)
+    torch.cuda.synchronize()
+    yield pipe, ds, items, out
+    recon_util._cap.clear()
+
+
+def test_occupancy_and_rgba_match_oracle_at_512(frame512):
+    from oracle import avatarcap_oracle as orc
+    pipe, ds, items, out = frame512
+    vol = out['occ_volume']
+    assert vol.numel() == 512 ** 3 and bool(torch.isfinite(vol).all())
+    rs = np.random.RandomState(512)
+    sel = np.sort(rs.choice(vol.numel(), 1200, replace=False))          # includes indices beyond 2^26: points / outputs addressed with 64-bit offsets
+    sel[-1] = vol.numel() - 1
+    st = torch.from_numpy(sel).cuda()
+    pts = ds.infer_pts[st].cpu().numpy()
+    fmap = pipe.network.warping_field.pose_feat_map[0].cpu().numpy()
+    ref = orc.occupancy_query(pts, fmap, ds.cano_smpl_center, geotex_sd())
+    assert maxabs(vol[st].cpu().numpy(), ref['cano_pts_ov'][:, 0]) < 1e-4                          # BASELINE.json: occupancy within 1e-4
+    # the colour head of the same fused kernel (rgb + sigma) on the same points (the raw field GeoTexAvatar.forward composites,
+    # arch_avatar.py:211-219), against the oracle with the slack of the reference's own fp32 arithmetic measured
+    occ2, off, rgba = pipe.network._avatar_query(ds.infer_pts[st][None].contiguous(), items, want_offset=True, want_rgba=True)
+    assert torch.equal(occ2[0, :, 0], vol[st])                                                     # colour kernel == geometry kernel on the occupancy
+    assert maxabs(off[0].cpu().numpy(), ref['nonrigid_offset']) < 1e-4
+    refs = {}
+    for dt in (np.float64, np.float32):
+        o = orc.warping_query(pts, fmap, ds.cano_smpl_center, geotex_sd(), 0, dt=dt)
+        rgb, alpha, _ = orc.double_tnet((pts.astype(dt) + o).astype(dt), geotex_sd(), with_colour=True, dt=dt)
+        refs[dt] = np.concatenate([rgb, alpha], -1)
+    slack = maxabs(refs[np.float32], refs[np.float64])
+    err = maxabs(rgba[0].cpu().numpy(), refs[np.float64])
+    print(f'512^3 rgba: err {err:.3e}, fp32-oracle slack {slack:.3e}')
+    assert err < 1e-4 + 2 * slack
+
+
+def test_mesh_is_the_oracles_bit_for_bit_at_512(frame512):
+    """The whole 512^3 volume through the sequential C restatement of the library on the host (a few seconds) and through the
+    device kernels: identical vertices (float32 bits), faces, numbering."""
+    from oracle import mc
+    pipe, ds, items, out = frame512
+    vol = out['occ_volume'].reshape(RES).cpu().numpy()
+    bounds = np.asarray(ds.cano_bounds, np.float32)
+    voxel = ((bounds[1] - bounds[0]) / np.array(RES, np.float32)).astype(np.float32)                # recon_util.py:61-62
+    ov, of = mc.marching_cubes(vol, float(config.iso_value), voxel)                                 # :64 (the library call, restated)
+    ov = ov + bounds[0] + np.float32(0.5) * voxel                                                   # :65
+    of = of[:, [2, 1, 0]]                                                                           # :69
+    v, f = out['cano_v'].cpu().numpy(), out['f'].cpu().numpy()
+    assert v.shape[0] > (1 << 16) and f.shape[0] > (1 << 16)                                        # the capacity regrow happened
+    assert f.shape == of.shape and np.array_equal(f, of)
+    assert v.shape == ov.shape and np.array_equal(v, ov)
+    n = out['cano_vn']
+    assert float((n.norm(dim=1) - 1).abs().max()) < 1e-4                                            # normals: parity is held at 64^3 / 256^3 sizes
+
+
+def test_mesh_topology_at_512(frame512):
+    pipe, ds, items, out = frame512
+    v, f, vol = out['cano_v'], out['f'].long(), out['occ_volume'].reshape(RES)
+    inside = vol > config.iso_value
+    crossings = sum(int((inside.narrow(a, 0, 511) != inside.narrow(a, 1, 511)).sum()) for a in range(3))
+    assert crossings <= v.shape[0] <= crossings + max(64, crossings // 1000), (v.shape[0], crossings)
+    assert int(f.min()) == 0 and int(f.max()) == v.shape[0] - 1
+    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    key = torch.minimum(e[:, 0], e[:, 1]) * v.shape[0] + torch.maximum(e[:, 0], e[:, 1])
+    uniq, cnt = torch.unique(key, return_counts=True)
+    assert int(cnt.max()) == 2                                                        # manifold: no edge shared by 3+ faces
+    dkey = e[:, 0] * v.shape[0] + e[:, 1]
+    assert torch.unique(dkey).numel() == dkey.numel()                                  # consistently oriented
+
+
+def test_vertex_colours_at_512(frame512):
+    """main.py:464-477 on vertices of the 512^3 mesh: 64 samples per ray through the colour kernel + compositing, against the
+    oracle chain, with the slack the reference's own fp32 arithmetic has on this network measured (fp32 vs fp64 oracle)."""
+    from oracle import avatarcap_oracle as orc
+    pipe, ds, items, out = frame512
+    nv = 100_000
+    idx = torch.linspace(0, out['cano_v'].shape[0] - 1, nv, device='cuda').long()
+    v, n = out['cano_v'][idx].contiguous(), out['cano_vn'][idx].contiguous()
+    rgb = pipe.colour_vertices(items, v, n)
+    assert rgb.shape == (nv, 3) and bool(torch.isfinite(rgb).all())
+    pick = np.arange(0, nv, nv // 150)[:150]
+    fmap = pipe.network.warping_field.pose_feat_map[0].cpu().numpy()
+    vv, nn = v[pick].cpu().numpy().astype(np.float64), n[pick].cpu().numpy().astype(np.float64)
+    t = np.linspace(0., 1., config.N_samples, dtype=np.float32).astype(np.float64)
+    near, far = 1.0 - 0.02, 1.0 + 0.05
+    z = near * (1 - t) + far * t
+    pts = ((vv + nn)[:, None, :] - nn[:, None, :] * z[None, :, None]).reshape(-1, 3).astype(np.float32)
+    dists = np.concatenate([z[1:] - z[:-1], z[-1:] - z[-2:-1]])
+    ref = {}
+    for dt in (np.float64, np.float32):
+        raw, _, _ = orc.geotex_forward_cano(pts, np.tile(dists, len(pick))[:, None], fmap, ds.cano_smpl_center, ds.cano_bounds,
+                                            ds.body['cano_smpl_v'], geotex_sd(), dt=dt)
+        ref[dt] = orc.raw2outputs(raw.reshape(len(pick), -1, 4), np.tile(z, (len(pick), 1)))[0][:, [2, 1, 0]]
+    slack = maxabs(ref[np.float32], ref[np.float64])
+    err = maxabs(rgb[pick].cpu().numpy(), ref[np.float64])
+    print(f'512^3 vertex colours: err {err:.3e}, fp32-oracle slack {slack:.3e}')
+    assert err < 1e-4 + 2 * slack
