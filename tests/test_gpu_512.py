@@ -53,7 +53,8 @@ def test_occupancy_and_rgba_match_oracle_at_512(frame512):
     # the colour head of the same fused kernel (rgb + sigma) on the same points (the raw field GeoTexAvatar.forward composites,
     # arch_avatar.py:211-219), against the oracle with the slack of the reference's own fp32 arithmetic measured
     occ2, off, rgba = pipe.network._avatar_query(ds.infer_pts[st][None].contiguous(), items, want_offset=True, want_rgba=True)
-    assert torch.equal(occ2[0, :, 0], vol[st])                                                     # colour kernel == geometry kernel on the occupancy
+    # (the geometry-only kernel folds shared.6 into geo.0 at pack time, the colour kernel keeps it: equal up to rounding)
+    assert maxabs(occ2[0, :, 0].cpu().numpy(), ref['cano_pts_ov'][:, 0]) < 1e-4
     assert maxabs(off[0].cpu().numpy(), ref['nonrigid_offset']) < 1e-4
     refs = {}
     for dt in (np.float64, np.float32):
@@ -105,11 +106,16 @@ def test_vertex_colours_at_512(frame512):
     oracle chain, with the slack the reference's own fp32 arithmetic has on this network measured (fp32 vs fp64 oracle)."""
     from oracle import avatarcap_oracle as orc
     pipe, ds, items, out = frame512
+    from avatarcap_amd.utils.smpl_util import smpl_util
     nv = 100_000
-    idx = torch.linspace(0, out['cano_v'].shape[0] - 1, nv, device='cuda').long()
+    # vertices close to the body: elsewhere GeoTexAvatar.forward zeroes the density (arch_avatar.py:208-209,226) and the colour is 0
+    d2, _ = smpl_util.knn_points(out['cano_v'][None], smpl_util.cano_smpl_vertices[None], K=1)
+    near = torch.nonzero(d2[0, :, 0] < 0.03 * 0.03)[:, 0]
+    assert near.numel() > nv
+    idx = near[torch.linspace(0, near.numel() - 1, nv, device='cuda').long()]
     v, n = out['cano_v'][idx].contiguous(), out['cano_vn'][idx].contiguous()
     rgb = pipe.colour_vertices(items, v, n)
-    assert rgb.shape == (nv, 3) and bool(torch.isfinite(rgb).all())
+    assert rgb.shape == (nv, 3) and bool(torch.isfinite(rgb).all()) and float(rgb.abs().max()) > 0.05
     pick = np.arange(0, nv, nv // 150)[:150]
     fmap = pipe.network.warping_field.pose_feat_map[0].cpu().numpy()
     vv, nn = v[pick].cpu().numpy().astype(np.float64), n[pick].cpu().numpy().astype(np.float64)
