@@ -47,6 +47,9 @@
 #ifndef AVC_DBG_PF_SAME
 #define AVC_DBG_PF_SAME 0
 #endif
+#ifndef AVC_DBG_NO_LDSREAD
+#define AVC_DBG_NO_LDSREAD 0      // A fragments read once per chunk instead of once per k-step
+#endif
 
 namespace avc {
 
@@ -97,7 +100,8 @@ __device__ __forceinline__ void static_for(F &&f)
 {
     static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
-struct NoSide { template <class K> __device__ __forceinline__ void operator()(K) const {} };
+struct NoSide { template <class K, class R> __device__ __forceinline__ void operator()(K, R) const {} };
+template <int R> using RegionC = std::integral_constant<int, R>;
 
 // B-operand providers of a chunk: k-step K -> fragment.
 struct RegIn {                       // activations living in registers
@@ -136,7 +140,8 @@ __device__ __forceinline__ void park_store(unsigned base, int k, const Frag &f)
 // weight stream: 2-slot LDS ring, one chunk of prefetch, sizes known at compile time
 // ------------------------------------------------------------------------------------------
 struct Stream {
-    const char *gs;          // weight stream (wave-uniform: stays in SGPRs => saddr-form global loads)
+    __amdgpu_buffer_rsrc_t rs;   // buffer resource over the weight stream (LDS-DMA source)
+    const char *gs;          // weight stream (wave-uniform)
     unsigned total;          // bytes per pass
     unsigned pf_off;         // offset of the next chunk to prefetch
     unsigned parity;         // ring slot of the chunk about to be consumed
@@ -147,12 +152,14 @@ struct Stream {
 #endif
 };
 
-// The next chunk travels global -> VGPR -> LDS (global_load_dwordx4 + ds_write_b128), NOT through
-// LDS-DMA: a global_load_lds costs the issuing wave 60-100 cycles (MI355X_MICROARCH.md), and with one
-// wave per SIMD those cycles come straight out of the MFMA stream (measured: 889 of them per tile
-// = 23 % of the kernel).  A chunk is covered in GROUPS of 16 KiB (a shorter last group for sizes that
-// are not a multiple of 16 KiB); inside a group wave w owns a contiguous quarter and walks it with
-// immediate offsets, so a piece needs no address arithmetic beyond one scalar add per group.
+// The next chunk travels L2 -> LDS by LDS-DMA in its BUFFER form, `buffer_load_dwordx4 v_off32, s[rsrc], s_off offen lds`: the data never
+// touches a VGPR, there is no ds_write, and the only per-lane operand is one 32-bit offset register (lane * 16) that never changes.
+// Measured beside the MFMA stream of this kernel's chunk step (tools/ubench/copy_cost.hip, profiles/r02_ubench_copy_cost.md): 35.9 cycles
+// per MFMA against 34.6 with no copy at all -- while `global_load_lds_dwordx4` (64-bit address VGPR pair) costs 41.3, the saddr-form
+// global_load + ds_write_b128 40.9, and what round 1 shipped (global_load with a 64-bit vaddr + ds_write_b128) cost the kernel 28 % of its
+// time (tools/ablate_run.sh).  A chunk is covered in GROUPS of 16 KiB (a shorter last group for sizes that are not a multiple of 16 KiB);
+// inside a group wave w owns a contiguous quarter, one 1 KiB piece per instruction: M0 = LDS destination, soffset = stream offset.
+// Completion: every wave drains its own pieces (`s_waitcnt vmcnt(0)`) right before the chunk barrier that publishes them.
 constexpr int GROUP = 16384;
 constexpr int pf_group_bytes(int bytes, int g) { return bytes - g * GROUP >= GROUP ? GROUP : bytes - g * GROUP; }
 constexpr int pf_slots(int bytes) { return 4 * ((bytes + GROUP - 1) / GROUP); }          // piece ids incl. holes
@@ -160,62 +167,56 @@ constexpr bool pf_valid(int bytes, int i) { return (i % 4) * 1024 < pf_group_byt
 constexpr int pf_count(int bytes) { int n = 0; for (int i = 0; i < pf_slots(bytes); ++i) n += pf_valid(bytes, i); return n; }
 constexpr int pf_nth(int bytes, int n) { for (int i = 0; i < pf_slots(bytes); ++i) { if (pf_valid(bytes, i)) { if (n == 0) return i; --n; } } return -1; }
 
-// schedule of the n-th piece over the 3*KS issue slots of a chunk: load at L, store to LDS at L + D
-struct PfPlan { int slots, npw, dist, ring; };
+// schedule of the n-th piece over the 3*KS issue slots of a chunk: issued at slot n * (slots - tail) / npw, i.e. spread evenly with the last
+// `tail` slots left free so that the final piece has landed when the wave reaches the barrier
+struct PfPlan { int slots, npw, tail; };
 constexpr PfPlan pf_plan(int ks, int bytes)
 {
-    PfPlan p{3 * ks, pf_count(bytes), 0, 1};
+    PfPlan p{3 * ks, pf_count(bytes), 0};
     if (p.npw == 0) return p;
-    p.dist = p.slots >= 36 ? 12 : (p.slots >= 18 ? 6 : (p.slots >= 9 ? 4 : 2));
+    p.tail = p.slots >= 36 ? 12 : (p.slots >= 18 ? 6 : (p.slots >= 9 ? 4 : 2));
 #ifdef AVC_PF_DIST_PCT
-    p.dist = p.dist * AVC_PF_DIST_PCT / 100; if (p.dist < 1) p.dist = 1; if (p.dist > p.slots - 2) p.dist = p.slots - 2;
+    p.tail = p.tail * AVC_PF_DIST_PCT / 100; if (p.tail < 1) p.tail = 1; if (p.tail > p.slots - 2) p.tail = p.slots - 2;
 #endif
-    const int span = p.slots - p.dist;                     // loads spread over [0, span)
-    // pieces in flight at once = ceil(dist * npw / span) (+1 for the slot where a store and a load meet)
-    p.ring = (p.dist * p.npw + span - 1) / span + 1;
     return p;
 }
-constexpr int pf_load_slot(const PfPlan &p, int n) { return n * (p.slots - p.dist) / p.npw; }
+constexpr int pf_load_slot(const PfPlan &p, int n) { return n * (p.slots - p.tail) / p.npw; }
 
+typedef __attribute__((address_space(3))) void lds_void;
+
+// piece I of the next chunk: stream offset `so` (+ group / wave / piece) -> LDS ring slot `dst` (same layout)
 template <int BYTES, int I>
-__device__ __forceinline__ u32x4 pf_load(const char *src, unsigned lane16, unsigned wave)
-{
-    constexpr int g = I / 4, j = I % 4, pw = pf_group_bytes(BYTES, g) / WAVES;
-    const char *sg = src + g * GROUP;                                    // scalar
-    return *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(
-        (const __attribute__((address_space(1))) char *)sg + (wave * pw + lane16) + j * 1024);
-}
-template <int BYTES, int I>
-__device__ __forceinline__ void pf_store(unsigned dst_slot, unsigned lane16, unsigned wave, const u32x4 &v)
+__device__ __forceinline__ void pf_dma(__amdgpu_buffer_rsrc_t rs, unsigned so, unsigned dst, unsigned lane16, unsigned wave)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int g = I / 4, j = I % 4, pw = pf_group_bytes(BYTES, g) / WAVES;
-    *reinterpret_cast<u32x4 *>(smem + (dst_slot + wave * pw + lane16) + g * GROUP + j * 1024) = v;
+    const unsigned rel = g * GROUP + wave * pw + j * 1024;                         // scalar
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + (dst + rel)), 16, (int)lane16, (int)(so + rel), 0, 0);
 }
 
-// work of issue slot SLOT: first retire the pieces whose data is due, then start new loads
-template <int KS, int NEXT_BYTES, int SLOT, int RING>
-__device__ __forceinline__ void pf_step(u32x4 (&st)[RING], const char *src, unsigned dst, unsigned lane16, unsigned wave)
+// work of issue slot SLOT: start the pieces scheduled here
+template <int KS, int NEXT_BYTES, int SLOT>
+__device__ __forceinline__ void pf_step(__amdgpu_buffer_rsrc_t rs, unsigned so, unsigned dst, unsigned lane16, unsigned wave)
 {
 #if !AVC_DBG_NO_PREFETCH
     constexpr PfPlan P = pf_plan(KS, NEXT_BYTES);
     static_for<P.npw>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
-        if constexpr (pf_load_slot(P, n) + P.dist == SLOT) pf_store<NEXT_BYTES, pf_nth(NEXT_BYTES, n)>(dst, lane16, wave, st[n % RING]);
-    });
-    static_for<P.npw>([&](auto nc) {
-        constexpr int n = decltype(nc)::value;
-        if constexpr (pf_load_slot(P, n) == SLOT) st[n % RING] = pf_load<NEXT_BYTES, pf_nth(NEXT_BYTES, n)>(src, lane16, wave);
+        if constexpr (pf_load_slot(P, n) == SLOT) pf_dma<NEXT_BYTES, pf_nth(NEXT_BYTES, n)>(rs, so, dst, lane16, wave);
     });
 #endif
 }
 
-// One chunk step: KS k-steps x TPC output tiles (units k-major in LDS).  Every k-step is three issue
-// slots -- (hi,hi), (hi,lo), (lo,hi) products, one MFMA per tile each -- fenced by sched_barriers so
-// that consecutive MFMAs never share an accumulator (an 8-pass MFMA that depends on its predecessor
-// issues 8 cycles late) and the side work is spread evenly: slot 0 carries the LDS reads of the next
-// k-step's operands, every slot one step of the next chunk's global->VGPR->LDS copy, slot 2 a slice of
-// the previous tile pair's epilogue (`side`).
+// every piece this wave has issued is in LDS (LDS-DMA completes in vmcnt order); the barrier that follows publishes them
+__device__ __forceinline__ void pf_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// One chunk step: KS k-steps x TPC output tiles (units k-major in LDS).  Every k-step is three issue slots -- (hi,hi), (hi,lo), (lo,hi)
+// products, one MFMA per output tile each, consecutive MFMAs never sharing an accumulator.  The side work is pinned BEHIND individual MFMAs
+// with sched_barriers, a few instructions per MFMA: with one wave per SIMD about five single-issue instructions hide in the 32-cycle shadow of
+// an MFMA, and whatever is clustered beyond that idles the matrix pipe (tools/ubench/copy_cost.hip: the same 16 VALU per k-step cost 43.2
+// cycles per MFMA when clustered in one slot and 36.3 when spread over the six MFMAs).  Slot 0 issues the LDS reads of the next k-step's
+// operands, every slot its share of the next chunk's LDS-DMA, and region r = 2 * slot + tile (TPC == 2) stage r of the PREVIOUS tile pair's
+// epilogue slice (`side(k, r)`: accumulator read -> activation -> fp16 split, six stages).
 template <int KS, int TPC, int NEXT_BYTES, class In, class Side>
 __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restrict__ acc, Side &&side)
 {
@@ -224,6 +225,7 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
 #if AVC_DBG_TIMING
     const long long tb0 = clock64();
 #endif
+    pf_drain();
 #if !AVC_DBG_NO_BARRIER
     __syncthreads();
 #endif
@@ -238,12 +240,8 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
     unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES;
     asm volatile("" : "+v"(base), "+s"(so), "+s"(dst));
 #if AVC_DBG_PF_SAME
-    const char *src = s.gs + (so & 0u);
-#else
-    const char *src = s.gs + so;
+    so &= 0u;
 #endif
-    constexpr PfPlan P = pf_plan(KS, NEXT_BYTES);
-    u32x4 st[P.ring];
 
     half8 ah[2][TPC], al[2][TPC];
     Frag b[2];
@@ -261,24 +259,36 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
             b[nxt] = in.template get<k + 1>();
 #pragma unroll
             for (int t = 0; t < TPC; ++t) {
+#if AVC_DBG_NO_LDSREAD
+                ah[nxt][t] = ah[cur][t]; al[nxt][t] = al[cur][t];
+#else
                 ah[nxt][t] = *reinterpret_cast<const half8 *>(smem + base + ((k + 1) * TPC + t) * layout::UNIT_BYTES);
                 al[nxt][t] = *reinterpret_cast<const half8 *>(smem + base + ((k + 1) * TPC + t) * layout::UNIT_BYTES + 1024);
+#endif
             }
         }
-        pf_step<KS, NEXT_BYTES, 3 * k + 0, P.ring>(st, src, dst, s.lane_off, s.wave);
-#pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
+        pf_step<KS, NEXT_BYTES, 3 * k + 0>(s.rs, so, dst, s.lane_off, s.wave);
+        static_for<TPC>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
+            if constexpr (TPC == 2) { side(kc, RegionC<t>{}); __builtin_amdgcn_sched_barrier(0); }
+        });
         __builtin_amdgcn_sched_barrier(0);
         // ---- slot 1
-        pf_step<KS, NEXT_BYTES, 3 * k + 1, P.ring>(st, src, dst, s.lane_off, s.wave);
-#pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].lo), acc[t], 0, 0, 0);
+        pf_step<KS, NEXT_BYTES, 3 * k + 1>(s.rs, so, dst, s.lane_off, s.wave);
+        static_for<TPC>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].lo), acc[t], 0, 0, 0);
+            if constexpr (TPC == 2) { side(kc, RegionC<2 + t>{}); __builtin_amdgcn_sched_barrier(0); }
+        });
         __builtin_amdgcn_sched_barrier(0);
         // ---- slot 2
-        pf_step<KS, NEXT_BYTES, 3 * k + 2, P.ring>(st, src, dst, s.lane_off, s.wave);
-        side(kc);
-#pragma unroll
-        for (int t = 0; t < TPC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
+        pf_step<KS, NEXT_BYTES, 3 * k + 2>(s.rs, so, dst, s.lane_off, s.wave);
+        static_for<TPC>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
+            if constexpr (TPC == 2) { side(kc, RegionC<4 + t>{}); __builtin_amdgcn_sched_barrier(0); }
+        });
         __builtin_amdgcn_sched_barrier(0);
     });
     const unsigned no = s.pf_off + NEXT_BYTES;
@@ -386,43 +396,47 @@ __device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo)
     }
 }
 
-// Slice K of NS of the epilogue of a tile pair: accumulators -> scale -> activation -> split fp16,
-// written into the 4 B fragments (k-steps) the pair becomes for the next layer.  32 values per lane.
-// two values at once: both additions of the softplus become one packed v_pk_add_f32 each
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int ACT>
-__device__ __forceinline__ void act2_f(float x0, float x1, float &y0, float &y1)
-{
-    if constexpr (ACT == ACT_SOFTPLUS) {
-        f32x2 r, e;
-        asm("v_max_f32 %0, 0, %1" : "=v"(r.x) : "v"(x0));
-        asm("v_max_f32 %0, 0, %1" : "=v"(r.y) : "v"(x1));
-        e.x = __builtin_amdgcn_exp2f(-__builtin_fabsf(x0));
-        e.y = __builtin_amdgcn_exp2f(-__builtin_fabsf(x1));
-        e = e + 1.0f;
-        e.x = __builtin_amdgcn_logf(e.x);
-        e.y = __builtin_amdgcn_logf(e.y);
-        r = r + e;
-        y0 = r.x; y1 = r.y;
-    } else {
-        y0 = act_f<ACT>(x0); y1 = act_f<ACT>(x1);
-    }
-}
+// Epilogue of a tile pair: accumulators -> activation -> split fp16, written into the 4 B fragments (k-steps) the pair becomes for the next
+// layer; 32 values per lane.  The work is cut into NS slices (one per k-step of the chunk it hides in) of PPS value pairs, and every slice into
+// SIX STAGES, one per MFMA of the k-step (chunk() pins stage r behind MFMA r).  Intermediate values travel in EpiRegs.
+//   Softplus (log2 domain, see softplus_f):  0: x <- acc, e = 2^-|x|   1: e += 1   2: e = log2 e   3: y = max(x, 0) + e   4: hi = cvt_pk(y)   5: lo
+//   ReLU / LeakyReLU / none:                 0: x <- acc               1: y = act(x)   2: hi = cvt_pk(y)   3: lo (low half)   4: lo (high half)
+// Scalar f32 adds on purpose: packed v_pk_add_f32 beside MFMAs costs ~13 cycles each (MI355X_MICROARCH.md).
+template <int PPS>
+struct EpiRegs { float x[2 * PPS]; float e[2 * PPS]; unsigned hi[PPS], lo[PPS]; };
 
-template <int ACT, int NS, int K>
-__device__ __forceinline__ void epi_slice(const f32x16 *__restrict__ acc, Frag *__restrict__ out4)
+template <int ACT, int NS, int K, int R>
+__device__ __forceinline__ void epi_part(const f32x16 *__restrict__ acc, Frag *__restrict__ out4, EpiRegs<(16 + NS - 1) / NS> &st)
 {
     constexpr int PPS = (16 + NS - 1) / NS;          // value PAIRS per slice (16 pairs per lane)
     static_for<PPS>([&](auto ic) {
-        constexpr int pr = K * PPS + decltype(ic)::value;
+        constexpr int i = decltype(ic)::value, pr = K * PPS + i;
         if constexpr (K < NS && pr < 16) {
             constexpr int v = 2 * pr, t = v >> 4, r = v & 15;
-            unsigned h, l;
-            float y0, y1;
-            act2_f<ACT>(acc[t][r], acc[t][r + 1], y0, y1);
-            split2(y0, y1, h, l);
-            out4[2 * t + (r >> 3)].hi[(r & 7) >> 1] = h;
-            out4[2 * t + (r >> 3)].lo[(r & 7) >> 1] = l;
+            float &x0 = st.x[2 * i], &x1 = st.x[2 * i + 1], &e0 = st.e[2 * i], &e1 = st.e[2 * i + 1];
+            auto write_out = [&]() { out4[2 * t + (r >> 3)].hi[(r & 7) >> 1] = st.hi[i]; out4[2 * t + (r >> 3)].lo[(r & 7) >> 1] = st.lo[i]; };
+            auto cvt = [&]() { const half2_t hv = {(_Float16)x0, (_Float16)x1}; st.hi[i] = __builtin_bit_cast(unsigned, hv); };
+            if constexpr (ACT == ACT_SOFTPLUS) {
+                if constexpr (R == 0) { x0 = acc[t][r]; x1 = acc[t][r + 1]; e0 = __builtin_amdgcn_exp2f(-__builtin_fabsf(x0)); e1 = __builtin_amdgcn_exp2f(-__builtin_fabsf(x1)); }
+                else if constexpr (R == 1) { e0 = e0 + 1.0f; e1 = e1 + 1.0f; }
+                else if constexpr (R == 2) { e0 = __builtin_amdgcn_logf(e0); e1 = __builtin_amdgcn_logf(e1); }
+                else if constexpr (R == 3) {
+                    float r0, r1;
+                    asm("v_max_f32 %0, 0, %1" : "=v"(r0) : "v"(x0));          // bare max (fmaxf would canonicalise first)
+                    asm("v_max_f32 %0, 0, %1" : "=v"(r1) : "v"(x1));
+                    x0 = r0 + e0; x1 = r1 + e1;
+                }
+                else if constexpr (R == 4) cvt();
+                else { unsigned l; asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                                        : "=&v"(l) : "v"(st.hi[i]), "v"(x0), "v"(x1)); st.lo[i] = l; write_out(); }
+            } else {
+                if constexpr (R == 0) { x0 = acc[t][r]; x1 = acc[t][r + 1]; }
+                else if constexpr (R == 1) { x0 = act_f<ACT>(x0); x1 = act_f<ACT>(x1); }
+                else if constexpr (R == 2) cvt();
+                else if constexpr (R == 3) { unsigned l; asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(st.hi[i]), "v"(x0)); st.lo[i] = l; }
+                else if constexpr (R == 4) { unsigned l = st.lo[i]; asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(st.hi[i]), "v"(x1));
+                                             st.lo[i] = l; write_out(); }
+            }
         }
     });
 }
@@ -432,8 +446,9 @@ template <int ACT, int NS>
 struct Pending {
     const f32x16 *acc;
     Frag *out4;
-    template <class KC>
-    __device__ __forceinline__ void operator()(KC) const { epi_slice<ACT, NS, KC::value>(acc, out4); }
+    EpiRegs<(16 + NS - 1) / NS> st;
+    template <class KC, class RC>
+    __device__ __forceinline__ void operator()(KC, RC) { epi_part<ACT, NS, KC::value, RC::value>(acc, out4, st); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -453,17 +468,21 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
     constexpr int B0 = chunk_bytes(KS0, 2), B1 = chunk_bytes(KS1, 2);
     constexpr int NS = KS0 < 16 ? KS0 : 16;
     f32x16 prev[2];
+    EpiRegs<(16 + NS - 1) / NS> est;
     static_for<NPAIR>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
         f32x16 acc[2];
         bias.take(acc, 2, h);
         constexpr int after0 = KS1 > 0 ? B1 : (p + 1 < NPAIR ? B0 : NEXT_BYTES);
         if constexpr (p == 0) {
-            chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc) { if constexpr (decltype(kc)::value == 0) bias.after_barrier(h); pre(kc); });
+            chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc, auto rc) {
+                if constexpr (decltype(kc)::value == 0 && decltype(rc)::value == 5) bias.after_barrier(h);
+                pre(kc, rc);
+            });
         } else {
-            chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc) {
-                if constexpr (decltype(kc)::value == 0) bias.after_barrier(h);
-                epi_slice<ACT, NS, decltype(kc)::value>(prev, out + 4 * (p - 1));
+            chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc, auto rc) {
+                if constexpr (decltype(kc)::value == 0 && decltype(rc)::value == 5) bias.after_barrier(h);
+                epi_part<ACT, NS, decltype(kc)::value, decltype(rc)::value>(prev, out + 4 * (p - 1), est);
             });
         }
         if constexpr (KS1 > 0) {
@@ -479,7 +498,8 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
 template <int ACT>
 __device__ __forceinline__ void flush(const f32x16 *__restrict__ pend, Frag *__restrict__ out4)
 {
-    static_for<4>([&](auto kc) { epi_slice<ACT, 4, decltype(kc)::value>(pend, out4); });
+    EpiRegs<4> st;
+    static_for<4>([&](auto kc) { static_for<6>([&](auto rc) { epi_part<ACT, 4, decltype(kc)::value, decltype(rc)::value>(pend, out4, st); }); });
 }
 
 // one-tile linear head (rows 0..31 of which only the first few are real): the three products of a
@@ -493,6 +513,7 @@ __device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, B
     if constexpr (LAST) bias.rewind(bias_head);      // the next block is the first one of the next point tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a1[r] = 0.f; a2[r] = 0.f; }
+    pf_drain();
 #if !AVC_DBG_NO_BARRIER
     __syncthreads();
 #endif
@@ -500,23 +521,22 @@ __device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, B
     unsigned so = s.pf_off;
     unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES;
     asm volatile("" : "+v"(base), "+s"(so), "+s"(dst));
-    const char *src = s.gs + so;
-    constexpr PfPlan P = pf_plan(KS, NEXT_BYTES);
-    u32x4 st[P.ring];
     static_for<KS>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const half8 ah = *reinterpret_cast<const half8 *>(smem + base + k * layout::UNIT_BYTES);
         const half8 al = *reinterpret_cast<const half8 *>(smem + base + k * layout::UNIT_BYTES + 1024);
         if constexpr (k == 0) bias.after_barrier(h);
-        pf_step<KS, NEXT_BYTES, 3 * k + 0, P.ring>(st, src, dst, s.lane_off, s.wave);
+        pf_step<KS, NEXT_BYTES, 3 * k + 0>(s.rs, so, dst, s.lane_off, s.wave);
         a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].hi), a0, 0, 0, 0);
+        pre(kc, RegionC<0>{}); pre(kc, RegionC<1>{});
         __builtin_amdgcn_sched_barrier(0);
-        pf_step<KS, NEXT_BYTES, 3 * k + 1, P.ring>(st, src, dst, s.lane_off, s.wave);
+        pf_step<KS, NEXT_BYTES, 3 * k + 1>(s.rs, so, dst, s.lane_off, s.wave);
         a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_half8(in[k].lo), a1, 0, 0, 0);
+        pre(kc, RegionC<2>{}); pre(kc, RegionC<3>{});
         __builtin_amdgcn_sched_barrier(0);
-        pf_step<KS, NEXT_BYTES, 3 * k + 2, P.ring>(st, src, dst, s.lane_off, s.wave);
-        pre(kc);
+        pf_step<KS, NEXT_BYTES, 3 * k + 2>(s.rs, so, dst, s.lane_off, s.wave);
         a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_half8(in[k].hi), a2, 0, 0, 0);
+        pre(kc, RegionC<4>{}); pre(kc, RegionC<5>{});
         __builtin_amdgcn_sched_barrier(0);
     });
     const unsigned no = s.pf_off + NEXT_BYTES;
@@ -631,6 +651,7 @@ __device__ __forceinline__ Stream stream_init(const QueryParams &p, int wave, in
     Stream s;
     s.wave = wave; s.lane_off = lane * 16u;
     s.gs = p.wstream;
+    s.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p.wstream), 0, (int)p.stream_bytes, 0x00027000);   // raw buffer, range-checked at stream_bytes
     s.total = p.stream_bytes; s.parity = 0;
     // chunk 0 -> slot 0, synchronously (same group layout as the pipelined copy; run-time sizes)
     for (int g0 = 0; g0 < first_bytes; g0 += GROUP) {
