@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AVCAP_LIB', os.path.join(_HERE, 'libavcap_hip.so'))   # override only for kernel A/B experiments
 
 AVC_ERR_CAPACITY = -4
+AVC_ERR_RANGE = -5
 
 
 class avc_dense(C.Structure):
@@ -36,6 +37,9 @@ _SIGNATURES = {
     'avc_set_pose_feat_map': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'avc_set_img_feat_map': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'avc_avatar_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'avc_avatar_query_grid': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    'avc_set_range_check': (C.c_int, [C.c_void_p, C.c_int]),
     'avc_template_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_recon_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
     'avc_group_norm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
@@ -105,6 +109,26 @@ def ctx(device=None) -> int:
         check(lib().avc_ctx_create(int(device), C.byref(h)))
         _ctxs[device] = h.value
     return _ctxs[device]
+
+
+# A context holds ONE packed avatar network, ONE packed recon decoder and ONE bound feature map of each kind, while the host-side
+# modules cache "I have packed / bound already".  Two modules with different weights on the same device would otherwise evaluate
+# with each other's weights: every slot records which module (and which version of it) the context currently holds.
+_owners: dict[tuple[int, str], object] = {}
+
+
+def owns(ctx_handle: int, slot: str, token) -> bool:
+    return _owners.get((ctx_handle, slot)) == token
+
+
+def set_owner(ctx_handle: int, slot: str, token) -> None:
+    _owners[(ctx_handle, slot)] = token
+
+
+def apply_range_check(ctx_handle: int) -> None:
+    """config.check_range -> avc_set_range_check (include/avcap.h 'numeric range')."""
+    from . import config
+    check(lib().avc_set_range_check(ctx_handle, 1 if getattr(config, 'check_range', False) else 0))
 
 
 def stream_ptr(device=None) -> int:

@@ -20,7 +20,9 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
 # mesh / KNN kernels promise bit-exact agreement with the C oracle (built with -ffp-contract=off):
 # HIP's __fmul_rn/__fadd_rn are plain operators, so contraction has to be disabled per file.
-EXTRA = {'mesh.hip': ['-ffp-contract=off'], 'knn_lbs.hip': ['-ffp-contract=off'], 'raster.hip': ['-ffp-contract=off']}
+EXTRA = {'mesh.hip': ['-ffp-contract=off'], 'knn_lbs.hip': ['-ffp-contract=off'], 'raster.hip': ['-ffp-contract=off'],
+         # MFMA accumulators in VGPRs: the epilogue reads them without a v_accvgpr_read per value (-0.7 % launch time, tools/ablate_run.sh)
+         'fused_mlp.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
 
 def _stale(target, deps):
@@ -34,12 +36,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
-    for src in SOURCES:
+    # (object name, source, extra flags): fused_mlp.hip is built twice -- the plain kernels and the range-checking flavour
+    # (include/avcap.h avc_set_range_check), which live in different namespaces of the same library
+    units = [(src + '.o', src, []) for src in SOURCES] + [('fused_mlp_checked.o', 'fused_mlp.hip', ['-DAVC_CHECK_RANGE=1'])]
+    for obj, src, extra in units:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJ, src + '.o')
+        op = os.path.join(OBJ, obj)
         if force or _stale(op, [sp] + hdrs):
-            cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', sp, '-o', op]
-            jobs.append((src, cmd))
+            cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + extra + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', sp, '-o', op]
+            jobs.append((obj, cmd))
 
     def run(job):
         src, cmd = job
@@ -49,7 +54,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, s + '.o') for s in SOURCES]
+    objs = [os.path.join(OBJ, u[0]) for u in units]
     if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
         if verbose:

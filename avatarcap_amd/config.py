@@ -26,6 +26,10 @@ sdf_thres = 0.1
 
 cfg = dict()           # configurations from the yaml file (config.py:25)
 
+# not in the reference: opt-in check that no feature / activation leaves the fp16 range of the fused queries (include/avcap.h,
+# 'numeric range'); a query then synchronises and raises AvcapError (AVC_ERR_RANGE) instead of returning silently wrong values
+check_range = False
+
 
 def load_config(path):
     import yaml

@@ -69,8 +69,11 @@ struct avc_ctx {
     void *fusion_graph = nullptr, *fusion_graph_exec = nullptr;        // hipGraph_t / hipGraphExec_t of the fusion iterations
     int fusion_graph_H = 0, fusion_graph_W = 0, fusion_graph_iters = 0;
     void *gn_scratch = nullptr; size_t gn_scratch_bytes = 0;       // GroupNorm slice sums
+    void *scatter_scratch = nullptr; size_t scatter_scratch_bytes = 0;   // block counts of avc_scatter_volume
     void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
     avc::Timing timing;
+    int check_range = 0;                 // avc_set_range_check
+    unsigned *range_flag_dev = nullptr;
 };
 
 namespace avc {
@@ -80,13 +83,22 @@ int pack_recon(avc_ctx *ctx, const avc_dense fc[4]);
 int upload(PackedNet &net);
 void release(PackedNet &net);
 // fused_mlp.hip
-int launch_avatar(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], int occ_sigmoid,
+// dense-grid point generator of the queries (pts == nullptr): three per-axis coordinate tables on the device
+struct GridDesc { const float *x, *y, *z; int32_t res[3]; };
+namespace plain {       // fused_mlp.hip
+int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], int occ_sigmoid,
                   float *occ, float *offset, float *rgba, bool template_only, hipStream_t s);
-int launch_recon(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], float *out, hipStream_t s);
+int launch_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], float *out, hipStream_t s);
+}
+namespace checked {     // the same file built with -DAVC_CHECK_RANGE=1 (synchronous; returns AVC_ERR_RANGE)
+int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], int occ_sigmoid,
+                  float *occ, float *offset, float *rgba, bool template_only, hipStream_t s);
+int launch_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], float *out, hipStream_t s);
+}
 int launch_nchw_to_hwc(const float *src, float *dst, int C, int H, int W, hipStream_t s);
 int launch_group_norm(avc_ctx *ctx, const float *x, int N, int C, int64_t HW, int G, const float *gamma, const float *beta, float eps,
                       int relu, float *y, hipStream_t s);
-int launch_scatter(const uint8_t *valid, int64_t N, const float *values, const float *fill, float *vol, hipStream_t s);
+int launch_scatter(avc_ctx *ctx, const uint8_t *valid, int64_t N, const float *values, const float *fill, float *vol, hipStream_t s);
 // mesh.hip
 int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float bounds[6], float iso,
                float *verts, float *normals, int32_t *faces, int64_t cap_v, int64_t cap_f, int64_t counts[2], hipStream_t s);

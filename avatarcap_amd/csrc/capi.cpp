@@ -42,6 +42,8 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->img_feat_hwc) hipFree(ctx->img_feat_hwc);
     if (ctx->mc_scratch) hipFree(ctx->mc_scratch);
     if (ctx->mc_cells) hipFree(ctx->mc_cells);
+    if (ctx->scatter_scratch) hipFree(ctx->scatter_scratch);
+    if (ctx->range_flag_dev) hipFree(ctx->range_flag_dev);
     if (ctx->mc_tables_dev) hipFree(ctx->mc_tables_dev);
     if (ctx->raster_scratch) hipFree(ctx->raster_scratch);
     if (ctx->knn_scratch) hipFree(ctx->knn_scratch);
@@ -146,26 +148,52 @@ int avc_set_img_feat_map(avc_ctx *ctx, const float *map, int C, int H, int W, av
     return set_map(ctx, ctx ? &ctx->img_feat_hwc : nullptr, &ctx->img_C, &ctx->img_H, &ctx->img_W, map, C, H, W, 32, (hipStream_t)stream);
 }
 
+// plain build of the fused kernels, or the range-checking one (avc_set_range_check)
+static int run_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], int sig, float *occ, float *offset,
+                      float *rgba, bool template_only, hipStream_t s)
+{
+    return ctx->check_range ? checked::launch_avatar(ctx, pts, grid, n, center, sig, occ, offset, rgba, template_only, s)
+                            : plain::launch_avatar(ctx, pts, grid, n, center, sig, occ, offset, rgba, template_only, s);
+}
+
 int avc_avatar_query(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], int occupancy_sigmoid,
                      float *occ, float *offset, float *rgba, avc_stream stream)
 {
     AVC_REQUIRE(ctx && center && n >= 0 && (n == 0 || (pts && occ)), AVC_ERR_ARG, "avc_avatar_query: NULL argument or negative n");
     AVC_HIP(hipSetDevice(ctx->device));
-    return launch_avatar(ctx, pts, n, center, occupancy_sigmoid, occ, offset, rgba, false, (hipStream_t)stream);
+    return run_avatar(ctx, pts, nullptr, n, center, occupancy_sigmoid, occ, offset, rgba, false, (hipStream_t)stream);
+}
+
+int avc_avatar_query_grid(avc_ctx *ctx, const float *axis_x, const float *axis_y, const float *axis_z, const int32_t res[3], const float center[3],
+                          int occupancy_sigmoid, float *occ, float *offset, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && axis_x && axis_y && axis_z && res && center && occ, AVC_ERR_ARG, "avc_avatar_query_grid: NULL argument");
+    AVC_REQUIRE(res[0] >= 1 && res[1] >= 1 && res[2] >= 1, AVC_ERR_ARG, "avc_avatar_query_grid: every resolution must be >= 1");
+    AVC_HIP(hipSetDevice(ctx->device));
+    const GridDesc g{axis_x, axis_y, axis_z, {res[0], res[1], res[2]}};
+    return run_avatar(ctx, nullptr, &g, (int64_t)res[0] * res[1] * res[2], center, occupancy_sigmoid, occ, offset, nullptr, false, (hipStream_t)stream);
 }
 
 int avc_template_query(avc_ctx *ctx, const float *pts, int64_t n, int occupancy_sigmoid, float *occ, float *rgba, avc_stream stream)
 {
     AVC_REQUIRE(ctx && n >= 0 && (n == 0 || (pts && occ)), AVC_ERR_ARG, "avc_template_query: NULL argument or negative n");
     AVC_HIP(hipSetDevice(ctx->device));
-    return launch_avatar(ctx, pts, n, nullptr, occupancy_sigmoid, occ, nullptr, rgba, true, (hipStream_t)stream);
+    return run_avatar(ctx, pts, nullptr, n, nullptr, occupancy_sigmoid, occ, nullptr, rgba, true, (hipStream_t)stream);
 }
 
 int avc_recon_query(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], float *out, avc_stream stream)
 {
     AVC_REQUIRE(ctx && center && n >= 0 && (n == 0 || (pts && out)), AVC_ERR_ARG, "avc_recon_query: NULL argument or negative n");
     AVC_HIP(hipSetDevice(ctx->device));
-    return launch_recon(ctx, pts, n, center, out, (hipStream_t)stream);
+    return ctx->check_range ? checked::launch_recon(ctx, pts, nullptr, n, center, out, (hipStream_t)stream)
+                            : plain::launch_recon(ctx, pts, nullptr, n, center, out, (hipStream_t)stream);
+}
+
+int avc_set_range_check(avc_ctx *ctx, int enabled)
+{
+    AVC_REQUIRE(ctx, AVC_ERR_ARG, "avc_set_range_check: NULL context");
+    ctx->check_range = enabled ? 1 : 0;
+    return AVC_OK;
 }
 
 int avc_group_norm(avc_ctx *ctx, const float *x, int N, int C, int64_t HW, int G, const float *gamma, const float *beta, float eps,
@@ -183,7 +211,7 @@ int avc_scatter_volume(avc_ctx *ctx, const uint8_t *valid, int64_t N, const floa
 {
     AVC_REQUIRE(ctx && valid && vol && N > 0, AVC_ERR_ARG, "avc_scatter_volume: NULL argument or N <= 0");
     AVC_HIP(hipSetDevice(ctx->device));
-    return launch_scatter(valid, N, values, fill, vol, (hipStream_t)stream);
+    return launch_scatter(ctx, valid, N, values, fill, vol, (hipStream_t)stream);
 }
 
 int avc_recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float bounds[6], float iso,

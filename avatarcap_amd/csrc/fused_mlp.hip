@@ -51,7 +51,21 @@
 #define AVC_DBG_NO_LDSREAD 0      // A fragments read once per chunk instead of once per k-step
 #endif
 
+// Opt-in range check (a second build of this file with -DAVC_CHECK_RANGE=1, selected at run time by avc_set_range_check): every value
+// that is about to be split into fp16 halves -- sampled features, positional encodings, every post-activation value of every layer -- feeds
+// a running max of magnitudes; a value above 65504 would become +-inf in its `hi` half and silently poison what follows (a ReLU swallows the
+// NaN again), so the launch raises a flag instead and the query returns AVC_ERR_RANGE.  Costs one VALU per value pair: off by default.
+#ifndef AVC_CHECK_RANGE
+#define AVC_CHECK_RANGE 0
+#endif
+#if AVC_CHECK_RANGE
+#define AVC_FLAVOUR checked
+#else
+#define AVC_FLAVOUR plain
+#endif
+
 namespace avc {
+namespace AVC_FLAVOUR {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -88,6 +102,39 @@ struct QueryParams {
     float *out2;             // rgba (n,4) or null
     int sigmoid_occ;
     int64_t ntiles;
+    // dense-grid mode (pts == nullptr): point i = (gx[i / (gry*grz)], gy[(i / grz) % gry], gz[i % grz]) -- the flat order of
+    // AvatarCapDataset.generate_volume_points (dataset/avatarcap_dataset.py:312-326); the three axis tables hold lin * (b1 - b0) + b0
+    const float *gx, *gy, *gz;
+    unsigned gry, grz;
+    unsigned *range_flag;    // AVC_CHECK_RANGE builds: set to 1 when a value left the fp16 range
+};
+
+__device__ __forceinline__ void load_point(const QueryParams &p, int64_t pidx, float pt[3])
+{
+    if (p.pts) {
+        pt[0] = p.pts[pidx * 3 + 0]; pt[1] = p.pts[pidx * 3 + 1]; pt[2] = p.pts[pidx * 3 + 2];
+    } else {
+        const unsigned i = (unsigned)pidx, yz = p.gry * p.grz;
+        const unsigned ix = i / yz, r = i - ix * yz, iy = r / p.grz, iz = r - iy * p.grz;
+        pt[0] = p.gx[ix]; pt[1] = p.gy[iy]; pt[2] = p.gz[iz];
+    }
+}
+
+// running max of the magnitudes that go through an fp16 split (AVC_CHECK_RANGE builds only)
+struct RangeTrack {
+    float amax = 0.0f;
+    __device__ __forceinline__ void see(float a, float b)
+    {
+#if AVC_CHECK_RANGE
+        amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));
+#endif
+    }
+    __device__ __forceinline__ void report(const QueryParams &p) const
+    {
+#if AVC_CHECK_RANGE
+        if (!(amax <= 65504.0f) && p.range_flag) atomicOr(p.range_flag, 1u);
+#endif
+    }
 };
 
 template <int... Is, class F>
@@ -140,6 +187,7 @@ __device__ __forceinline__ void park_store(unsigned base, int k, const Frag &f)
 // weight stream: 2-slot LDS ring, one chunk of prefetch, sizes known at compile time
 // ------------------------------------------------------------------------------------------
 struct Stream {
+    RangeTrack range;
     __amdgpu_buffer_rsrc_t rs;   // buffer resource over the weight stream (LDS-DMA source)
     const char *gs;          // weight stream (wave-uniform)
     unsigned total;          // bytes per pass
@@ -190,8 +238,10 @@ __device__ __forceinline__ void pf_dma(__amdgpu_buffer_rsrc_t rs, unsigned so, u
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int g = I / 4, j = I % 4, pw = pf_group_bytes(BYTES, g) / WAVES;
-    const unsigned rel = g * GROUP + wave * pw + j * 1024;                         // scalar
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + (dst + rel)), 16, (int)lane16, (int)(so + rel), 0, 0);
+    // the instruction's immediate offset is added to BOTH the LDS and the memory address (tools/ubench/dma_semantics.hip), and the stream
+    // layout is the LDS layout: M0 and soffset are set once per group, the four pieces differ only in the immediate
+    const unsigned rel = g * GROUP + wave * pw;                                    // scalar
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(smem + (dst + rel)), 16, (int)lane16, (int)(so + rel), j * 1024, 0);
 }
 
 // work of issue slot SLOT: start the pieces scheduled here
@@ -255,6 +305,9 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
         constexpr int k = decltype(kc)::value;
         constexpr int cur = k & 1, nxt = cur ^ 1;
         // ---- slot 0
+        // ONE wait for this k-step's operands (requested a whole k-step ago), before the next k-step's reads go out: hipcc would otherwise put
+        // a counted `s_waitcnt lgkmcnt(n)` in front of every MFMA that touches a freshly read fragment, four issue slots per k-step
+        __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0), vmcnt / expcnt untouched
         if constexpr (k + 1 < KS) {
             b[nxt] = in.template get<k + 1>();
 #pragma unroll
@@ -386,11 +439,12 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigne
         : "v"(hi), "v"(x0), "v"(x1));
 }
 
-__device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo)
+__device__ __forceinline__ void split8(const float *v, u32x4 &hi, u32x4 &lo, RangeTrack &range)
 {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         unsigned h, l;
+        range.see(v[2 * e], v[2 * e + 1]);
         split2(v[2 * e], v[2 * e + 1], h, l);
         hi[e] = h; lo[e] = l;
     }
@@ -406,7 +460,7 @@ template <int PPS>
 struct EpiRegs { float x[2 * PPS]; float e[2 * PPS]; unsigned hi[PPS], lo[PPS]; };
 
 template <int ACT, int NS, int K, int R>
-__device__ __forceinline__ void epi_part(const f32x16 *__restrict__ acc, Frag *__restrict__ out4, EpiRegs<(16 + NS - 1) / NS> &st)
+__device__ __forceinline__ void epi_part(const f32x16 *__restrict__ acc, Frag *__restrict__ out4, EpiRegs<(16 + NS - 1) / NS> &st, RangeTrack &range)
 {
     constexpr int PPS = (16 + NS - 1) / NS;          // value PAIRS per slice (16 pairs per lane)
     static_for<PPS>([&](auto ic) {
@@ -415,7 +469,7 @@ __device__ __forceinline__ void epi_part(const f32x16 *__restrict__ acc, Frag *_
             constexpr int v = 2 * pr, t = v >> 4, r = v & 15;
             float &x0 = st.x[2 * i], &x1 = st.x[2 * i + 1], &e0 = st.e[2 * i], &e1 = st.e[2 * i + 1];
             auto write_out = [&]() { out4[2 * t + (r >> 3)].hi[(r & 7) >> 1] = st.hi[i]; out4[2 * t + (r >> 3)].lo[(r & 7) >> 1] = st.lo[i]; };
-            auto cvt = [&]() { const half2_t hv = {(_Float16)x0, (_Float16)x1}; st.hi[i] = __builtin_bit_cast(unsigned, hv); };
+            auto cvt = [&]() { range.see(x0, x1); const half2_t hv = {(_Float16)x0, (_Float16)x1}; st.hi[i] = __builtin_bit_cast(unsigned, hv); };
             if constexpr (ACT == ACT_SOFTPLUS) {
                 if constexpr (R == 0) { x0 = acc[t][r]; x1 = acc[t][r + 1]; e0 = __builtin_amdgcn_exp2f(-__builtin_fabsf(x0)); e1 = __builtin_amdgcn_exp2f(-__builtin_fabsf(x1)); }
                 else if constexpr (R == 1) { e0 = e0 + 1.0f; e1 = e1 + 1.0f; }
@@ -446,9 +500,10 @@ template <int ACT, int NS>
 struct Pending {
     const f32x16 *acc;
     Frag *out4;
+    RangeTrack *range;
     EpiRegs<(16 + NS - 1) / NS> st;
     template <class KC, class RC>
-    __device__ __forceinline__ void operator()(KC, RC) { epi_part<ACT, NS, KC::value, RC::value>(acc, out4, st); }
+    __device__ __forceinline__ void operator()(KC, RC) { epi_part<ACT, NS, KC::value, RC::value>(acc, out4, st, *range); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -482,7 +537,7 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
         } else {
             chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc, auto rc) {
                 if constexpr (decltype(kc)::value == 0 && decltype(rc)::value == 5) bias.after_barrier(h);
-                epi_part<ACT, NS, decltype(kc)::value, decltype(rc)::value>(prev, out + 4 * (p - 1), est);
+                epi_part<ACT, NS, decltype(kc)::value, decltype(rc)::value>(prev, out + 4 * (p - 1), est, s.range);
             });
         }
         if constexpr (KS1 > 0) {
@@ -496,10 +551,10 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
 
 // run a deferred epilogue right away (no chunk to hide it in)
 template <int ACT>
-__device__ __forceinline__ void flush(const f32x16 *__restrict__ pend, Frag *__restrict__ out4)
+__device__ __forceinline__ void flush(const f32x16 *__restrict__ pend, Frag *__restrict__ out4, RangeTrack &range)
 {
     EpiRegs<4> st;
-    static_for<4>([&](auto kc) { static_for<6>([&](auto rc) { epi_part<ACT, 4, decltype(kc)::value, decltype(rc)::value>(pend, out4, st); }); });
+    static_for<4>([&](auto kc) { static_for<6>([&](auto rc) { epi_part<ACT, 4, decltype(kc)::value, decltype(rc)::value>(pend, out4, st, range); }); });
 }
 
 // one-tile linear head (rows 0..31 of which only the first few are real): the three products of a
@@ -576,7 +631,7 @@ __device__ __forceinline__ Bilinear bilinear_setup(const float *__restrict__ fea
 }
 
 // 8 consecutive channels starting at channel offset c (relative to c0) -> one split fragment
-__device__ __forceinline__ void bilinear_frag(const Bilinear &b, int c, Frag &f)
+__device__ __forceinline__ void bilinear_frag(const Bilinear &b, int c, Frag &f, RangeTrack &range)
 {
     float v[8];
 #pragma unroll
@@ -588,7 +643,7 @@ __device__ __forceinline__ void bilinear_frag(const Bilinear &b, int c, Frag &f)
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[4 * q + i] = a[i] * b.w00 + bb[i] * b.w01 + cc[i] * b.w10 + d[i] * b.w11;
     }
-    split8(v, f.hi, f.lo);
+    split8(v, f.hi, f.lo, range);
 }
 
 // sin and cos of q * S for S = 2^f, to ~1.6e-7 absolute (tools: see DESIGN.md section 2) in ~25 VALU
@@ -620,7 +675,7 @@ __device__ __forceinline__ void sincos_pow2(float q, float S, float &sn, float &
 // NeRF positional encoding of q (3 floats) into the 4 k-steps of the PE layout (mlp_layout.h):
 // lane-half h evaluates arguments 15h .. 15h+14: coordinate i%3, frequency 2^(5h + i/3) -- exact
 // power-of-two scaling like the reference's x * freq (net_util.py:27-33).
-__device__ __forceinline__ void posenc(const float q[3], int h, unsigned park)
+__device__ __forceinline__ void posenc(const float q[3], int h, unsigned park, RangeTrack &range)
 {
     float v[32];
     const float hs = h ? 32.0f : 1.0f;
@@ -640,7 +695,7 @@ __device__ __forceinline__ void posenc(const float q[3], int h, unsigned park)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         Frag f;
-        split8(v + 8 * k, f.hi, f.lo);
+        split8(v + 8 * k, f.hi, f.lo, range);
         park_store(park, k, f);
     }
 }
@@ -693,7 +748,7 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         const int64_t pidx_raw = tile * TILE_PTS + wave * 32 + j;
         const int64_t pidx = pidx_raw < p.n ? pidx_raw : p.n - 1;
         float pt[3];
-        pt[0] = p.pts[pidx * 3 + 0]; pt[1] = p.pts[pidx * 3 + 1]; pt[2] = p.pts[pidx * 3 + 2];
+        load_point(p, pidx, pt);
 
         Frag X[16], Y[16];
         unsigned park = PARK_BASE + wave * PARK_PER_WAVE + lane * 16;
@@ -710,47 +765,47 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             {
                 const Bilinear bl = bilinear_setup<64>(p.feat, p.H, p.W, pt[0] - p.cx, -(pt[1] - p.cy), 32 * h);   // :125-133
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { Frag f; bilinear_frag(bl, 8 * k, f); park_store(park, k, f); __builtin_amdgcn_sched_barrier(0); }
+                for (int k = 0; k < 4; ++k) { Frag f; bilinear_frag(bl, 8 * k, f, s.range); park_store(park, k, f); __builtin_amdgcn_sched_barrier(0); }
                 float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (h == 0) { z[0] = pt[0]; z[1] = pt[1]; z[2] = pt[2]; }
-                split8(z, S4.hi, S4.lo);
+                split8(z, S4.hi, S4.lo, s.range);
             }
             const ParkIn S{park, &S4};
             const RegIn RX{X}, RY{Y};
             using SP = Pending<ACT_SOFTPLUS, 8>;
             dense<8, layout::IN67_KS, 0, ACT_SOFTPLUS, B_MAIN>(s, S, S, X, bias, h, NoSide{}, pa);                       // conv1+bn1
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12}, pb);                        // conv2
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RY, RY, X, bias, h, SP{pb, Y + 12}, pa);                        // conv3
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12}, pb);                        // conv4
-            dense<8, 16, layout::IN67_KS, ACT_SOFTPLUS, B_MAIN>(s, RY, S, X, bias, h, SP{pb, Y + 12}, pa);           // conv5 on [x0|x4]
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12}, pb);                        // conv6
-            dense<8, 16, 0, ACT_SOFTPLUS, B_HEAD16>(s, RY, RY, X, bias, h, SP{pb, Y + 12}, pa);                      // conv7
-            const f32x16 o = head<16, B_PE, false>(s, X, bias, bias_head, h, SP{pa, X + 12});                                  // out_layer_coord_affine
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                        // conv2
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RY, RY, X, bias, h, SP{pb, Y + 12, &s.range}, pa);                        // conv3
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                        // conv4
+            dense<8, 16, layout::IN67_KS, ACT_SOFTPLUS, B_MAIN>(s, RY, S, X, bias, h, SP{pb, Y + 12, &s.range}, pa);           // conv5 on [x0|x4]
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                        // conv6
+            dense<8, 16, 0, ACT_SOFTPLUS, B_HEAD16>(s, RY, RY, X, bias, h, SP{pb, Y + 12, &s.range}, pa);                      // conv7
+            const f32x16 o = head<16, B_PE, false>(s, X, bias, bias_head, h, SP{pa, X + 12, &s.range});                                  // out_layer_coord_affine
             // rows 0..2 live in lanes h == 0, regs 0..2: broadcast to the other half
             off[0] = __shfl(o[0], j, 64); off[1] = __shfl(o[1], j, 64); off[2] = __shfl(o[2], j, 64);
             q[0] = pt[0] + off[0]; q[1] = pt[1] + off[1]; q[2] = pt[2] + off[2];                                       // arch_avatar.py:372 (fp32 add)
         }
 
         // ---- DoubleTNet.forward (arch_avatar.py:65-83) ----
-        posenc(q, h, park);                                                                                            // :70 (parked in LDS)
+        posenc(q, h, park, s.range);                                                                                            // :70 (parked in LDS)
         const ParkIn P{park, nullptr};
         const RegIn TX{X}, TY{Y};
         using RP = Pending<ACT_RELU, 8>;
         dense<8, layout::PE_KS, 0, ACT_RELU, B_MAIN>(s, P, P, X, bias, h, NoSide{}, pa);                                 // shared 0
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12}, pb);
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TY, TY, X, bias, h, RP{pb, Y + 12}, pa);
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12}, pb);
-        dense<8, 16, layout::PE_KS, ACT_RELU, B_MAIN>(s, TY, P, X, bias, h, RP{pb, Y + 12}, pa);                     // shared 4 on [x|x0]
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12}, pb);                                                       // shared 5
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12, &s.range}, pb);
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TY, TY, X, bias, h, RP{pb, Y + 12, &s.range}, pa);
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12, &s.range}, pb);
+        dense<8, 16, layout::PE_KS, ACT_RELU, B_MAIN>(s, TY, P, X, bias, h, RP{pb, Y + 12, &s.range}, pa);                     // shared 4 on [x|x0]
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12, &s.range}, pb);                                                       // shared 5
         f32x16 g;
         if constexpr (COLOUR) {
-            dense<8, 16, 0, ACT_NONE, B_MAIN>(s, TY, TY, X, bias, h, RP{pb, Y + 12}, pa);                                // shared 6: no activation (mlp.py:46,64)
-            dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TX, TX, Y, bias, h, Pending<ACT_NONE, 8>{pa, X + 12}, pb);           // geo 0
-            g = head<8, B_MAIN, false>(s, Y, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pb, Y + 4});                      // geo 1: row 0 = occ/sdf, row 1 = sigma
+            dense<8, 16, 0, ACT_NONE, B_MAIN>(s, TY, TY, X, bias, h, RP{pb, Y + 12, &s.range}, pa);                                // shared 6: no activation (mlp.py:46,64)
+            dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TX, TX, Y, bias, h, Pending<ACT_NONE, 8>{pa, X + 12, &s.range}, pb);           // geo 0
+            g = head<8, B_MAIN, false>(s, Y, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pb, Y + 4, &s.range});                      // geo 1: row 0 = occ/sdf, row 1 = sigma
         } else {
             // geometry only: pack.cpp folded shared.6 (linear) into geo.0 -- one 256->128 layer instead of two
-            dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TY, TY, X, bias, h, RP{pb, Y + 12}, pa);                              // geo 0 o shared 6
-            g = head<8, B_FIRST, true>(s, X, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pa, X + 4});                      // geo 1
+            dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TY, TY, X, bias, h, RP{pb, Y + 12, &s.range}, pa);                              // geo 0 o shared 6
+            g = head<8, B_FIRST, true>(s, X, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pa, X + 4, &s.range});                      // geo 1
         }
 
         const bool writer = (h == 0) && (pidx_raw < p.n);
@@ -761,14 +816,15 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         if constexpr (COLOUR) {
             // X (the shared feature) is complete: its last pair was finished inside geo 0's first chunk
             dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, NoSide{}, pa);                                      // clr 0
-            dense<4, 16, 0, ACT_RELU, B_HEAD8>(s, TY, TY, X, bias, h, RP{pa, Y + 12}, pb);                           // clr 1
-            const f32x16 c = head<8, B_FIRST, true>(s, X, bias, bias_head, h, Pending<ACT_RELU, 4>{pb, X + 4});                        // clr 2
+            dense<4, 16, 0, ACT_RELU, B_HEAD8>(s, TY, TY, X, bias, h, RP{pa, Y + 12, &s.range}, pb);                           // clr 1
+            const f32x16 c = head<8, B_FIRST, true>(s, X, bias, bias_head, h, Pending<ACT_RELU, 4>{pb, X + 4, &s.range});                        // clr 2
             if (writer && p.out2) {
                 f32x4 rgba = {sigmoid_f(c[0]), sigmoid_f(c[1]), sigmoid_f(c[2]), __builtin_fmaxf(g[1], 0.0f)};         // :75-76
                 *reinterpret_cast<f32x4 *>(p.out2 + pidx_raw * 4) = rgba;
             }
         }
     }
+    s.range.report(p);
 #if AVC_DBG_TIMING
     if (lane == 0 && p.out1) {     // debug: overwrite the head of the offsets buffer with (total, barrier) cycles per wave
         long long *dbg = reinterpret_cast<long long *>(p.out1) + 2 * (blockIdx.x * 4 + wave);
@@ -796,16 +852,18 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int64_t pidx_raw = tile * TILE_PTS + wave * 32 + j;
         const int64_t pidx = pidx_raw < p.n ? pidx_raw : p.n - 1;
-        const float px = p.pts[pidx * 3 + 0] - p.cx, py = p.pts[pidx * 3 + 1] - p.cy, pz = p.pts[pidx * 3 + 2] - p.cz;   // :62
+        float pt[3];
+        load_point(p, pidx, pt);
+        const float px = pt[0] - p.cx, py = pt[1] - p.cy, pz = pt[2] - p.cz;   // :62
 
         Frag I[layout::IN33_KS];
         {
             const Bilinear bl = bilinear_setup<32>(p.feat, p.H, p.W, px, -py, 16 * h);            // :63-68
-            bilinear_frag(bl, 0, I[0]);
-            bilinear_frag(bl, 8, I[1]);
+            bilinear_frag(bl, 0, I[0], s.range);
+            bilinear_frag(bl, 8, I[1], s.range);
             float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (h == 0) z[0] = pz;                                                               // :69
-            split8(z, I[2].hi, I[2].lo);
+            split8(z, I[2].hi, I[2].lo, s.range);
         }
         Frag X[16], Y[16];
         const RegIn RI{I}, RX{X}, RY{Y};
@@ -815,7 +873,7 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
         f32x16 acc[8];
         // fc0 rows 0..255
         dense<8, layout::IN33_KS, 0, ACT_LEAKY, B_WIDE4>(s, RI, RI, X, bias, h, NoSide{}, pend);
-        flush<ACT_LEAKY>(pend, X + 12);
+        flush<ACT_LEAKY>(pend, X + 12, s.range);
         // fc1 partial over x[0..255]: 8 tiles live, 4 k-steps per chunk
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] = bias_tile(bias.p + 32 * t, h);
@@ -826,7 +884,7 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
         chunk<4, 8, B_IN33>(s, RegIn{X + 12}, acc, NoSide{});
         // fc0 rows 256..511
         dense<8, layout::IN33_KS, 0, ACT_LEAKY, B_WIDE4>(s, RI, RI, X, bias, h, NoSide{}, pend);
-        flush<ACT_LEAKY>(pend, X + 12);
+        flush<ACT_LEAKY>(pend, X + 12, s.range);
         bias.p += 256;   // (zero bias block of the second fc1 pack call)
         chunk<4, 8, B_WIDE4>(s, RegIn{X}, acc, NoSide{});
         chunk<4, 8, B_WIDE4>(s, RegIn{X + 4}, acc, NoSide{});
@@ -834,12 +892,13 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
         chunk<4, 8, B_WIDE_IN33>(s, RegIn{X + 12}, acc, NoSide{});
         chunk<layout::IN33_KS, 8, B_MAIN>(s, RI, acc, NoSide{});
 #pragma unroll
-        for (int t = 0; t < 8; t += 2) flush<ACT_LEAKY>(acc + t, Y + 2 * t);
+        for (int t = 0; t < 8; t += 2) flush<ACT_LEAKY>(acc + t, Y + 2 * t, s.range);
         // fc2 on [x(256) | in(33)] -> 128
         dense<4, 16, layout::IN33_KS, ACT_LEAKY, B_HEAD8>(s, RY, RI, X, bias, h, NoSide{}, pend);
-        const f32x16 o = head<8, B_IN33, true>(s, X, bias, p.bias, h, Pending<ACT_LEAKY, 4>{pend, X + 4});
+        const f32x16 o = head<8, B_IN33, true>(s, X, bias, p.bias, h, Pending<ACT_LEAKY, 4>{pend, X + 4, &s.range});
         if (h == 0 && pidx_raw < p.n) p.out0[pidx_raw] = sigmoid_f(o[0]);                         // last_op sigmoid
     }
+    s.range.report(p);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -873,7 +932,43 @@ static unsigned bytes_until(const PackedNet &net, size_t nchunks)
     return b;
 }
 
-int launch_avatar(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], int occ_sigmoid,
+static int fill_points(QueryParams &p, avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const char *who)
+{
+    p.pts = pts; p.n = n;
+    if (grid) {
+        AVC_REQUIRE(grid->x && grid->y && grid->z && grid->res[0] > 0 && grid->res[1] > 0 && grid->res[2] > 0, AVC_ERR_ARG, "%s: bad grid descriptor", who);
+        AVC_REQUIRE((int64_t)grid->res[0] * grid->res[1] * grid->res[2] == n && n < ((int64_t)1 << 31), AVC_ERR_ARG,
+                    "%s: grid of %d x %d x %d points does not match n = %lld (or exceeds 2^31)", who, grid->res[0], grid->res[1], grid->res[2], (long long)n);
+        p.pts = nullptr; p.gx = grid->x; p.gy = grid->y; p.gz = grid->z; p.gry = (unsigned)grid->res[1]; p.grz = (unsigned)grid->res[2];
+    }
+#if AVC_CHECK_RANGE
+    if (!ctx->range_flag_dev) AVC_HIP(hipMalloc((void **)&ctx->range_flag_dev, sizeof(unsigned)));
+    p.range_flag = ctx->range_flag_dev;
+#endif
+    return AVC_OK;
+}
+
+// AVC_CHECK_RANGE builds: clear the flag before the launch, read it back (synchronously) after
+static int range_begin(avc_ctx *ctx, hipStream_t s)
+{
+#if AVC_CHECK_RANGE
+    AVC_HIP(hipMemsetAsync(ctx->range_flag_dev, 0, sizeof(unsigned), s));
+#endif
+    return AVC_OK;
+}
+static int range_end(avc_ctx *ctx, hipStream_t s, const char *who)
+{
+#if AVC_CHECK_RANGE
+    unsigned flag = 0;
+    AVC_HIP(hipMemcpyAsync(&flag, ctx->range_flag_dev, sizeof flag, hipMemcpyDeviceToHost, s));
+    AVC_HIP(hipStreamSynchronize(s));
+    AVC_REQUIRE(flag == 0, AVC_ERR_RANGE, "%s: a feature or activation exceeded 65504 in magnitude -- outside the range of the split-fp16 "
+                "arithmetic (include/avcap.h, 'numeric range'); the outputs of this call are not valid", who);
+#endif
+    return AVC_OK;
+}
+
+int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], int occ_sigmoid,
                   float *occ, float *offset, float *rgba, bool template_only, hipStream_t s)
 {
     const bool colour = rgba != nullptr;
@@ -884,53 +979,61 @@ int launch_avatar(avc_ctx *ctx, const float *pts, int64_t n, const float center[
     AVC_REQUIRE(template_only || ctx->pose_feat_hwc, AVC_ERR_STATE, "avatar query: pose feature map not set (WarpingField.precompute_conv)");
     if (n == 0) return AVC_OK;
     QueryParams p{};
-    p.pts = pts; p.n = n; p.feat = ctx->pose_feat_hwc; p.H = ctx->pose_H; p.W = ctx->pose_W;
+    int rc = fill_points(p, ctx, pts, grid, n, "avatar query");
+    if (rc) return rc;
+    p.feat = ctx->pose_feat_hwc; p.H = ctx->pose_H; p.W = ctx->pose_W;
     p.cx = center ? center[0] : 0.f; p.cy = center ? center[1] : 0.f; p.cz = center ? center[2] : 0.f;
     p.wstream = (const char *)net.d_stream; p.bias = net.d_bias;
     p.out0 = occ; p.out1 = offset; p.out2 = rgba; p.sigmoid_occ = occ_sigmoid;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;
     p.stream_bytes = bytes_until(net, net.chunks.size());
     const char *gb = getenv("AVC_MLP_BLOCKS");           // experiment knob: persistent workgroups (default: one per CU)
-    const int grid = (int)std::min<int64_t>(p.ntiles, gb && atoi(gb) > 0 ? atoi(gb) : ctx->num_cus);
+    const int grid_dim = (int)std::min<int64_t>(p.ntiles, gb && atoi(gb) > 0 ? atoi(gb) : ctx->num_cus);
+    rc = range_begin(ctx, s);
+    if (rc) return rc;
     hipEvent_t e0, e1;
     timing_begin(ctx, 0, s, e0, e1);
-    int rc = AVC_OK;
 #define LAUNCH(W_, C_)                                                                              \
     do {                                                                                            \
         rc = set_lds(avatar_kernel<W_, C_>);                                                        \
         if (rc) return rc;                                                                          \
-        hipLaunchKernelGGL((avatar_kernel<W_, C_>), dim3(grid), dim3(256), LDS_BYTES, s, p);       \
+        hipLaunchKernelGGL((avatar_kernel<W_, C_>), dim3(grid_dim), dim3(256), LDS_BYTES, s, p);   \
     } while (0)
     if (template_only) { if (colour) LAUNCH(false, true); else LAUNCH(false, false); }
     else               { if (colour) LAUNCH(true, true);  else LAUNCH(true, false); }
 #undef LAUNCH
     AVC_HIP(hipGetLastError());
     timing_end(ctx, 0, s, e0, e1);
-    return AVC_OK;
+    return range_end(ctx, s, "avatar query");
 }
 
-int launch_recon(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], float *out, hipStream_t s)
+int launch_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], float *out, hipStream_t s)
 {
     PackedNet &net = ctx->recon;
     AVC_REQUIRE(net.ready, AVC_ERR_STATE, "recon query: weights not packed (call avc_pack_recon_weights)");
     AVC_REQUIRE(ctx->img_feat_hwc, AVC_ERR_STATE, "recon query: image feature map not set");
     if (n == 0) return AVC_OK;
     QueryParams p{};
-    p.pts = pts; p.n = n; p.feat = ctx->img_feat_hwc; p.H = ctx->img_H; p.W = ctx->img_W;
+    int rc = fill_points(p, ctx, pts, grid, n, "recon query");
+    if (rc) return rc;
+    p.feat = ctx->img_feat_hwc; p.H = ctx->img_H; p.W = ctx->img_W;
     p.cx = center[0]; p.cy = center[1]; p.cz = center[2];
     p.wstream = (const char *)net.d_stream; p.bias = net.d_bias;
     p.stream_bytes = bytes_until(net, net.chunks.size());
     p.out0 = out;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;
-    const int grid = (int)std::min<int64_t>(p.ntiles, ctx->num_cus);
-    int rc = set_lds(recon_kernel);
+    const int grid_dim = (int)std::min<int64_t>(p.ntiles, ctx->num_cus);
+    rc = set_lds(recon_kernel);
+    if (rc) return rc;
+    rc = range_begin(ctx, s);
     if (rc) return rc;
     hipEvent_t e0, e1;
     timing_begin(ctx, 1, s, e0, e1);
-    hipLaunchKernelGGL(recon_kernel, dim3(grid), dim3(256), LDS_BYTES, s, p);
+    hipLaunchKernelGGL(recon_kernel, dim3(grid_dim), dim3(256), LDS_BYTES, s, p);
     AVC_HIP(hipGetLastError());
     timing_end(ctx, 1, s, e0, e1);
-    return AVC_OK;
+    return range_end(ctx, s, "recon query");
 }
 
+}  // namespace AVC_FLAVOUR
 }  // namespace avc

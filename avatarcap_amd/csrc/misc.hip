@@ -102,17 +102,16 @@ __global__ void scatter_write_kernel(const uint8_t *__restrict__ valid, int64_t 
     }
 }
 
-static unsigned *g_scatter_scratch = nullptr;
-static size_t g_scatter_cap = 0;
-
-int launch_scatter(const uint8_t *valid, int64_t N, const float *values, const float *fill, float *vol, hipStream_t s)
+int launch_scatter(avc_ctx *ctx, const uint8_t *valid, int64_t N, const float *values, const float *fill, float *vol, hipStream_t s)
 {
     const int nblocks = (int)((N + 1023) / 1024);
-    if ((size_t)nblocks > g_scatter_cap) {
-        if (g_scatter_scratch) hipFree(g_scatter_scratch);
-        AVC_HIP(hipMalloc((void **)&g_scatter_scratch, sizeof(unsigned) * nblocks));
-        g_scatter_cap = nblocks;
+    if (sizeof(unsigned) * (size_t)nblocks > ctx->scatter_scratch_bytes) {        // per-context (per-device) block counts
+        if (ctx->scatter_scratch) AVC_HIP(hipFree(ctx->scatter_scratch));
+        ctx->scatter_scratch = nullptr; ctx->scatter_scratch_bytes = 0;
+        AVC_HIP(hipMalloc(&ctx->scatter_scratch, sizeof(unsigned) * (size_t)nblocks));
+        ctx->scatter_scratch_bytes = sizeof(unsigned) * (size_t)nblocks;
     }
+    unsigned *g_scatter_scratch = (unsigned *)ctx->scatter_scratch;
     hipLaunchKernelGGL(scatter_count_kernel, dim3(nblocks), dim3(256), 0, s, valid, N, g_scatter_scratch);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, g_scatter_scratch, nblocks);
     hipLaunchKernelGGL(scatter_write_kernel, dim3(nblocks), dim3(256), 0, s, valid, N, g_scatter_scratch, values, fill, vol);

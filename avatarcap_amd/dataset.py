@@ -16,7 +16,7 @@ import torch
 
 from . import config
 from . import synthetic as syn
-from .grid import generate_volume_points
+from .grid import generate_volume_points, volume_axes
 
 
 class SyntheticTestDataset:
@@ -34,6 +34,7 @@ class SyntheticTestDataset:
 
         vol_pts = generate_volume_points(self.cano_bounds, self.vol_res, self.device)     # :111
         N = vol_pts.shape[0]
+        self.grid_axes = volume_axes(self.cano_bounds, self.vol_res, self.device)        # per-axis tables of the same grid (avc_avatar_query_grid)
         if valid == 'dense':
             self.infer_pts_flag = torch.ones(N, dtype=torch.bool, device=self.device)
             self.infer_pts = vol_pts

@@ -33,6 +33,22 @@ def generate_volume_points_np(bounds: np.ndarray, res) -> np.ndarray:
     return (pts * (bounds[1] - bounds[0]) + bounds[0]).astype(np.float32)
 
 
+def volume_axes_np(bounds: np.ndarray, res):
+    """The three per-axis coordinate tables of the grid: axis_a[k] = lin_a[k] * (b1_a - b0_a) + b0_a with the reference's float32
+    roundings (one for the product, one for the sum -- avatarcap_dataset.py:323), so that point i = x*Ry*Rz + y*Rz + z of
+    generate_volume_points_np equals (axis_x[x], axis_y[y], axis_z[z]) bit for bit.  Input of avc_avatar_query_grid."""
+    bounds = np.asarray(bounds, np.float32)
+    ln = (bounds[1] - bounds[0]).astype(np.float32)
+    return tuple((linspace01_f32(int(r)) * ln[a] + bounds[0][a]).astype(np.float32) for a, r in enumerate(res))
+
+
+def volume_axes(bounds, res, device=None):
+    import torch
+    from . import config
+    device = device if device is not None else config.device
+    return tuple(torch.from_numpy(a).to(device) for a in volume_axes_np(bounds, res))
+
+
 def generate_volume_points(bounds, testing_res=(256, 256, 256), device=None):
     """Reference signature (avatarcap_dataset.py:312): (N,3) float32 tensor on `device`.  Built on the
     host with the bit-exact restatement above and uploaded once per sequence, so the query points are

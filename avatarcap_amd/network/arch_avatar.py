@@ -99,12 +99,13 @@ class WarpingField(nn.Module):
     def bind_map(self, ctx, b):
         if self.pose_feat_map is None:
             raise AttributeError('pose_feat_map is None: call WarpingField.precompute_conv(batch) first')
-        key = (self.pose_feat_map.data_ptr(), b)
-        if self._map_on_device != key:
+        key = (id(self), self.pose_feat_map.data_ptr(), self.pose_feat_map._version, b)
+        if self._map_on_device != key or not _lib.owns(ctx, 'pose_map', key):
             m = self.pose_feat_map[b]
             _lib.check(_lib.lib().avc_set_pose_feat_map(ctx, _lib.dev_ptr(m, name='pose_feat_map'), m.shape[0], m.shape[1], m.shape[2],
                                                         _lib.stream_ptr(m.device)))
             self._map_on_device = key
+            _lib.set_owner(ctx, 'pose_map', key)
 
     def query(self, pts, batch):
         """pts (B,N,3) -> offsets (B,N,3)  (arch_avatar.py:113-140)."""
@@ -155,11 +156,13 @@ class GeoTexAvatar(nn.Module):
 
     def _ctx(self, device):
         ctx = _lib.ctx(device)
-        ver = (ctx, self._weights_version())
-        if self._packed_version != ver:
+        ver = (ctx, id(self), self._weights_version())
+        if self._packed_version != ver or not _lib.owns(ctx, 'avatar', ver):     # another network may have packed into this context since
             self.warping_field.pack_into(ctx)
             self.cano_template.pack_into(ctx)
             self._packed_version = ver
+            _lib.set_owner(ctx, 'avatar', ver)
+        _lib.apply_range_check(ctx)
         return ctx
 
     def _avatar_query(self, pts, batch, want_offset=True, want_rgba=False):
@@ -286,3 +289,29 @@ class OccupancyNet:
         must have run.  -> {'cano_pts_ov': (B,N,1), 'nonrigid_offset': (B,N,3)}"""
         occ, off, _ = self.net._avatar_query(batch['cano_pts'], batch, want_offset=True, want_rgba=False)
         return {'cano_pts_ov': occ, 'nonrigid_offset': off}
+
+    def query_grid(self, batch, axes, res, want_offset=False):
+        """The same query on the whole dense grid without the (N,3) point tensor: `axes` = grid.volume_axes(bounds, res) (three device
+        tensors), point order as generate_volume_points.  Results are bit-identical to query() on the materialised points; the offsets
+        (which main.py:360-364 never reads) are only produced on request.  -> {'cano_pts_ov': (1,N,1)[, 'nonrigid_offset': (1,N,3)]}"""
+        net = self.net
+        res = [int(r) for r in res]
+        N = res[0] * res[1] * res[2]
+        dev = axes[0].device
+        ctx = net._ctx(dev)
+        if config.if_type not in ('sdf', 'occupancy'):
+            raise ValueError('Invalid config.if_type!')
+        occ = torch.empty((1, N, 1), dtype=torch.float32, device=dev)
+        off = torch.empty((1, N, 3), dtype=torch.float32, device=dev) if want_offset else None
+        net.warping_field.bind_map(ctx, 0)
+        for a, r in zip(axes, res):
+            if a.numel() != r:
+                raise ValueError(f'query_grid: axis table of {a.numel()} entries for a resolution of {r}')
+        _lib.check(_lib.lib().avc_avatar_query_grid(
+            ctx, _lib.dev_ptr(axes[0], name='axis_x'), _lib.dev_ptr(axes[1], name='axis_y'), _lib.dev_ptr(axes[2], name='axis_z'),
+            (C.c_int32 * 3)(*res), _lib.f3(batch['cano_smpl_center'][0]), 1 if config.if_type == 'occupancy' else 0,
+            occ.data_ptr(), off.data_ptr() if want_offset else None, _lib.stream_ptr(dev)))
+        out = {'cano_pts_ov': occ}
+        if want_offset:
+            out['nonrigid_offset'] = off
+        return out

@@ -30,11 +30,13 @@ class ReconNetwork(nn.Module):
 
     def _ctx(self, device):
         ctx = _lib.ctx(device)
-        ver = (ctx, tuple(p._version for p in self.image_decoder.parameters()))
-        if self._packed_version != ver:
+        ver = (ctx, id(self), tuple(p._version for p in self.image_decoder.parameters()))
+        if self._packed_version != ver or not _lib.owns(ctx, 'recon', ver):      # another ReconNetwork may have packed into this context since
             fc = _lib.DenseList(_mlp_entries(self.image_decoder))
             _lib.check(_lib.lib().avc_pack_recon_weights(ctx, fc.arr))
             self._packed_version = ver
+            _lib.set_owner(ctx, 'recon', ver)
+        _lib.apply_range_check(ctx)
         return ctx
 
     def infer(self, items):
@@ -58,4 +60,6 @@ class ReconNetwork(nn.Module):
                                                        _lib.stream_ptr(pts.device)))
             _lib.check(_lib.lib().avc_recon_query(ctx, _lib.dev_ptr(pts[b], name='cano_pts'), N, _lib.f3(center[b]),
                                                   out[b].data_ptr(), _lib.stream_ptr(pts.device)))
-        return out.squeeze(0) if B == 1 else out
+        # the reference concatenates (B,1,n) chunks and squeezes dim 0 (arch_recon.py:73-76): (1,N) for B == 1, which is what
+        # main.py:442 indexes with [0]; (B,1,N) otherwise
+        return out[:, None, :].squeeze(0)

@@ -1,7 +1,7 @@
 """The per-frame driver segment of `main.run_avatarcap` (main.py:357-367, 383-389, 438-453) with every
 tensor kept on the device: no `.cpu()` of the volume for marching cubes, no host round trip of the
-vertices for normals / LBS.  Rendering (OpenGL), image I/O and normal fusion are outside this path
-(SURVEY.md section 8(f)).
+vertices for normals / LBS.  Steps 1-4 of the loop body are here: avatar geometry, canonical normal maps + fusion with the
+image-observed normals, reconstruction, vertex colours; image file I/O stays with the caller.
 """
 from __future__ import annotations
 
@@ -44,7 +44,12 @@ class FramePipeline:
     def avatar_frame(self, items: dict, skin=True):
         """1. geometric avatar in canonical space (main.py:357-367) + skinning to live space (:383-389)."""
         self.network.warping_field.precompute_conv(items)                    # :359
-        out = self.occ_net.query(items)                                      # :360
+        if getattr(self.ds, 'valid_mode', None) == 'dense' and items['cano_pts'].shape[1] == self.ds.valid_u8.numel():
+            # every grid point is queried: the kernel generates the points from the grid index (no 12 B/point read) and the
+            # offsets, which :360-364 never read, are not written -- bit-identical occupancy (tests/test_gpu_pipeline.py)
+            out = self.occ_net.query_grid(items, self.ds.grid_axes, self.vol_res)
+        else:
+            out = self.occ_net.query(items)                                  # :360
         vol = fill_volume(out['cano_pts_ov'][0, :, 0], self.ds.valid_u8, self.ds.invalid_pts_ov)   # :362-364
         v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds, iso_value=config.iso_value)   # :367
         res = {'cano_v': v, 'cano_vn': n, 'f': f, 'occ_volume': vol}
@@ -83,7 +88,7 @@ class FramePipeline:
     def recon_frame(self, items: dict):
         """3. reconstruction network (main.py:438-453); items must hold front_normal / back_normal."""
         out = self.recon_net.infer(items)                                    # :440
-        vol = fill_volume(out.reshape(-1), self.ds.valid_u8, self.ds.invalid_pts_ov)               # :442-443
+        vol = fill_volume(out[0], self.ds.valid_u8, self.ds.invalid_pts_ov)                        # :442-443 (output[0])
         v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds)             # :444 (iso 0.5)
         res = {'cano_v': v, 'cano_vn': n, 'f': f, 'occ_volume': vol}
         if v.shape[0] > 0:

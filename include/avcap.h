@@ -33,7 +33,8 @@ enum avc_status {
     AVC_ERR_ARG = -1,      /* invalid argument (the reference would raise ValueError/TypeError) */
     AVC_ERR_STATE = -2,    /* weights / feature map not set (reference: AttributeError / ValueError) */
     AVC_ERR_HIP = -3,      /* a HIP runtime call failed */
-    AVC_ERR_CAPACITY = -4  /* caller-provided output capacity too small; required sizes are reported */
+    AVC_ERR_CAPACITY = -4, /* caller-provided output capacity too small; required sizes are reported */
+    AVC_ERR_RANGE = -5     /* range check on (avc_set_range_check): a value left the range of the split-fp16 arithmetic */
 };
 
 const char *avc_last_error(void);
@@ -96,6 +97,24 @@ int avc_group_norm(avc_ctx *ctx, const float *x_dev, int N, int C, int64_t HW, i
 int avc_avatar_query(avc_ctx *ctx, const float *pts_dev, int64_t n, const float center[3],
                      int occupancy_sigmoid, float *occ_out_dev, float *offset_out_dev,
                      float *rgba_out_dev, avc_stream stream);
+
+/* The same query on the dense canonical grid of AvatarCapDataset.generate_volume_points (dataset/avatarcap_dataset.py:312-326)
+ * WITHOUT materialising the (N,3) point array (201 MB at 256^3): point i = x*Ry*Rz + y*Rz + z has the coordinates
+ * (axis_x[x], axis_y[y], axis_z[z]), where axis_a[k] = linspace(0,1,R_a)[k] * (b1_a - b0_a) + b0_a in float32 -- the caller
+ * builds the three tables with the reference's own arithmetic (avatarcap_amd/grid.py: volume_axes), so the points are
+ * bit-identical to the reference's.  Outputs as above; offset_out_dev may be NULL (main.py:360-364 never reads it). */
+int avc_avatar_query_grid(avc_ctx *ctx, const float *axis_x_dev, const float *axis_y_dev, const float *axis_z_dev,
+                          const int32_t res[3], const float center[3], int occupancy_sigmoid,
+                          float *occ_out_dev, float *offset_out_dev, avc_stream stream);
+
+/* Numeric range.  The fused queries evaluate every float32 product as three fp16 x fp16 products with float32 accumulation
+ * (DESIGN.md section 2): weights are split on the host -- a packed weight above 3e4 in magnitude is refused with AVC_ERR_ARG --
+ * and every sampled feature, positional-encoding value and post-activation value is split on the fly, which requires
+ * |value| <= 65504 (Softplus layers carry y / ln 2).  The reference's float32 path has no such bound (network/mlp.py:90-110).
+ * avc_set_range_check(ctx, 1) switches the queries of this context to a build of the kernels that tracks the largest
+ * magnitude entering a split; a query then synchronises its stream and returns AVC_ERR_RANGE when the bound was exceeded
+ * (its outputs are not valid).  Off by default: the check costs one VALU instruction per value pair and the synchronisation. */
+int avc_set_range_check(avc_ctx *ctx, int enabled);
 
 /* DoubleTNet.forward alone on given points (pts_space == 'temp', arch_avatar.py:216-219) */
 int avc_template_query(avc_ctx *ctx, const float *pts_dev, int64_t n, int occupancy_sigmoid,
