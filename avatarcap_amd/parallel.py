@@ -51,14 +51,29 @@ def _pack(meshes, device):
     return counts, vbuf.to(torch.float32), fbuf
 
 
-def all_gather_meshes(meshes: list[dict], n_frames: int, group=None, force: bool = False) -> list[dict]:
-    """meshes: this rank's frames in ascending frame order, each {'v' (V,3) f32, 'vn' (V,3) f32,
-    'f' (F,3) i32}.  Returns, on every rank, all n_frames meshes in frame order."""
+def _collective_device(meshes, group, device):
+    """Device of the send / receive buffers: the meshes' own, else the caller's, else -- for a rank that owns no frame (fewer frames
+    than ranks) -- the current HIP device under the nccl (= RCCL) backend, which cannot move host tensors, and the host under gloo."""
+    if device is not None:
+        return torch.device(device)
+    if meshes:
+        return meshes[0]['v'].device
+    if dist.is_initialized() and dist.get_backend(group) == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def all_gather_meshes(meshes: list[dict], n_frames: int, group=None, force: bool = False, device=None) -> list[dict]:
+    """meshes: this rank's frames -- exactly shard_frames(n_frames, rank, world), in that (ascending) order -- each
+    {'v' (V,3) f32, 'vn' (V,3) f32, 'f' (F,3) i32}.  Returns, on every rank, all n_frames meshes in frame order."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1 and not force:      # `force` runs the collectives even with one rank (RCCL smoke test)
         return list(meshes)
-    device = meshes[0]['v'].device if meshes else torch.device('cpu')
+    mine = len(shard_frames(n_frames, rank, world))
+    if len(meshes) != mine:
+        raise ValueError(f'all_gather_meshes: rank {rank} of {world} owns {mine} of {n_frames} frames but was given {len(meshes)} meshes')
+    device = _collective_device(meshes, group, device)
     kmax = (n_frames + world - 1) // world
     counts, vbuf, fbuf = _pack(meshes, device)
     cpad = torch.zeros((kmax, 2), dtype=torch.int64, device=device)

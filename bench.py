@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- reconstructed-mesh frames/sec at 256^3 (BASELINE.json metric), 1..8 MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 8 --frames 64                     (BASELINE configs[4]: a batch of 64 frames sharded 8-way, meshes all-gathered)
+    python bench.py --gpus 2 --dry-run                       (no GPU: launcher + gloo all-gather of stand-in meshes; what the CPU test runs)
 
 A step = one frame of BASELINE.json configs[1] ("AvatarNet occupancy-only, 256^3 grid, random SMPL
 pose") on every rank: UNet7DS pose-feature map (MIOpen) -> fused warp+template occupancy query over
@@ -138,30 +140,94 @@ def cpu_baseline(pipe, sd, frame_out, res, budget_s=24.0):
             'seconds_per_frame': frame_s, 'numpy_port_us_per_point': per_pt_np * 1e6, 'torch_cpu_us_per_point': per_pt * 1e6}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this script, one per GPU, under
+    torch.distributed.run on 127.0.0.1 and pass rank 0's JSON line through.  (Round 1 silently measured ONE GPU in this case.)"""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """No GPU: the launcher, the rendezvous and the mesh all-gather on gloo with stand-in meshes.  Prints the same line shape with
+    n_gpus = the ranks the process group really has (tests/test_parallel_gloo.py)."""
+    import torch.distributed as dist
+    from avatarcap_amd.parallel import all_gather_meshes, shard_frames
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        with _stdout_to_stderr():                        # gloo announces its peers on stdout
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+    K = args.frames // world if args.frames else args.steps
+    n_frames = world * K
+    g = torch.Generator().manual_seed(1234)
+    sizes = torch.randint(5, 40, (n_frames,), generator=g).tolist()
+    mesh = lambda f: {'v': torch.full((sizes[f], 3), float(f)), 'vn': torch.full((sizes[f], 3), -float(f)),    # noqa: E731
+                      'f': torch.full((2 * sizes[f], 3), f, dtype=torch.int32)}
+    t0 = time.perf_counter()
+    with _stdout_to_stderr():
+        got = all_gather_meshes([mesh(f) for f in shard_frames(n_frames, rank, world)], n_frames)
+    dt = time.perf_counter() - t0
+    ok = len(got) == n_frames and all(got[f]['v'].shape[0] == sizes[f] and float(got[f]['v'][0, 0]) == float(f) and int(got[f]['f'][0, 0]) == f
+                                      for f in range(n_frames))
+    ranks = dist.get_world_size() if dist.is_initialized() else 1
+    if rank == 0:
+        print(json.dumps({'metric': 'dry run (no GPU): launcher + gloo all-gather of stand-in meshes', 'value': n_frames / max(dt, 1e-9),
+                          'unit': 'frames/s', 'n_gpus': ranks, 'rccl_ranks': 0, 'gloo_ranks': ranks, 'steps': K, 'warmup': 0,
+                          'frames': n_frames, 'all_gather_ok': bool(ok), 'data': 'synthetic'}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--res', type=int, default=256)
+    ap.add_argument('--frames', type=int, default=0, help='total frames of the batch over all ranks (BASELINE configs[4]: 64); sets steps = frames / gpus')
+    ap.add_argument('--dry-run', action='store_true', help='no GPU: launcher + gloo all-gather of stand-in meshes')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-masked', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    if args.frames:
+        if args.frames % world:
+            raise SystemExit(f'bench.py: --frames {args.frames} is not a multiple of --gpus {world}')
+        args.steps = args.frames // world
+    if args.dry_run:
+        raise SystemExit(dry_run(args, world, rank))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the hot path)')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    force_dist = os.environ.get('AVC_FORCE_DIST') == '1' and 'RANK' in os.environ    # exercise the RCCL path with a single rank
+    force_dist = os.environ.get('AVC_FORCE_DIST') == '1'    # exercise the RCCL all-gather with a single rank (tests/test_gpu_pipeline.py)
     if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
         with _stdout_to_stderr():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 0
+    assert rccl_ranks in (0, world)
 
     from avatarcap_amd import _lib
     from avatarcap_amd.dataset import to_cuda
@@ -213,13 +279,15 @@ def main():
     if rank == 0:
         line = {
             'metric': 'reconstructed-mesh frames/sec at 256^3 grid (avatar occupancy-only, dense query + marching cubes + LBS)',
-            'value': world * K / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'value': world * K / dt, 'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': K, 'warmup': W,
             'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (products as 3 split-fp16 MFMA passes, fp32 accumulate)', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: AvatarNet occupancy-only, {res}^3 grid dense ({N} points/frame), random SMPL pose, '
                                    f'UNet7DS + fused query + marching cubes + normals + KNN-4 LBS per frame',
                        'grid': [res] * 3, 'points_per_frame': N, 'vertices_last_frame': int(out['cano_v'].shape[0]),
-                       'faces_last_frame': int(out['f'].shape[0]), 'parallelism': f'frame-sharded x{world}'},
+                       'faces_last_frame': int(out['f'].shape[0]), 'parallelism': f'frame-sharded x{world}',
+                       'frames_in_batch': world * K, 'meshes_all_gathered': bool(world > 1 or force_dist),
+                       'dense_points': 'generated from the grid index (avc_avatar_query_grid), offsets not written'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_TFLOPS,
                          'traffic': HBM_TRAFFIC_BYTES_256 if res == 256 else None, 'traffic_source': 'profiles/r01_c_pmc_avatar.md (FETCH_SIZE x2 + WRITE_SIZE)',

@@ -242,3 +242,23 @@ def test_latency_mode_single_rank_equals_throughput_mode(pipe64):
     finally:
         wf.precompute_conv = keep
     assert torch.equal(a['occ_volume'], b['occ_volume']) and torch.equal(a['f'], b['f']) and torch.equal(a['live_v'], b['live_v'])
+
+
+def test_bench_single_rank_through_rccl():
+    """bench.py with AVC_FORCE_DIST=1: one rank, but the process group is RCCL and the timed region ends with the all-gather of the
+    frames' meshes -- the N > 1 code path on the one GPU a test box has.  The line must report the ranks RCCL really has."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    env = dict(os.environ, AVC_FORCE_DIST='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1')
+    env.pop('MASTER_PORT', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--res', '64',
+                        '--no-cpu-baseline', '--no-masked'], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1 and line['config']['meshes_all_gathered'] is True
+    assert line['steps'] == 2 and line['value'] > 0 and line['config']['vertices_last_frame'] > 0

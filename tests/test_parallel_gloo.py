@@ -100,3 +100,44 @@ def test_all_gather_slabs_world2(n):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (round 1 silently measured one GPU) and report the number
+    of ranks the process group really has; --frames F is BASELINE configs[4]'s batch (F frames sharded N-way, meshes all-gathered).
+    --dry-run swaps the GPU work for stand-in meshes on gloo, so the launcher / rendezvous / gather logic runs here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    env = dict(os.environ); env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    for argv, ranks, frames in ((['--gpus', '2', '--steps', '3', '--dry-run'], 2, 6), (['--gpus', '4', '--frames', '8', '--dry-run'], 4, 8),
+                                (['--gpus', '1', '--dry-run'], 1, 5)):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + argv, capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout                                   # exactly ONE line on stdout
+        line = json.loads(lines[0])
+        assert line['n_gpus'] == ranks and line['gloo_ranks'] == ranks and line['frames'] == frames and line['all_gather_ok'] is True
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '3', '--frames', '8', '--dry-run'], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0 and 'not a multiple' in (r.stderr + r.stdout)
+
+
+def test_all_gather_meshes_validates_its_shard():
+    """A rank must hand over exactly its shard_frames(); a mismatch raises instead of silently mis-assigning frames."""
+    import torch
+    import torch.distributed as dist
+    from avatarcap_amd.parallel import all_gather_meshes
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0)); port = so.getsockname()[1]
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        m = {'v': torch.zeros(4, 3), 'vn': torch.zeros(4, 3), 'f': torch.zeros((2, 3), dtype=torch.int32)}
+        with pytest.raises(ValueError, match='owns 2 of 2 frames'):
+            all_gather_meshes([m], 2, force=True)
+        out = all_gather_meshes([m, m], 2, force=True)
+        assert len(out) == 2 and out[1]['v'].shape == (4, 3)
+        assert all_gather_meshes([], 0, force=True) == []                   # a rank / batch without frames
+    finally:
+        dist.destroy_process_group()
