@@ -9,7 +9,7 @@ import torch
 
 import golden_inputs as gi
 from avatarcap_amd import config
-from common import geotex_sd, maxabs
+from common import geotex_sd_with_density as geotex_sd, maxabs       # density head not identically zero: colours are not black
 
 pytestmark = pytest.mark.gpu
 RES = [512, 512, 512]
@@ -115,7 +115,7 @@ def test_vertex_colours_at_512(frame512):
     idx = near[torch.linspace(0, near.numel() - 1, nv, device='cuda').long()]
     v, n = out['cano_v'][idx].contiguous(), out['cano_vn'][idx].contiguous()
     rgb = pipe.colour_vertices(items, v, n)
-    assert rgb.shape == (nv, 3) and bool(torch.isfinite(rgb).all()) and float(rgb.abs().max()) > 0.05
+    assert rgb.shape == (nv, 3) and bool(torch.isfinite(rgb).all()) and float(rgb.max()) > 0.2
     pick = np.arange(0, nv, nv // 150)[:150]
     fmap = pipe.network.warping_field.pose_feat_map[0].cpu().numpy()
     vv, nn = v[pick].cpu().numpy().astype(np.float64), n[pick].cpu().numpy().astype(np.float64)

@@ -55,8 +55,19 @@ def test_geotex_forward_posed_matches_reference(net, golden, body):
     b3 = {'cano_smpl_center': _t(gi.center()[None]), 'cano_bounds': _t(syn.CANO_BOUNDS[None]), 'live_smpl_v': _t(live_v[None]),
           'cano2live_jnt_mats': _t(jm[None])}
     o = net.forward(_t(wl[None]), None, _t(np.full((1, 500, 1), 0.0016, np.float32)), b3, pts_space='posed')
-    assert maxabs(o['raw'][0].cpu().numpy(), golden['G13_raw']) < 3e-4      # two inverse-skinning stages in fp32 upstream of the net
-    assert maxabs(o['occ'][0].cpu().numpy(), golden['G13_occ']) < 3e-4
+    # Two inverse-skinning stages in fp32 sit upstream of the network here and the template is steep in its input (2^9 positional
+    # frequency): the golden is ONE float32 realisation of the path (the reference's), the device another.  What float32 itself loses
+    # on this path is measured, not guessed: float32 oracle vs float64 oracle; two float32 realisations may differ by twice that.
+    from oracle import avatarcap_oracle as orc
+    args = (wl, np.full((500, 1), 0.0016, np.float32), gi.pose_feat_map(), gi.center(), syn.CANO_BOUNDS, live_v, body['skin_weights'],
+            gi.blend_weight_volume(), jm, geotex_sd())
+    r64, r32 = orc.geotex_forward_posed(*args, dt=np.float64), orc.geotex_forward_posed(*args, dt=np.float32)
+    for k, name in ((0, 'raw'), (1, 'occ')):
+        slack = maxabs(r32[k], r64[k])
+        got = o[name][0].cpu().numpy()
+        e_gold, e_64 = maxabs(got, golden['G13_' + name]), maxabs(got, r64[k])
+        print(f'G13 {name}: vs reference golden {e_gold:.3e}, vs fp64 oracle {e_64:.3e}, fp32-oracle slack {slack:.3e}')
+        assert e_gold < 1e-4 + 2 * slack and e_64 < 1e-4 + slack
     assert maxabs(o['nonrigid_offset'][0].cpu().numpy(), golden['G13_off']) < 1e-4
 
 
@@ -145,26 +156,41 @@ def test_recon_frame_64(pipe64):
 
 def test_vertex_colours_match_oracle(pipe64):
     """NerfRenderer.render(pts_space='cano') + raw2outputs on the avatar's vertices (main.py:464-477):
-    64 samples per ray through the fused colour kernel, composited; compared with the oracle chain."""
+    64 samples per ray through the fused colour kernel, composited; compared with the oracle chain on a network whose density head is
+    not identically zero (common.geotex_sd_with_density), with the slack of the reference's own fp32 arithmetic measured."""
     from avatarcap_amd.dataset import to_cuda
+    from avatarcap_amd.utils.smpl_util import smpl_util
+    from common import geotex_sd_with_density
     from oracle import avatarcap_oracle as orc
     ds = pipe64.ds
     items = to_cuda(ds[0], add_batch=True)
-    out = pipe64.avatar_frame(items)
-    v, n = out['cano_v'][:300].contiguous(), out['cano_vn'][:300].contiguous()
-    rgb = pipe64.colour_vertices(items, v, n)
-    assert rgb.shape == (300, 3)
+    sd = geotex_sd_with_density()
+    pipe64.network.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    try:
+        out = pipe64.avatar_frame(items)
+        d2, _ = smpl_util.knn_points(out['cano_v'][None], smpl_util.cano_smpl_vertices[None], K=1)
+        near = torch.nonzero(d2[0, :, 0] < 0.03 ** 2)[:, 0]                       # elsewhere the density is zeroed (arch_avatar.py:208-209,226)
+        idx = near[torch.linspace(0, near.numel() - 1, 300, device='cuda').long()]
+        v, n = out['cano_v'][idx].contiguous(), out['cano_vn'][idx].contiguous()
+        rgb = pipe64.colour_vertices(items, v, n)
+    finally:
+        pipe64.network.load_state_dict({k: torch.from_numpy(v_) for k, v_ in geotex_sd().items()})
+    assert rgb.shape == (300, 3) and float(rgb.max()) > 0.2                        # not black: the comparison below is not vacuous
     fmap = pipe64.network.warping_field.pose_feat_map[0].cpu().numpy()
     vv, nn = v.cpu().numpy().astype(np.float64), n.cpu().numpy().astype(np.float64)
     t = np.linspace(0., 1., config.N_samples, dtype=np.float32).astype(np.float64)
-    near, far = 1.0 - 0.02, 1.0 + 0.05                                              # depth = 1, near_dist 0.02, far_dist 0.05
-    z = near * (1 - t) + far * t
-    pts = (vv + nn)[:, None, :] - nn[:, None, :] * z[None, :, None]
+    near_, far_ = 1.0 - 0.02, 1.0 + 0.05                                            # depth = 1, near_dist 0.02, far_dist 0.05
+    z = near_ * (1 - t) + far_ * t
+    pts = ((vv + nn)[:, None, :] - nn[:, None, :] * z[None, :, None]).reshape(-1, 3).astype(np.float32)
     dists = np.concatenate([z[1:] - z[:-1], z[-1:] - z[-2:-1]])
-    raw, _, _ = orc.geotex_forward_cano(pts.reshape(-1, 3).astype(np.float32), np.tile(dists, 300)[:, None], fmap, ds.cano_smpl_center,
-                                        ds.cano_bounds, ds.body['cano_smpl_v'], geotex_sd())
-    rgb_ref = orc.raw2outputs(raw.reshape(300, -1, 4), np.tile(z, (300, 1)))[0][:, [2, 1, 0]]
-    assert maxabs(rgb.cpu().numpy(), rgb_ref) < 2e-4
+    ref = {}
+    for dt in (np.float64, np.float32):
+        raw, _, _ = orc.geotex_forward_cano(pts, np.tile(dists, 300)[:, None], fmap, ds.cano_smpl_center, ds.cano_bounds, ds.body['cano_smpl_v'], sd, dt=dt)
+        ref[dt] = orc.raw2outputs(raw.reshape(300, -1, 4), np.tile(z, (300, 1)))[0][:, [2, 1, 0]]
+    slack = maxabs(ref[np.float32], ref[np.float64])
+    err = maxabs(rgb.cpu().numpy(), ref[np.float64])
+    print(f'vertex colours: err {err:.3e}, fp32-oracle slack {slack:.3e}')
+    assert err < 1e-4 + 2 * slack
 
 
 def test_full_frame_chain(pipe64):
