@@ -66,6 +66,11 @@ class _stdout_to_stderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:                                    # RCCL's banner sits in the C library's stdout buffer: flush it while fd 1 still is stderr
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                       # noqa: BLE001
+            pass
         os.dup2(self._saved, 1)
         os.close(self._saved)
         return False
