@@ -25,7 +25,9 @@ class ReconNetwork(nn.Module):
         self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, '_packed_version', None))
 
     def get_feat_maps(self, image):
-        feat_maps, _ = self.image_encoder(image)
+        from .unets import deterministic_convs
+        with deterministic_convs():              # bit-identical feature maps from call to call (see unets.deterministic_convs)
+            feat_maps, _ = self.image_encoder(image)
         return feat_maps
 
     def _ctx(self, device):

@@ -4,9 +4,25 @@ network/unets.py:169-229).  Runs once per frame on PyTorch-ROCm / MIOpen (SURVEY
 
 state_dict-compatible with the reference (50 keys incl. the dead `upconv4.*`).
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+@contextlib.contextmanager
+def deterministic_convs():
+    """MIOpen picks an atomics-based transposed-convolution kernel for this U-Net by default: the pose feature map then differs by ~2e-6
+    from call to call, which is enough to move a marching-cubes vertex count by a few units between two runs of the same frame.  With
+    PyTorch's deterministic flag MIOpen is asked for deterministic solutions only (bit-identical across calls, and 10 % faster here:
+    tools/determinism_producers.py).  The flag is restored on exit."""
+    prev = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        yield
+    finally:
+        torch.backends.cudnn.deterministic = prev
 
 
 class _Down(nn.Module):
@@ -65,6 +81,10 @@ class UnetNoCond7DS(nn.Module):
         self.upconvC7 = _Up(2 * nf, output_nc, 'upsample', bn=False, bias=True)
 
     def forward(self, x):
+        with deterministic_convs():
+            return self._forward(x)
+
+    def _forward(self, x):
         d = [x]
         for i in range(1, 8):
             d.append(getattr(self, f'conv{i}')(d[-1]))

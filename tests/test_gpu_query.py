@@ -98,7 +98,7 @@ def test_recon_decoder_matches_reference_golden(golden):
     assert y2.shape == golden['G6_recon'].shape
     err = maxabs(y2.cpu().numpy(), golden['G6_recon'])
     print(f'infer() vs G6_recon: {err:.3e}')
-    assert err < 5e-4   # includes fp32 conv-stack differences (MIOpen vs CPU)
+    assert err < 1e-4   # measured 8e-7 (MIOpen's fp32 conv stack + the fused GroupNorm vs the reference on the CPU): north_star's bar holds end to end
 
 
 @pytest.mark.parametrize('n', [1, 33, 4097])

@@ -12,9 +12,16 @@ net = GeoTexAvatar(base_weight_volume=np.zeros((2, 2, 2, 24), np.float32)).to('c
 sd = syn.synth_state_dict(syn.module_shapes(net), syn.SEED)
 net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
 net.warping_field.pose_feat_map = torch.randn(1, 64, 256, 256, device='cuda')
-pts = generate_volume_points(syn.CANO_BOUNDS, (res, res, res), 'cuda')[None]
-batch = {'cano_pts': pts, 'cano_smpl_center': torch.zeros(1, 3, device='cuda')}
+from avatarcap_amd.grid import volume_axes
+batch = {'cano_smpl_center': torch.zeros(1, 3, device='cuda')}
+axes = volume_axes(syn.CANO_BOUNDS, (res, res, res), 'cuda')
+mode = sys.argv[3] if len(sys.argv) > 3 else 'grid'       # 'grid' = what bench.py launches (points from the index, no offsets); 'pts' = the (N,3) array
+if mode == 'pts':
+    batch['cano_pts'] = generate_volume_points(syn.CANO_BOUNDS, (res, res, res), 'cuda')[None]
 for _ in range(reps + 1):
-    OccupancyNet(net).query(batch)
+    if mode == 'pts':
+        OccupancyNet(net).query(batch)
+    else:
+        OccupancyNet(net).query_grid(batch, axes, (res, res, res))
 torch.cuda.synchronize()
 print('done')
