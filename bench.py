@@ -21,7 +21,7 @@ The JSON line also carries:
                   SURVEY.md 8(d)) / mean launch time measured with HIP events on the launch stream,
                   against the dense fp16 MFMA peak (the kernel issues 3 fp16 MFMA passes per fp32
                   product, so `mfma_util` = 2.84 x frac is the matrix-pipe utilisation; `traffic` is the
-                  HBM byte count of the committed rocprofv3 --pmc pass, profiles/r01_c_pmc_avatar.md;
+                  HBM byte count of the committed rocprofv3 --pmc pass, profiles/r02_pmc_avatar.md;
                   `sustained_mfma_tflops_measured` is the rate a pure MFMA + LDS-read loop holds on this part
                   under its power-managed clock, profiles/r01_ubench_mfma_clock.md -- information, not `peak`).
   cpu_baseline -- the CPU restatements of oracle/ (the query on stock PyTorch CPU ops with identical weights on all host
@@ -49,9 +49,9 @@ MFMA_ISSUED_PER_POINT = 4920 * 32 * 32 * 16 * 2 / 32   # 4920 v_mfma_f32_32x32x1
 PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 SUSTAINED_F16_TFLOPS = 1673.0      # what this part sustains on split-fp16 MFMAs fed from LDS once its clock manager has
                                     # settled (1.6 GHz, pipe 99 % busy): profiles/r01_ubench_mfma_clock.md -- information only
-HBM_TRAFFIC_BYTES_256 = 1.98e9      # per dense 256^3 launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc
-                                    # (profiles/r01_c_pmc_avatar.md; an earlier run measured 0.72e9: the share of the weight stream
-                                    # that falls out of L2 varies, the writes are exact)
+HBM_TRAFFIC_BYTES_256 = 0.174e9     # per dense 256^3 launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc (profiles/r02_pmc_avatar.md):
+                                    # 67.1 MB of occupancy written (exact) + the feature map per XCD and what share of the weight stream left L2;
+                                    # round 1's 1.98e9 also read 201 MB of points and wrote 201 MB of offsets nobody reads
 
 
 class _stdout_to_stderr:
@@ -295,7 +295,7 @@ def main():
                        'dense_points': 'generated from the grid index (avc_avatar_query_grid), offsets not written'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_TFLOPS,
-                         'traffic': HBM_TRAFFIC_BYTES_256 if res == 256 else None, 'traffic_source': 'profiles/r01_c_pmc_avatar.md (FETCH_SIZE x2 + WRITE_SIZE)',
+                         'traffic': HBM_TRAFFIC_BYTES_256 if res == 256 else None, 'traffic_source': 'profiles/r02_pmc_avatar.md (FETCH_SIZE x2 + WRITE_SIZE)',
                          'kernel': 'avc::avatar_kernel<true,false>', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
                          'algorithmic_flop_per_launch': N * FLOP_PER_POINT,
                          'mfma_issued_tflops': N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0,
