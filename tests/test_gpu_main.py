@@ -1,0 +1,66 @@
+"""`python main.py -c <yaml> -m test` on a CAPTURED-SEQUENCE layout (no --synthetic): dataConfig.yaml, SMPL model file, pose / shape / position-map
+files, checkpoints and image-normal EXRs are all read from disk through the reference-shaped loader (avatarcap_amd.avatarcap_dataset), steps 1-4
+of the frame loop run on the device, PLYs are written (main.py:275-498).  The files are synthetic stand-ins of the right layout
+(tests/synthetic_sequence.py): the licensed model / data / checkpoints cannot ship."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import synthetic_sequence as sq
+from avatarcap_amd import config, synthetic as syn
+from test_host import _write_exr
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def test_main_test_mode_on_a_sequence_directory(tmp_path):
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar
+    from avatarcap_amd.network.arch_recon import ReconNetwork
+    data, train, out = tmp_path / 'testing', tmp_path / 'training', tmp_path / 'out'
+    smpl_dir = tmp_path / 'smpl_files'
+    for d in (data, train, smpl_dir):
+        os.makedirs(d)
+    sq.write_smpl_file(str(smpl_dir / 'basicmodel_M_lbs_10_207_0_v1.0.0.pkl'))
+    ids = sq.build_sequence(str(data), lambda p, img: _write_exr(p, img[..., ::-1].copy(), 'RGB', 2, 3), n_frames=2, start=7, data_type='real')
+    os.makedirs(data / 'imgs' / 'normal')
+    for idx in ids:                                                   # the image-observed normal maps of step 2 (main.py:409)
+        nm = syn.smooth_normal_maps(40 + idx, 512)[:3].transpose(1, 2, 0)
+        nm[:, :140] = 0                                               # part of the image shows no body
+        _write_exr(str(data / 'imgs' / 'normal' / ('normal_%04d.exr' % idx)), np.ascontiguousarray(nm[..., ::-1]), 'RGB', 1, 3)
+    np.save(str(train / 'cano_base_blend_weight_volume.npy'), np.full((4, 4, 4, 24), 1 / 24, np.float32))
+    config.cfg = config.default_cfg()
+    config.cfg['training']['training_data_dir'] = str(train)
+    net = GeoTexAvatar()
+    rn = ReconNetwork()
+    for name, m, fn in (('avatar', net, 'net.pt'), ('recon', rn, 'recon_net.pt')):
+        os.makedirs(tmp_path / name)
+        sd = syn.synth_state_dict(syn.module_shapes(m), syn.SEED)
+        torch.save({'network': {k: torch.from_numpy(v) for k, v in sd.items()}}, str(tmp_path / name / fn))
+    cfg = {'training': {'training_data_dir': str(train)},
+           'testing': {'vol_res': [40, 96, 36], 'recon_net_ckpt': str(tmp_path / 'recon'), 'net_ckpt': str(tmp_path / 'avatar'),
+                       'net_ckpt_finetuned': None, 'testing_data_dir': str(data), 'output_dir': str(out)},
+           'model': {'cano_template': {'pos_encoding': 10}, 'warping_field': {'pos_encoding': 0}}}
+    with open(tmp_path / 'cfg.yaml', 'w') as fh:
+        yaml.safe_dump(cfg, fh)
+    env = dict(os.environ, AVC_SMPL_DIR=str(smpl_dir))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '-c', str(tmp_path / 'cfg.yaml'), '-m', 'test', '--save-ply', '--nerf', '--integrate', 'cover'],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert '# Real data' in r.stdout and '# Start data index: 7' in r.stdout and '# Data num: 2' in r.stdout
+    for idx in ids:
+        m = np.load(str(out / ('%04d_mesh.npz' % idx)))
+        assert m['cano_v'].shape[0] > 100 and m['f'].max() < m['cano_v'].shape[0] and m['live_v'].shape == m['cano_v'].shape
+        assert m['recon_cano_v'].shape[0] > 0 and m['live_vc'].shape == m['cano_v'].shape
+        ply = open(str(out / ('%04d_avatar.ply' % idx)), 'rb').read()
+        assert ply.startswith(b'ply\n') and (b'element vertex %d' % m['cano_v'].shape[0]) in ply[:400]
+        assert os.path.exists(str(out / ('%04d_recon.ply' % idx)))
+    # a missing model file is the reference's FileNotFoundError, not a silent fallback
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '-c', str(tmp_path / 'cfg.yaml'), '-m', 'test'],
+                        capture_output=True, text=True, env=dict(os.environ, AVC_SMPL_DIR=str(tmp_path / 'nowhere')), timeout=600, cwd=ROOT)
+    assert r2.returncode != 0 and 'FileNotFoundError' in r2.stderr
