@@ -53,22 +53,22 @@ def write_smpl_file(path, seed=77):
         pickle.dump(synthetic_smpl_dict(seed), fh, protocol=2)
 
 
-def pos_map_array(data_idx):
+def pos_map_array(data_idx, src=None):
     """(H, 2H, 3) float32 'position map' as it sits in the EXR: smooth + noise, front | back halves different."""
     rs = np.random.RandomState(500 + data_idx)
-    H, W = POS_MAP_SRC
+    H, W = src or POS_MAP_SRC
     ys, xs = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing='ij')
     m = np.stack([np.sin(3 * xs) + 0.1 * rs.randn(H, W), ys * xs + 0.1 * rs.randn(H, W), np.cos(2 * ys) + 0.1 * rs.randn(H, W)], -1)
     return m.astype(np.float32)
 
 
-def build_sequence(root, write_exr, n_frames=2, start=3, data_type='real', pos_map_name='cano'):
+def build_sequence(root, write_exr, n_frames=2, start=3, data_type='real', pos_map_name='cano', pos_map_res=POS_MAP_RES, pos_map_src=None):
     """Writes <root>/{dataConfig.yaml, smpl/shape.txt, smpl/pose_%04d.txt, smpl/smpl_pos_map_%04d_<name>.exr[, imgs/%03d/cams.mat]} and returns
     the list of data indices.  `write_exr(path, img_bgr_float32)` is the caller's EXR writer."""
     import yaml
     os.makedirs(os.path.join(root, 'smpl'), exist_ok=True)
     with open(os.path.join(root, 'dataConfig.yaml'), 'w', encoding='UTF-8') as fh:
-        yaml.safe_dump({'data_type': data_type, 'pos_map_name': pos_map_name, 'pos_map_res': POS_MAP_RES,
+        yaml.safe_dump({'data_type': data_type, 'pos_map_name': pos_map_name, 'pos_map_res': pos_map_res,
                         'camera': {'fx': 550.0, 'fy': 552.0, 'cx': 255.5, 'cy': 254.0, 'img_width': 512, 'img_height': 512}}, fh)
     rs = np.random.RandomState(91)
     np.savetxt(os.path.join(root, 'smpl', 'shape.txt'), 0.5 * rs.randn(10))
@@ -77,7 +77,7 @@ def build_sequence(root, write_exr, n_frames=2, start=3, data_type='real', pos_m
         idx = start + k
         pose = np.concatenate([0.05 * rs.randn(3), 0.25 * rs.randn(72)])
         np.savetxt(os.path.join(root, 'smpl', 'pose_%04d.txt' % idx), pose)
-        write_exr(os.path.join(root, 'smpl', 'smpl_pos_map_%04d_%s.exr' % (idx, pos_map_name)), pos_map_array(idx))
+        write_exr(os.path.join(root, 'smpl', 'smpl_pos_map_%04d_%s.exr' % (idx, pos_map_name)), pos_map_array(idx, pos_map_src))
         if data_type == 'synthetic':
             import scipy.io as sio
             os.makedirs(os.path.join(root, 'imgs', '%03d' % idx), exist_ok=True)

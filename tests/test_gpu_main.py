@@ -27,7 +27,8 @@ def test_main_test_mode_on_a_sequence_directory(tmp_path):
     for d in (data, train, smpl_dir):
         os.makedirs(d)
     sq.write_smpl_file(str(smpl_dir / 'basicmodel_M_lbs_10_207_0_v1.0.0.pkl'))
-    ids = sq.build_sequence(str(data), lambda p, img: _write_exr(p, img[..., ::-1].copy(), 'RGB', 2, 3), n_frames=2, start=7, data_type='real')
+    ids = sq.build_sequence(str(data), lambda p, img: _write_exr(p, img[..., ::-1].copy(), 'RGB', 2, 3), n_frames=2, start=7, data_type='real',
+                            pos_map_res=256, pos_map_src=(192, 384))     # the 7-level U-Net needs its real 256^2 input
     os.makedirs(data / 'imgs' / 'normal')
     for idx in ids:                                                   # the image-observed normal maps of step 2 (main.py:409)
         nm = syn.smooth_normal_maps(40 + idx, 512)[:3].transpose(1, 2, 0)
