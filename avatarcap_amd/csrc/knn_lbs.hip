@@ -432,7 +432,8 @@ static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, Gri
     // cells per axis: about one occupied cell per few reference points for surface-like sets (6890 -> 32, 1e6 -> 128)
     const int axis = std::min(GRID_MAX_AXIS, std::max(8, (int)(1.7 * cbrt((double)nr))));
     const size_t ncell = (size_t)axis * axis * axis;
-    const size_t bytes = 256 + 2 * sizeof(int) * (ncell + 64) + sizeof(float4) * ((size_t)nr + 8) + (size_t)((nq + 255) / 256);
+    const size_t cells = (ncell + 64 + 1) & ~(size_t)1;      // even: the two int arrays together stay a multiple of 16 bytes, so `sorted` (float4) is aligned
+    const size_t bytes = 256 + 2 * sizeof(int) * cells + sizeof(float4) * ((size_t)nr + 8) + (size_t)((nq + 255) / 256);
     if (ctx->knn_scratch_bytes < bytes) {
         if (ctx->knn_scratch) AVC_HIP(hipFree(ctx->knn_scratch));
         ctx->knn_scratch = nullptr; ctx->knn_scratch_bytes = 0;
@@ -443,8 +444,8 @@ static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, Gri
     GridHdr *hdr = reinterpret_cast<GridHdr *>(base);
     unsigned *keys = reinterpret_cast<unsigned *>(base + 128);
     int *start = reinterpret_cast<int *>(base + 256);
-    int *cursor = start + ncell + 64;
-    float4 *sorted = reinterpret_cast<float4 *>(cursor + ncell + 64);
+    int *cursor = start + cells;
+    float4 *sorted = reinterpret_cast<float4 *>(cursor + cells);
     AVC_HIP(hipMemsetAsync(keys, 0xff, 3 * sizeof(unsigned), s));                 // running minima start at the largest key
     AVC_HIP(hipMemsetAsync(keys + 3, 0x00, 3 * sizeof(unsigned), s));
     AVC_HIP(hipMemsetAsync(start, 0, sizeof(int) * (ncell + 1), s));
