@@ -197,6 +197,8 @@ struct Stream {
     unsigned lane_off;       // lane * 16
 #if AVC_DBG_TIMING
     long long t_bar = 0;     // cycles spent waiting at chunk barriers
+    long long t_drain = 0;   // ... of which waiting for this wave's own LDS-DMA pieces (s_waitcnt vmcnt(0))
+    long long t_pro = 0;     // cycles of the per-tile prologues (point load, gathers, positional encoding) and output stores
 #endif
 };
 
@@ -276,6 +278,9 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
     const long long tb0 = clock64();
 #endif
     pf_drain();
+#if AVC_DBG_TIMING
+    s.t_drain += clock64() - tb0;
+#endif
 #if !AVC_DBG_NO_BARRIER
     __syncthreads();
 #endif
@@ -747,6 +752,9 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int64_t pidx_raw = tile * TILE_PTS + wave * 32 + j;
         const int64_t pidx = pidx_raw < p.n ? pidx_raw : p.n - 1;
+#if AVC_DBG_TIMING
+        const long long tp0 = clock64();
+#endif
         float pt[3];
         load_point(p, pidx, pt);
 
@@ -772,6 +780,9 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             }
             const ParkIn S{park, &S4};
             const RegIn RX{X}, RY{Y};
+#if AVC_DBG_TIMING
+            s.t_pro += clock64() - tp0;
+#endif
             using SP = Pending<ACT_SOFTPLUS, 8>;
             dense<8, layout::IN67_KS, 0, ACT_SOFTPLUS, B_MAIN>(s, S, S, X, bias, h, NoSide{}, pa);                       // conv1+bn1
             dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                        // conv2
@@ -787,9 +798,15 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         }
 
         // ---- DoubleTNet.forward (arch_avatar.py:65-83) ----
+#if AVC_DBG_TIMING
+        const long long tp1 = clock64();
+#endif
         posenc(q, h, park, s.range);                                                                                            // :70 (parked in LDS)
         const ParkIn P{park, nullptr};
         const RegIn TX{X}, TY{Y};
+#if AVC_DBG_TIMING
+        s.t_pro += clock64() - tp1;
+#endif
         using RP = Pending<ACT_RELU, 8>;
         dense<8, layout::PE_KS, 0, ACT_RELU, B_MAIN>(s, P, P, X, bias, h, NoSide{}, pa);                                 // shared 0
         dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12, &s.range}, pb);
@@ -827,8 +844,8 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
     s.range.report(p);
 #if AVC_DBG_TIMING
     if (lane == 0 && p.out1) {     // debug: overwrite the head of the offsets buffer with (total, barrier) cycles per wave
-        long long *dbg = reinterpret_cast<long long *>(p.out1) + 2 * (blockIdx.x * 4 + wave);
-        dbg[0] = clock64() - tk0; dbg[1] = s.t_bar;
+        long long *dbg = reinterpret_cast<long long *>(p.out1) + 4 * (blockIdx.x * 4 + wave);
+        dbg[0] = clock64() - tk0; dbg[1] = s.t_bar; dbg[2] = s.t_drain; dbg[3] = s.t_pro;
     }
 #endif
 }

@@ -14,8 +14,8 @@ for V in ${ABL_VARIANTS:-BASE NO_PREFETCH NO_BARRIER NO_EPI NO_LDSREAD NO_PREFET
     *) FL=$(for x in $(echo "$V" | tr '+' ' '); do echo -n "-DAVC_DBG_$x=1 "; done) ;;
   esac
   [ -f $OUT/lib_$TAG.so ] && [ $OUT/lib_$TAG.so -nt avatarcap_amd/csrc/fused_mlp.hip ] && continue
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $FL -c avatarcap_amd/csrc/fused_mlp.hip -o $OUT/fused_$TAG.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/fused_$TAG.o $OBJ/misc.hip.o $OBJ/mesh.hip.o $OBJ/raster.hip.o $OBJ/fusion.hip.o $OBJ/knn_lbs.hip.o $OBJ/pack.cpp.o $OBJ/capi.cpp.o -o $OUT/lib_$TAG.so && echo built $TAG ) &
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form $FL -c avatarcap_amd/csrc/fused_mlp.hip -o $OUT/fused_$TAG.o &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/fused_$TAG.o $OBJ/fused_mlp_checked.o $OBJ/misc.hip.o $OBJ/mesh.hip.o $OBJ/raster.hip.o $OBJ/fusion.hip.o $OBJ/knn_lbs.hip.o $OBJ/pack.cpp.o $OBJ/capi.cpp.o -o $OUT/lib_$TAG.so && echo built $TAG ) &
 done
 wait
 ls -la $OUT/*.so

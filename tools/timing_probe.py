@@ -13,6 +13,9 @@ batch = {'cano_pts': pts, 'cano_smpl_center': torch.zeros(1, 3, device='cuda')}
 for _ in range(2):
     o = OccupancyNet(net).query(batch)
 torch.cuda.synchronize()
-d = o['nonrigid_offset'].view(-1).view(torch.int64)[:2 * 1024].cpu().numpy().reshape(1024, 2)
-print('per-wave total cycles: mean %.3e min %.3e max %.3e' % (d[:, 0].mean(), d[:, 0].min(), d[:, 0].max()))
-print('per-wave barrier-wait cycles: mean %.3e (%.1f%% of total)  per chunk %.0f' % (d[:, 1].mean(), 100 * d[:, 1].mean() / d[:, 0].mean(), d[:, 1].mean() / (512 * 59)))
+d = o['nonrigid_offset'].view(-1).view(torch.int64)[:4 * 1024].cpu().numpy().reshape(1024, 4)
+tot = d[:, 0].mean()
+print('per-wave total cycles: mean %.4e min %.4e max %.4e  -> %.2f cycles per MFMA' % (tot, d[:, 0].min(), d[:, 0].max(), tot / (4920 * 512)))
+print('chunk entry (LDS-DMA drain + barrier): %.1f %% of total, %.0f cycles per chunk; of which drain %.1f %% (%.0f per chunk)' %
+      (100 * d[:, 1].mean() / tot, d[:, 1].mean() / (512 * 59), 100 * d[:, 2].mean() / tot, d[:, 2].mean() / (512 * 59)))
+print('tile prologues (point, gathers, positional encoding): %.1f %% of total, %.0f cycles per tile' % (100 * d[:, 3].mean() / tot, d[:, 3].mean() / 512))
