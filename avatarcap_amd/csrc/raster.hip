@@ -101,20 +101,26 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float *__rest
     if (key == 0ull) { out[0] = 0.f; out[1] = 0.f; out[2] = 0.f; return; }
     const long long t = (long long)(0xffffffffu - (unsigned)(key & 0xffffffffull));
     const float half = 0.5f * (float)size;
-    Tri T;
-    load_tri(verts, faces, t, cx, cy, cz, half, T);
-    int a = 0, b = 1, c = 2;
-    long long area = edge_fn(T.fx[0], T.fy[0], T.fx[1], T.fy[1], T.fx[2], T.fy[2]);
-    if (area < 0) { b = 2; c = 1; area = -area; }
     const long long px = p % size, py = p / size;
-    const long long sx = px * SUB + SUB / 2, sy = py * SUB + SUB / 2;
-    const float inv = 1.0f / (float)area;
-    const float l0 = (float)edge_fn(T.fx[b], T.fy[b], T.fx[c], T.fy[c], sx, sy) * inv;
-    const float l1 = (float)edge_fn(T.fx[c], T.fy[c], T.fx[a], T.fy[a], sx, sy) * inv;
-    const float l2 = (float)edge_fn(T.fx[a], T.fy[a], T.fx[b], T.fy[b], sx, sy) * inv;
-    const float *A = attrs + 3 * (long long)faces[3 * t + a], *B = attrs + 3 * (long long)faces[3 * t + b], *C = attrs + 3 * (long long)faces[3 * t + c];
+    // Attribute interpolation from the UNSNAPPED window positions, in double, exactly as oracle/raster_oracle.c does it (coverage and depth
+    // use the 1/256-pixel fixed-point positions; OpenGL -- Mesa llvmpipe, tests/golden/gl_golden.npz -- derives the attribute planes from the
+    // float positions, and on a grazing triangle the snap would move an attribute by up to 1e-3)
+    double wx[3], wy[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) out[k] = (l0 * A[k] + l1 * B[k]) + l2 * C[k];
+    for (int k = 0; k < 3; ++k) {
+        const float *q = verts + 3 * (long long)faces[3 * t + k];
+        wx[k] = (double)((q[0] - cx + 1.0f) * half);
+        wy[k] = (double)((1.0f - (q[1] - cy)) * half);
+    }
+    const double qx = (double)px + 0.5, qy = (double)py + 0.5;
+    const double e0 = (wx[2] - wx[1]) * (qy - wy[1]) - (wy[2] - wy[1]) * (qx - wx[1]);
+    const double e1 = (wx[0] - wx[2]) * (qy - wy[2]) - (wy[0] - wy[2]) * (qx - wx[2]);
+    const double e2 = (wx[1] - wx[0]) * (qy - wy[0]) - (wy[1] - wy[0]) * (qx - wx[0]);
+    const double ar = (e0 + e1) + e2;
+    const double l0 = e0 / ar, l1 = e1 / ar, l2 = e2 / ar;
+    const float *A = attrs + 3 * (long long)faces[3 * t + 0], *B = attrs + 3 * (long long)faces[3 * t + 1], *C = attrs + 3 * (long long)faces[3 * t + 2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k] = (float)((l0 * (double)A[k] + l1 * (double)B[k]) + l2 * (double)C[k]);
 }
 
 
@@ -191,21 +197,29 @@ __global__ __launch_bounds__(256) void raster_mvp_resolve_kernel(const float *__
     const unsigned long long key = keys[pi];
     if (key == 0ull) { *o = make_float4(0.f, 0.f, 0.f, 0.f); return; }
     const long long t = (long long)(0xffffffffu - (unsigned)(key & 0xffffffffull));
-    TriP T;
-    load_tri_mvp(verts, faces, t, M, W, H, T);
-    const int a = 0, b = 2, c = 1;
-    const long long area = -edge_fn(T.fx[0], T.fy[0], T.fx[1], T.fy[1], T.fx[2], T.fy[2]);
     const long long px = pi % W, py = pi / W;
-    const long long sx = px * SUB + SUB / 2, sy = py * SUB + SUB / 2;
-    const float inv = 1.0f / (float)area;
-    const float u0 = (float)edge_fn(T.fx[b], T.fy[b], T.fx[c], T.fy[c], sx, sy) * inv * T.iw[a];
-    const float u1 = (float)edge_fn(T.fx[c], T.fy[c], T.fx[a], T.fy[a], sx, sy) * inv * T.iw[b];
-    const float u2 = (float)edge_fn(T.fx[a], T.fy[a], T.fx[b], T.fy[b], sx, sy) * inv * T.iw[c];
-    const float den = 1.0f / ((u0 + u1) + u2);
-    const float *A = attrs + 3 * (long long)faces[3 * t + a], *B = attrs + 3 * (long long)faces[3 * t + b], *C = attrs + 3 * (long long)faces[3 * t + c];
+    double wx[3], wy[3], iw[3];        // perspective-correct attribute from the unsnapped window positions, in double (oracle/raster_oracle.c)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float *q = verts + 3 * (long long)faces[3 * t + k];
+        float c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = ((M.m[4 * r] * q[0] + M.m[4 * r + 1] * q[1]) + M.m[4 * r + 2] * q[2]) + M.m[4 * r + 3];
+        const float w1 = 1.0f / c[3];
+        iw[k] = (double)w1;
+        wx[k] = (double)((c[0] * w1 + 1.0f) * (0.5f * (float)W));
+        wy[k] = (double)((1.0f - c[1] * w1) * (0.5f * (float)H));
+    }
+    const double qx = (double)px + 0.5, qy = (double)py + 0.5;
+    const double e0 = (wx[2] - wx[1]) * (qy - wy[1]) - (wy[2] - wy[1]) * (qx - wx[1]);
+    const double e1 = (wx[0] - wx[2]) * (qy - wy[2]) - (wy[0] - wy[2]) * (qx - wx[2]);
+    const double e2 = (wx[1] - wx[0]) * (qy - wy[0]) - (wy[1] - wy[0]) * (qx - wx[0]);
+    const double u0 = e0 * iw[0], u1 = e1 * iw[1], u2 = e2 * iw[2];
+    const double den = (u0 + u1) + u2;
+    const float *A = attrs + 3 * (long long)faces[3 * t + 0], *B = attrs + 3 * (long long)faces[3 * t + 1], *C = attrs + 3 * (long long)faces[3 * t + 2];
     float r[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) r[k] = ((u0 * A[k] + u1 * B[k]) + u2 * C[k]) * den;
+    for (int k = 0; k < 3; ++k) r[k] = (float)(((u0 * (double)A[k] + u1 * (double)B[k]) + u2 * (double)C[k]) / den);
     *o = make_float4(r[0], r[1], r[2], 1.0f);
 }
 

@@ -7,7 +7,8 @@ and each restating a published, fixed algorithm (they are NOT the code under tes
   cv2.getStructuringElement / erode / distanceTransform / cvtColor / flip / Rodrigues : definitions of the OpenCV ops
   pytorch3d.transforms.axis_angle_to_matrix : the library's published quaternion route, written with torch ops
   glfw / OpenGL : empty modules (utils/renderer.py only needs to import); the two Renderer objects the function receives
-                  are replaced by a class with the same four methods that rasterises with oracle/raster.py
+                  are replaced by a class with the same four methods that replays the Renderer's GL calls on Mesa llvmpipe
+                  (tests/golden/make_golden_gl.py: MesaRenderer, tools/gl/mesa_raster.c) -- a real OpenGL implementation
 What the vectors therefore pin: merge_normal_images' optimisation loop as the reference's autograd + torch.optim.Adam run
 it (resize_img, get_neighbor_images, the data / smoothness terms, the two-phase schedule, the distance-transform blend,
 the face rectangle's slice semantics), and canonicalize_normal_map's per-vertex chain plus the way render_cano_mesh
@@ -65,7 +66,8 @@ def install_fusion_stubs():
 
 
 class OracleRenderer:
-    """The four methods canonicalize_normal_map / render_cano_mesh call on a Renderer; rasterisation by oracle/raster.py."""
+    """The four methods canonicalize_normal_map / render_cano_mesh call on a Renderer; rasterisation by oracle/raster.py.
+    (Kept for machines without Mesa; the committed goldens are made with make_golden_gl.MesaRenderer = real OpenGL, see main().)"""
 
     def __init__(self, w, h, shader):
         self.img_w, self.img_h, self.shader = w, h, shader
@@ -103,7 +105,18 @@ def main():
     out['G15_cover_lattice'] = merge_normal_images_cover(src.copy(), tar.copy())[::3, ::3]
     # ---- G16: canonicalize_normal_map on the synthetic scene of the tests ---------------------------------------------------
     s = tnf._scene()
-    pos_r, att_r = OracleRenderer(s['W'], s['H'], 'position'), OracleRenderer(512, 512, 'vertex_attribute')
+    # the two Renderer objects of canonicalize_normal_map: REAL OpenGL (Mesa llvmpipe through tools/gl/mesa_raster.c) where the build
+    # container has it -- the golden then carries the reference's function on a real GL implementation --, the oracle rasteriser otherwise
+    try:
+        import make_golden_gl as mgl
+        mgl.install_bin() if hasattr(mgl, 'install_bin') else None
+        pos_r, att_r = mgl.MesaRenderer(s['W'], s['H'], 'position'), mgl.MesaRenderer(512, 512, 'vertex_attribute')
+        pos_r.set_model(np.zeros((3, 3), np.float32)); pos_r.set_mvp_mat(np.eye(4, dtype=np.float32)); pos_r.render()       # probe
+        out['G16_renderer'] = np.array(pos_r.gl_info)
+    except Exception as e:        # noqa: BLE001
+        print('no Mesa harness (%r): the oracle rasteriser stands in for the two Renderers' % (e,))
+        pos_r, att_r = OracleRenderer(s['W'], s['H'], 'position'), OracleRenderer(512, 512, 'vertex_attribute')
+        out['G16_renderer'] = np.array('oracle/raster.py')
     c = np.float32([0.01, -0.02, 0.0])
     with torch.no_grad():
         fr, bk = canonicalize_normal_map(pos_r, att_r, s['v'], s['live'], s['f'], s['obs'], torch.from_numpy(s['M']), s['mv'], s['fx'], s['fy'],
