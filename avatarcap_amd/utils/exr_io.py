@@ -2,8 +2,9 @@
 main.py:408-410, and the EXR position / normal maps of gen_data) -- SURVEY.md section 8(f) item 4.  OpenCV is not part
 of this build; this module follows the published OpenEXR file layout for single-part scanline images with NONE, RLE,
 ZIPS or ZIP compression and HALF / FLOAT / UINT channels (what OpenCV's writer produces).  Tiled, deep, multi-part
-files and the PIZ / PXR24 / B44 / DWA codecs are refused with a clear error.  PARITY UNPINNED against OpenEXR itself:
-the reference ships no EXR file; tests/test_host.py round-trips files produced by an independent writer of the same layout.
+files and the PIZ / PXR24 / B44 / DWA codecs are refused with a clear error.  Pinned on a file written by the OpenEXR
+library with independently known pixel values (tests/golden/openexr_sample.exr + .ppm, tests/test_real_data_seam.py); tests/test_host.py
+also round-trips files produced by an independent writer of the same layout.
 """
 from __future__ import annotations
 

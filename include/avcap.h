@@ -132,14 +132,15 @@ int avc_scatter_volume(avc_ctx *ctx, const uint8_t *valid_dev, int64_t N, const 
 
 /* ---- meshing -------------------------------------------------------------------------------
  * recon_util.recon_mesh (utils/recon_util.py:51-70) with the volume kept on the device:
- * marching cubes at iso (replaces skimage.measure.marching_cubes, :64 -- parity UNPINNED, see
- * DESIGN.md), vertices = index*voxel + b0 + voxel/2 (:62,65), normals = -normalize(trilinear
+ * marching cubes at iso = scikit-image's Lewiner algorithm restated (skimage.measure.marching_cubes, :64): vertices, faces and their
+ * numbering are those of the library call (pinned on outputs of the real library), vertices = index*voxel + b0 + voxel/2 (:62,65), normals = -normalize(trilinear
  * sample of the Sobel gradient volume) (:9-48,66-68), faces flipped [2,1,0] (:69).
  *   vol_dev (X,Y,Z) float32, res = {X,Y,Z}, bounds = {b0x,b0y,b0z,b1x,b1y,b1z}
  *   verts_out_dev (cap_v,3) f32, normals_out_dev (cap_v,3) f32 or NULL, faces_out_dev (cap_f,3) i32
  *   counts_out[2] (HOST) = {V, F}.  Synchronises the stream once (the counts decide the emit
  *   launch sizes).  Returns AVC_ERR_CAPACITY (with counts filled) if V > cap_v or F > cap_f.
- * Output order is canonical (see oracle/mc_oracle.c): vertices by owning grid edge, faces by cell. */
+ * Output order is the library's: cells in (axis 0, axis 1, axis 2) order, a vertex is numbered the first time a triangle refers to it.
+ * counts_out = {0, 0} when no surface crosses iso (the library raises there; the Python mirror restates its exceptions). */
 int avc_recon_mesh(avc_ctx *ctx, const float *vol_dev, const int32_t res[3], const float bounds[6],
                    float iso, float *verts_out_dev, float *normals_out_dev, int32_t *faces_out_dev,
                    int64_t cap_v, int64_t cap_f, int64_t counts_out[2], avc_stream stream);
@@ -150,7 +151,8 @@ int avc_recon_mesh(avc_ctx *ctx, const float *vol_dev, const int32_t res[3], con
  * by -center, x,y in [-1,1] -> size x size pixels (row 0 at y=+1), depth-tested, back faces culled,
  * per-vertex attribute (the canonical normal) interpolated, 0 background; the back map is already
  * mirrored so that both maps are pixel-aligned.  Replaces the reference's OpenGL context + read-back;
- * parity with a GL driver is UNPINNED (oracle/raster_oracle.c).
+
+ * coverage identical to, values within 5e-5 of a real OpenGL implementation (Mesa llvmpipe, tests/golden/gl_golden.npz).
  *   verts_dev, attrs_dev (nv,3) f32; faces_dev (nf,3) i32; front_out_dev, back_out_dev (size,size,3) f32 */
 int avc_render_cano_maps(avc_ctx *ctx, const float *verts_dev, const float *attrs_dev, int64_t nv,
                          const int32_t *faces_dev, int64_t nf, const float center[3], int size,
@@ -162,7 +164,7 @@ int avc_render_cano_maps(avc_ctx *ctx, const float *verts_dev, const float *attr
  * mvp is row-major (the reference uploads it with transpose = GL_TRUE); attrs_dev == NULL renders the positions.
  * out_dev (height, width, 4) f32 RGBA = (perspective-correct attribute, 1), background 0, row 0 at ndc.y = +1 (the
  * reference flips the read-back, renderer.py:449).  Back faces culled, GL_LESS depth test on ndc.z in [-1, 1];
- * triangles with a vertex at w <= 0 are dropped (not clipped).  OpenGL parity UNPINNED, oracle/raster_oracle.c. */
+ * triangles with a vertex at w <= 0 are dropped (not clipped).  Pinned on Mesa llvmpipe like the call above. */
 int avc_render_mesh(avc_ctx *ctx, const float *verts_dev, const float *attrs_dev, int64_t nv, const int32_t *faces_dev,
                     int64_t nf, const float mvp[16], int width, int height, float *out_dev, avc_stream stream);
 

@@ -3,11 +3,11 @@
 PINNED against the reference's own code: tests/golden/make_golden_fusion.py runs /root/reference/normal_fusion/
 normal_fusion.py itself (its autograd + torch.optim.Adam loop, its resize / neighbour / blend / face-rectangle code, its
 per-vertex canonicalisation and render_cano_mesh's matrices) on the tests' synthetic inputs and stores the results in
-tests/golden/fusion_golden.npz; tests/test_normal_fusion.py holds this file to them.  Because OpenCV, pytorch3d and OpenGL
-do not exist offline, that run uses stand-ins for exactly those calls -- so what stays UNPINNED is: cv2.erode /
-cv2.distanceTransform (restated below from their definitions; checked against brute force), pytorch3d's
-axis_angle_to_matrix (restated as published: axis_angle_to_quaternion + quaternion_to_matrix), and the OpenGL
-rasterisation (oracle/raster_oracle.c).  The hand-written gradients are also checked against torch.autograd to 1e-12.
+tests/golden/fusion_golden.npz; tests/test_normal_fusion.py holds this file to them.  OpenCV and pytorch3d do not exist
+offline, so that run uses stand-ins for exactly their calls -- what stays UNPINNED is: cv2.erode /
+cv2.distanceTransform (restated below from their definitions; checked against brute force) and pytorch3d's
+axis_angle_to_matrix (restated as published: axis_angle_to_quaternion + quaternion_to_matrix).  The two OpenGL renderers of that run are
+real OpenGL (Mesa llvmpipe, headless: tests/golden/make_golden_gl.py), which also pins oracle/raster_oracle.c.  The hand-written gradients are also checked against torch.autograd to 1e-12.
 Every function cites the reference line it follows.
 """
 import numpy as np

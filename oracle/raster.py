@@ -1,4 +1,4 @@
-"""ctypes wrapper over oracle/raster_oracle.c -- TEST INFRASTRUCTURE ONLY (parity unpinned vs an OpenGL driver)."""
+"""ctypes wrapper over oracle/raster_oracle.c -- TEST INFRASTRUCTURE ONLY (pinned on Mesa llvmpipe: tests/golden/gl_golden.npz, see raster_oracle.c)."""
 import ctypes
 import os
 import subprocess
