@@ -123,25 +123,61 @@ __global__ void fus_erode_kernel(const uint8_t *__restrict__ in, int H, int W, i
     out[i] = all;
 }
 
-// cv.distanceTransform(DIST_L1, 3): the city-block distance is separable -- along rows first (one thread per row) ...
-__global__ void fus_dt_rows_kernel(const uint8_t *__restrict__ mask, int H, int W, float *__restrict__ g)
+// cv.distanceTransform(DIST_L1, 3): the city-block distance is separable.  Along a row it is the distance to the nearest zero pixel on
+// either side: one wave per row, 64 pixels at a time, the zero pixels of a segment as a ballot mask (highest zero bit at or below the
+// lane, lowest at or above it), the nearest zero of the segments already passed as a carry.  Counts of pixels, exact in fp32; rows
+// without a zero pixel keep the 1e18 the sequential recurrence d = mask ? d + 1 : 0 would leave there.
+constexpr float DT_FAR = 1e18f;
+constexpr int DT_SEGS = 16;
+__global__ __launch_bounds__(64) void fus_dt_rows_kernel(const uint8_t *__restrict__ mask, int H, int W, float *__restrict__ g)
 {
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y >= H) return;
-    float d = 1e18f;
-    for (int x = 0; x < W; ++x) { d = mask[y * W + x] ? d + 1.f : 0.f; g[y * W + x] = d; }
-    d = 1e18f;
-    for (int x = W - 1; x >= 0; --x) { d = mask[y * W + x] ? d + 1.f : 0.f; g[y * W + x] = fminf(g[y * W + x], d); }
+    const int y = blockIdx.x, lane = threadIdx.x;
+    const uint8_t *row = mask + (size_t)y * W;
+    float *out = g + (size_t)y * W;
+    int carry = -1;                                       // x of the nearest zero pixel left of the segment
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const unsigned long long z = __ballot(x < W && row[x] == 0);
+        const unsigned long long below = z & (~0ull >> (63 - lane));
+        const int last = below ? x0 + 63 - __clzll((long long)below) : carry;
+        if (x < W) out[x] = last >= 0 ? (float)(x - last) : DT_FAR;
+        if (z) carry = x0 + 63 - __clzll((long long)z);
+    }
+    carry = -1;                                           // ... and right of it
+    for (int x0 = ((W - 1) / 64) * 64; x0 >= 0; x0 -= 64) {
+        const int x = x0 + lane;
+        const unsigned long long z = __ballot(x < W && row[x] == 0);
+        const unsigned long long above = z >> lane;
+        const int next = above ? x + __ffsll((unsigned long long)above) - 1 : carry;
+        if (x < W && next >= 0) out[x] = fminf(out[x], (float)(next - x));
+        if (z) carry = x0 + __ffsll((unsigned long long)z) - 1;
+    }
 }
-// ... then down the columns
-__global__ void fus_dt_cols_kernel(const float *__restrict__ g, int H, int W, float *__restrict__ out)
+// ... then down the columns: d(y) = min over yy of g(yy) + |y - yy| = min( y + min_{yy <= y} (g(yy) - yy), -y + min_{yy >= y} (g(yy) + yy) ), two
+// running minima.  A workgroup takes 64 columns x DT_SEGS row segments: segment minima through LDS give every segment its carry-in, then one
+// downward and one upward sweep over the segment's rows.  Integer-valued floats (or 1e18, which absorbs the +-y): the same value as the
+// exhaustive minimum, bit for bit.
+__global__ __launch_bounds__(64 * DT_SEGS) void fus_dt_cols_kernel(const float *__restrict__ g, int H, int W, float *__restrict__ out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= H * W) return;
-    const int y = i / W, x = i % W;
-    float d = 1e18f;
-    for (int yy = 0; yy < H; ++yy) d = fminf(d, g[yy * W + x] + fabsf((float)(y - yy)));
-    out[i] = fminf(d, DT_CAP);
+    __shared__ float lo[DT_SEGS][64], hi[DT_SEGS][64];
+    const int lx = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lx;
+    const int rows = (H + DT_SEGS - 1) / DT_SEGS, y0 = seg * rows, y1 = min(H, y0 + rows);
+    float a = DT_FAR, b = DT_FAR;
+    if (x < W)
+        for (int y = y0; y < y1; ++y) { const float v = g[(size_t)y * W + x]; a = fminf(a, v - (float)y); b = fminf(b, v + (float)y); }
+    lo[seg][lx] = a; hi[seg][lx] = b;
+    __syncthreads();
+    if (x >= W) return;
+    float run = DT_FAR;
+    for (int q = 0; q < seg; ++q) run = fminf(run, lo[q][lx]);
+    for (int y = y0; y < y1; ++y) { run = fminf(run, g[(size_t)y * W + x] - (float)y); out[(size_t)y * W + x] = run + (float)y; }
+    run = DT_FAR;
+    for (int q = DT_SEGS - 1; q > seg; --q) run = fminf(run, hi[q][lx]);
+    for (int y = y1 - 1; y >= y0; --y) {
+        run = fminf(run, g[(size_t)y * W + x] + (float)y);
+        out[(size_t)y * W + x] = fminf(fminf(out[(size_t)y * W + x], run - (float)y), DT_CAP);
+    }
 }
 
 __global__ void fus_valid_kernel(const uint8_t *__restrict__ smask, const uint8_t *__restrict__ emask, int n, uint8_t *__restrict__ valid, int *__restrict__ count)
@@ -255,9 +291,10 @@ __global__ __launch_bounds__(256) void fus_pixel_kernel(const float *__restrict_
     }
 }
 
-// one node of the rotation grid per wave: the lanes share the node's transposed-bilinear footprint of g_up (up to
-// ~17 x 17 pixels), a fixed-order butterfly sums them (deterministic), lane 0 adds the smoothness gradient and takes the
-// Adam step
+// one node of the rotation grid per wave: the lanes share the node's transposed-bilinear footprint of g_up (up to ~19 x 19 pixels at
+// 512 / 64): lane & 31 walks the columns, lane >> 5 the rows two at a time, ten rows per lane in flight before the first is consumed (one
+// memory latency per node instead of one per 64 pixels); a fixed-order butterfly sums the lanes (deterministic).  The eight neighbours of
+// the smoothness term go to eight lanes, the three components of the Adam step to three.
 __global__ __launch_bounds__(64) void fus_grid_kernel(const float *__restrict__ rot_in, float *__restrict__ rot_out, const float *__restrict__ g_up,
                                                       int H, int W, float *__restrict__ am, float *__restrict__ av, AdamK ak)
 {
@@ -266,45 +303,57 @@ __global__ __launch_bounds__(64) void fus_grid_kernel(const float *__restrict__ 
     const float sy = (float)(GRID - 1) / (float)(H - 1), sx = (float)(GRID - 1) / (float)(W - 1);
     const int ya = max(0, (int)ceilf((float)(Y - 1) / sy) - 1), yb = min(H - 1, (int)floorf((float)(Y + 1) / sy) + 1);
     const int xa = max(0, (int)ceilf((float)(X - 1) / sx) - 1), xb = min(W - 1, (int)floorf((float)(X + 1) / sx) + 1);
-    const int nx = xb - xa + 1, cnt = nx * (yb - ya + 1);
+    constexpr int ROWS = 10;
     float g[3] = {0.f, 0.f, 0.f};
-    for (int e = lane; e < cnt; e += 64) {
-        const int y = ya + e / nx, x = xa + e % nx;
-        const float py = (float)y * sy, px = (float)x * sx;
-        const int y0 = min((int)floorf(py), GRID - 1), y1 = min(y0 + 1, GRID - 1);
+    for (int x = xa + (lane & 31); x <= xb; x += 32) {
+        const float px = (float)x * sx;
         const int x0 = min((int)floorf(px), GRID - 1), x1 = min(x0 + 1, GRID - 1);
-        const float ty = py - (float)y0, tx = px - (float)x0;
-        const float wy = (y0 == Y ? 1.f - ty : 0.f) + (y1 == Y ? ty : 0.f);
+        const float tx = px - (float)x0;
         const float wx = (x0 == X ? 1.f - tx : 0.f) + (x1 == X ? tx : 0.f);
-        const float w = wy * wx;
-        if (w == 0.f) continue;
-        const float *gp = g_up + 3 * ((size_t)y * W + x);
-        g[0] += w * gp[0]; g[1] += w * gp[1]; g[2] += w * gp[2];
+        for (int yy = ya + (lane >> 5); yy <= yb; yy += 2 * ROWS) {
+            float v[ROWS][3], w[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int y = yy + 2 * r;
+                const bool in = y <= yb;
+                const int yc = in ? y : yb;
+                const float py = (float)yc * sy;
+                const int y0 = min((int)floorf(py), GRID - 1), y1 = min(y0 + 1, GRID - 1);
+                const float ty = py - (float)y0;
+                const float wy = (y0 == Y ? 1.f - ty : 0.f) + (y1 == Y ? ty : 0.f);
+                w[r] = in ? wy * wx : 0.f;
+                const float *gp = g_up + 3 * ((size_t)yc * W + x);
+                v[r][0] = gp[0]; v[r][1] = gp[1]; v[r][2] = gp[2];
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { g[0] += w[r] * v[r][0]; g[1] += w[r] * v[r][1]; g[2] += w[r] * v[r][2]; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { g[0] += __shfl_xor(g[0], o); g[1] += __shfl_xor(g[1], o); g[2] += __shfl_xor(g[2], o); }
-    if (lane != 0) return;
     // smoothness: sum over the 8 neighbour images of mean((shift(rot) - rot)^2), zero padding (normal_fusion.py:66-78,127-131)
     const float cM = 2.f / (float)(GRID * GRID * 3);
     const float *c = rot_in + 3 * n;
-    for (int di = -1; di <= 1; ++di)
-        for (int dj = -1; dj <= 1; ++dj) {
-            if (di == 0 && dj == 0) continue;
-            const int yp = Y + di, xp = X + dj, ym = Y - di, xm = X - dj;
-            const bool inp = yp >= 0 && yp < GRID && xp >= 0 && xp < GRID, inm = ym >= 0 && ym < GRID && xm >= 0 && xm < GRID;
+    float t[3] = {0.f, 0.f, 0.f};
+    if (lane < 8) {
+        const int idx = lane < 4 ? lane : lane + 1, di = idx / 3 - 1, dj = idx % 3 - 1;
+        const int yp = Y + di, xp = X + dj, ym = Y - di, xm = X - dj;
+        const bool inp = yp >= 0 && yp < GRID && xp >= 0 && xp < GRID, inm = ym >= 0 && ym < GRID && xm >= 0 && xm < GRID;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float fwd = c[k] - (inp ? rot_in[(yp * GRID + xp) * 3 + k] : 0.f);
-                const float bwd = inm ? c[k] - rot_in[(ym * GRID + xm) * 3 + k] : 0.f;
-                g[k] += cM * (fwd + bwd);
-            }
+        for (int k = 0; k < 3; ++k) {
+            const float fwd = c[k] - (inp ? rot_in[(yp * GRID + xp) * 3 + k] : 0.f);
+            const float bwd = inm ? c[k] - rot_in[(ym * GRID + xm) * 3 + k] : 0.f;
+            t[k] = cM * (fwd + bwd);
         }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float m = am[3 * n + k], v = av[3 * n + k];
-        rot_out[3 * n + k] = adam_update(c[k], g[k], m, v, ak);
-        am[3 * n + k] = m; av[3 * n + k] = v;
     }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { t[0] += __shfl_xor(t[0], o); t[1] += __shfl_xor(t[1], o); t[2] += __shfl_xor(t[2], o); }
+    if (lane >= 3) return;
+    const int k = lane;
+    const float gk = (k == 0 ? g[0] : k == 1 ? g[1] : g[2]) + (k == 0 ? t[0] : k == 1 ? t[1] : t[2]);
+    float m = am[3 * n + k], v = av[3 * n + k];
+    rot_out[3 * n + k] = adam_update(c[k], gk, m, v, ak);
+    am[3 * n + k] = m; av[3 * n + k] = v;
 }
 
 // merge_normal_images_cover (normal_fusion.py:158-167): the observed normal wherever there is one
@@ -453,8 +502,8 @@ int merge_normal_images(avc_ctx *ctx, const float *src_in, const float *tar_in, 
     const dim3 blk(256), grd((unsigned)((np + 255) / 256));
     hipLaunchKernelGGL(fus_masks_kernel, grd, blk, 0, s, src_in, tar_in, (int)np, B.smask, B.tmask);
     hipLaunchKernelGGL(fus_erode_kernel, grd, blk, 0, s, B.tmask, H, W, 3, B.emask);
-    hipLaunchKernelGGL(fus_dt_rows_kernel, dim3((H + 63) / 64), dim3(64), 0, s, B.emask, H, W, B.dt_g);
-    hipLaunchKernelGGL(fus_dt_cols_kernel, grd, blk, 0, s, B.dt_g, H, W, B.dtm);
+    hipLaunchKernelGGL(fus_dt_rows_kernel, dim3(H), dim3(64), 0, s, B.emask, H, W, B.dt_g);
+    hipLaunchKernelGGL(fus_dt_cols_kernel, dim3((W + 63) / 64), dim3(64 * DT_SEGS), 0, s, B.dt_g, H, W, B.dtm);
     hipLaunchKernelGGL(fus_valid_kernel, grd, blk, 0, s, B.smask, B.emask, (int)np, B.valid, B.count);
     if (iter_num > 0) {
         if (getenv("AVC_FUSION_NO_GRAPH")) {                                                     // A/B knob: plain launches

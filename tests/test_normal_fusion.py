@@ -251,3 +251,26 @@ def test_hip_merge_normal_images_matches_oracle(size, iters, neck, fusion_golden
     assert np.array_equal(merge_normal_images(src, tar, iters, neck), out)            # deterministic
     assert np.array_equal(merge_normal_images_cover(src, tar), nfo.merge_normal_images_cover(src, tar))
     assert np.array_equal(merge_normal_images(src, np.zeros_like(tar), 4, neck), src)
+
+
+@pytest.mark.gpu
+def test_hip_merge_non_square_ragged_image():
+    """Rows and columns that are no multiple of anything the kernels tile by (wave-wide row segments, 64-column blocks, 16 row segments of the
+    distance transform): a 93 x 75 crop, HIP vs the oracle; the distance-transform blend outside the observed region is exact."""
+    from avatarcap_amd import config
+    from avatarcap_amd.normal_fusion.normal_fusion import merge_normal_images
+    config.device = torch.device('cuda')
+    _, src, tar = _case(9, H=96)
+    src, tar = np.ascontiguousarray(src[2:95, 11:86], np.float32), np.ascontiguousarray(tar[2:95, 11:86], np.float32)
+    assert src.shape == (93, 75, 3)
+    ref = nfo.merge_normal_images(src, tar, 12, (30, 70), np.float64)
+    out = merge_normal_images(src, tar, 12, (30, 70))
+    d = np.abs(out - ref)
+    assert d.mean() < 2e-5 and d.max() < 2e-2, (d.max(), d.mean())
+    obs = nfo.erode3x3(np.linalg.norm(tar, axis=-1) > 0, 3) > 0
+    assert np.array_equal(out[~obs], src[~obs])
+    # no observed pixel at all / every pixel observed: the distance transform's two saturated ends
+    assert np.array_equal(merge_normal_images(src, np.zeros_like(tar), 3, (30, 70)), src)
+    full = np.ascontiguousarray(np.where(np.linalg.norm(tar, axis=-1, keepdims=True) > 0, tar, np.float32([0, 0, 1])), np.float32)
+    o2, r2 = merge_normal_images(src, full, 3, (30, 70)), nfo.merge_normal_images(src, full, 3, (30, 70), np.float64)
+    assert np.abs(o2 - r2).max() < 2e-2 and np.abs(o2 - r2).mean() < 2e-5
