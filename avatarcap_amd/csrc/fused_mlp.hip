@@ -298,54 +298,61 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
     so &= 0u;
 #endif
 
-    half8 ah[2][TPC], al[2][TPC];
+    // The chunk is walked as Q steps of T2 (two, or one for the single-tile heads) output tiles: step q = k-step q / G, tile group q % G.  Units are
+    // k-major in LDS, so step q's A fragments are units q * T2 .. q * T2 + T2 - 1 whatever TPC is -- an 8-tile chunk (recon fc1) is the same loop as
+    // a 2-tile chunk with four times the k-steps, its B fragment changing every G steps: only the fragments of one tile pair and of the next are
+    // live (32 registers; holding a whole 8-tile k-step and its successor was 128, and the recon kernel spilled 350 registers for it).
+    constexpr int T2 = TPC >= 2 ? 2 : 1, G = TPC / T2, Q = KS * G;
+    static_assert(TPC == 1 || TPC % 2 == 0, "tiles per chunk: 1 or even");
+    half8 ah[2][T2], al[2][T2];
     Frag b[2];
     b[0] = in.template get<0>();
 #pragma unroll
-    for (int t = 0; t < TPC; ++t) {
+    for (int t = 0; t < T2; ++t) {
         ah[0][t] = *reinterpret_cast<const half8 *>(smem + base + t * layout::UNIT_BYTES);
         al[0][t] = *reinterpret_cast<const half8 *>(smem + base + t * layout::UNIT_BYTES + 1024);
     }
-    static_for<KS>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        constexpr int cur = k & 1, nxt = cur ^ 1;
+    static_for<Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int cur = q & 1, nxt = cur ^ 1;
+        f32x16 *const a2 = acc + (q % G) * T2;
         // ---- slot 0
-        // ONE wait for this k-step's operands (requested a whole k-step ago), before the next k-step's reads go out: hipcc would otherwise put
-        // a counted `s_waitcnt lgkmcnt(n)` in front of every MFMA that touches a freshly read fragment, four issue slots per k-step
+        // ONE wait for this step's operands (requested a whole step ago), before the next step's reads go out: hipcc would otherwise put
+        // a counted `s_waitcnt lgkmcnt(n)` in front of every MFMA that touches a freshly read fragment, four issue slots per step
         __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0), vmcnt / expcnt untouched
-        if constexpr (k + 1 < KS) {
-            b[nxt] = in.template get<k + 1>();
+        if constexpr (q + 1 < Q) {
+            b[nxt] = in.template get<(q + 1) / G>();
 #pragma unroll
-            for (int t = 0; t < TPC; ++t) {
+            for (int t = 0; t < T2; ++t) {
 #if AVC_DBG_NO_LDSREAD
                 ah[nxt][t] = ah[cur][t]; al[nxt][t] = al[cur][t];
 #else
-                ah[nxt][t] = *reinterpret_cast<const half8 *>(smem + base + ((k + 1) * TPC + t) * layout::UNIT_BYTES);
-                al[nxt][t] = *reinterpret_cast<const half8 *>(smem + base + ((k + 1) * TPC + t) * layout::UNIT_BYTES + 1024);
+                ah[nxt][t] = *reinterpret_cast<const half8 *>(smem + base + ((q + 1) * T2 + t) * layout::UNIT_BYTES);
+                al[nxt][t] = *reinterpret_cast<const half8 *>(smem + base + ((q + 1) * T2 + t) * layout::UNIT_BYTES + 1024);
 #endif
             }
         }
-        pf_step<KS, NEXT_BYTES, 3 * k + 0>(s.rs, so, dst, s.lane_off, s.wave);
-        static_for<TPC>([&](auto tc) {
+        pf_step<Q, NEXT_BYTES, 3 * q + 0>(s.rs, so, dst, s.lane_off, s.wave);
+        static_for<T2>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
-            if constexpr (TPC == 2) { side(kc, RegionC<t>{}); __builtin_amdgcn_sched_barrier(0); }
+            a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].hi), a2[t], 0, 0, 0);
+            if constexpr (TPC == 2) { side(qc, RegionC<t>{}); __builtin_amdgcn_sched_barrier(0); }
         });
         __builtin_amdgcn_sched_barrier(0);
         // ---- slot 1
-        pf_step<KS, NEXT_BYTES, 3 * k + 1>(s.rs, so, dst, s.lane_off, s.wave);
-        static_for<TPC>([&](auto tc) {
+        pf_step<Q, NEXT_BYTES, 3 * q + 1>(s.rs, so, dst, s.lane_off, s.wave);
+        static_for<T2>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].lo), acc[t], 0, 0, 0);
-            if constexpr (TPC == 2) { side(kc, RegionC<2 + t>{}); __builtin_amdgcn_sched_barrier(0); }
+            a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].lo), a2[t], 0, 0, 0);
+            if constexpr (TPC == 2) { side(qc, RegionC<2 + t>{}); __builtin_amdgcn_sched_barrier(0); }
         });
         __builtin_amdgcn_sched_barrier(0);
         // ---- slot 2
-        pf_step<KS, NEXT_BYTES, 3 * k + 2>(s.rs, so, dst, s.lane_off, s.wave);
-        static_for<TPC>([&](auto tc) {
+        pf_step<Q, NEXT_BYTES, 3 * q + 2>(s.rs, so, dst, s.lane_off, s.wave);
+        static_for<T2>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], as_half8(b[cur].hi), acc[t], 0, 0, 0);
-            if constexpr (TPC == 2) { side(kc, RegionC<4 + t>{}); __builtin_amdgcn_sched_barrier(0); }
+            a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], as_half8(b[cur].hi), a2[t], 0, 0, 0);
+            if constexpr (TPC == 2) { side(qc, RegionC<4 + t>{}); __builtin_amdgcn_sched_barrier(0); }
         });
         __builtin_amdgcn_sched_barrier(0);
     });
