@@ -3,13 +3,13 @@
 //                    avatarcap_dataset.py:114, arch_avatar.py:190,208).  Exact K nearest, squared L2
 //                    ascending, ties -> lower index.  The reference points are binned into a uniform grid
 //                    (<= 32^3 cells, rebuilt on the device per call: one workgroup, tens of us for the 6890
-//                    SMPL vertices).  A WAVE searches together: it takes the cell bounding box of its 64
-//                    queries and scans the cells of that box, then ring after ring around it, until every
-//                    lane's K-th best is closer than the nearest unscanned cell face.  All control flow and
-//                    all candidate addresses are wave-uniform, so candidates arrive through scalar loads and
-//                    each costs ~9 VALU ops per lane, as in a brute-force scan -- but mesh vertices / grid
-//                    points that sit next to each other only ever look at the few hundred candidates around
-//                    them instead of all of them.  Small or huge reference sets use the brute-force scan
+//                    SMPL vertices).  A WAVE of coherent queries searches together: it takes the cell bounding box
+//                    of its 64 queries and scans the cells of that box, then ring after ring around it, until every
+//                    lane's K-th best is closer than the nearest unscanned cell face; control flow and candidate
+//                    addresses are wave-uniform, so candidates arrive through scalar loads at ~9 VALU per lane each.
+//                    A wave whose queries span a large box (marching-cubes vertices in the library's order trace the
+//                    contour of a slice; scattered queries) lets every lane search the 27 cells around its own query
+//                    instead (knn_lane_scan).  Reference sets too small for a grid use the exhaustive scan
 //                    (reference points staged through LDS in tiles).
 //   calculate_lbs  : KNN-4 + Gaussian weights + gather/blend of the 24-wide skin weights (:24-39), fused
 //   skinning       : per-point blend of the 24 joint 4x4s and its application to points / normals (:58-81)
@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <cmath>
 
@@ -83,7 +84,7 @@ __device__ __forceinline__ void knn_scan(const float *__restrict__ ref, int nr, 
 // ---- uniform grid over the reference points ----------------------------------------------------
 constexpr int GRID_MAX_AXIS = 128;              // cells per axis (upper bound)
 constexpr int GRID_MIN_REFS = 512;               // below: exhaustive scan only
-constexpr int GRID_FALLBACK_REFS = 1 << 16;      // above: no exhaustive-scan fallback for scattered workgroups
+constexpr int LANE_BOX = 64;                     // cells of a wave's box (+ one ring) above which its lanes search on their own (knn_lane_scan)
 struct GridHdr { float ox, oy, oz, h, inv_h, eps; int nx, ny, nz, ncell; };
 
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int n)
@@ -179,11 +180,16 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float *__restri
         sorted[nr + threadIdx.x] = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
 }
 
-// insertion under the total order (distance, index): candidates arrive in cell order, not index order
+// insertion under the total order (distance, index): candidates arrive in cell order, not index order.  A candidate that is already in the
+// list is skipped: a wave whose lanes first looked around themselves (knn_lane_ring1) rescans those cells when it goes on cooperatively.
 template <int K>
 __device__ __forceinline__ void knn_insert_lex(float d, int id, float (&bd)[K], int (&bi)[K])
 {
     if (d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1])) {
+        bool seen = false;
+#pragma unroll
+        for (int k = 0; k < K - 1; ++k) seen = seen || bi[k] == id;
+        if (seen) return;
         bd[K - 1] = d; bi[K - 1] = id;
 #pragma unroll
         for (int k = K - 1; k > 0; --k) {
@@ -260,15 +266,16 @@ __device__ __forceinline__ void scan_box(const int *__restrict__ start, const fl
 // the lane's distance to the nearest such face away (less `eps` for the rounding of the cell assignment).
 template <int K>
 __device__ __forceinline__ void knn_grid_scan(const GridHdr *__restrict__ hdr, const int *__restrict__ start, const float4 *__restrict__ sorted,
-                                              float qx, float qy, float qz, float (&bd)[K], int (&bi)[K])
+                                              float qx, float qy, float qz, float (&bd)[K], int (&bi)[K], bool settled)
 {
+    // `settled` lanes already hold their exact answer (knn_lane_ring1): they ride along, but neither shape the box nor keep the wave going
     const float ox = hdr->ox, oy = hdr->oy, oz = hdr->oz, h = hdr->h, inv_h = hdr->inv_h, eps = hdr->eps;
     const int nx = hdr->nx, ny = hdr->ny, nz = hdr->nz;
     const GridDims g{nx, ny, nz};
-#pragma unroll
-    for (int k = 0; k < K; ++k) { bd[k] = __builtin_inff(); bi[k] = 0x7fffffff; }
     const int cx = cell_coord(qx, ox, inv_h, nx), cy = cell_coord(qy, oy, inv_h, ny), cz = cell_coord(qz, oz, inv_h, nz);
-    const int lx = wave_mini(cx), hx = wave_maxi(cx), ly = wave_mini(cy), hy = wave_maxi(cy), lz = wave_mini(cz), hz = wave_maxi(cz);
+    const int big = 0x3fffffff;
+    const int lx = wave_mini(settled ? big : cx), hx = wave_maxi(settled ? -big : cx), ly = wave_mini(settled ? big : cy), hy = wave_maxi(settled ? -big : cy),
+              lz = wave_mini(settled ? big : cz), hz = wave_maxi(settled ? -big : cz);
     scan_box<K>(start, sorted, g, lx, hx, ly, hy, lz, hz, qx, qy, qz, bd, bi);
     for (int r = 0, rp = 0;;) {                  // box radius scanned so far (r) and before that (rp), in cells around [l, h]
         const int X0 = max(lx - r, 0), X1 = min(hx + r, nx - 1), Y0 = max(ly - r, 0), Y1 = min(hy + r, ny - 1),
@@ -293,7 +300,7 @@ __device__ __forceinline__ void knn_grid_scan(const GridHdr *__restrict__ hdr, c
         if (Z0 > 0) b = fminf(b, qz - (oz + (float)Z0 * h));
         if (Z1 < nz - 1) b = fminf(b, (oz + (float)(Z1 + 1) * h) - qz);
         b = fmaxf(b - eps, 0.f);
-        const bool done = bd[K - 1] < b * b;
+        const bool done = settled || bd[K - 1] < b * b;
         if (__all(done)) break;
         // next radius: grow by a quarter (at least one cell), but never beyond the radius that settles the worst unsettled
         // lane even if its K-th best does not improve any more
@@ -305,32 +312,68 @@ __device__ __forceinline__ void knn_grid_scan(const GridHdr *__restrict__ hdr, c
     }
 }
 
-struct GridView { const GridHdr *hdr; const int *start; const float4 *sorted; uint8_t *flags; int scatter_div; };   // hdr == nullptr: brute force
+// First look of an INCOHERENT wave: every lane scans the 3 x 3 x 3 cells around its own query (per-lane vector loads, divergent trip counts:
+// ~1.5x the cost per candidate of the cooperative scan) and applies the stopping rule to that box.  Marching-cubes vertices arrive in the
+// library's order -- rows of cells along the last axis, a few crossings per row -- so the 64 queries of a wave trace a whole contour of a slice
+// and their common box holds hundreds of cells; but a vertex of the avatar is within a cell or two of the SMPL surface and settles here.
+// Returns whether the lane's answer is final; the lanes that are not go on together (knn_grid_scan, which skips what is already listed).
+template <int K>
+__device__ __forceinline__ bool knn_lane_ring1(const GridHdr *__restrict__ hdr, const int *__restrict__ start, const float4 *__restrict__ sorted,
+                                               float qx, float qy, float qz, float (&bd)[K], int (&bi)[K])
+{
+    const float ox = hdr->ox, oy = hdr->oy, oz = hdr->oz, h = hdr->h, inv_h = hdr->inv_h, eps = hdr->eps;
+    const int nx = hdr->nx, ny = hdr->ny, nz = hdr->nz;
+    const int cx = cell_coord(qx, ox, inv_h, nx), cy = cell_coord(qy, oy, inv_h, ny), cz = cell_coord(qz, oz, inv_h, nz);
+    const int X0 = max(cx - 1, 0), X1 = min(cx + 1, nx - 1), Y0 = max(cy - 1, 0), Y1 = min(cy + 1, ny - 1), Z0 = max(cz - 1, 0), Z1 = min(cz + 1, nz - 1);
+    for (int x = X0; x <= X1; ++x)
+        for (int y = Y0; y <= Y1; ++y) {
+            const int c0 = (x * ny + y) * nz;
+            const int s = start[c0 + Z0], e = start[c0 + Z1 + 1];               // cells are stored z fastest: one contiguous range per column
+            for (int j = s; j < e; ++j) {
+                const float4 c = sorted[j];
+                const float d = cand_d2(c, qx, qy, qz);
+                if (d <= bd[K - 1]) knn_insert_lex<K>(d, __float_as_int(c.w), bd, bi);
+            }
+        }
+    if (X0 == 0 && X1 == nx - 1 && Y0 == 0 && Y1 == ny - 1 && Z0 == 0 && Z1 == nz - 1) return true;
+    float b = __builtin_inff();
+    if (X0 > 0) b = fminf(b, qx - (ox + (float)X0 * h));
+    if (X1 < nx - 1) b = fminf(b, (ox + (float)(X1 + 1) * h) - qx);
+    if (Y0 > 0) b = fminf(b, qy - (oy + (float)Y0 * h));
+    if (Y1 < ny - 1) b = fminf(b, (oy + (float)(Y1 + 1) * h) - qy);
+    if (Z0 > 0) b = fminf(b, qz - (oz + (float)Z0 * h));
+    if (Z1 < nz - 1) b = fminf(b, (oz + (float)(Z1 + 1) * h) - qz);
+    b = fmaxf(b - eps, 0.f);
+    return bd[K - 1] < b * b;
+}
 
-// Two launches share the work of a call.  The grid launch (GRID = true) serves every workgroup whose waves
-// are spatially coherent; a workgroup holding a wave whose queries are scattered over more than a quarter of
-// the grid would end up scanning most cells through the (slower) scalar path, so it only raises its flag and
-// leaves.  The exhaustive launch (GRID = false) then serves exactly the flagged workgroups (all of them when
-// there is no grid: flags == nullptr).  Returns false when this launch has nothing to do for the workgroup.
+struct GridView { const GridHdr *hdr; const int *start; const float4 *sorted; int lane_box; };   // hdr == nullptr: brute force
+
+// GRID = true: the grid search.  A coherent wave searches cooperatively (candidates through scalar loads, shared by the lanes); a wave whose
+// box-plus-one-ring holds more than `lane_box` cells lets every lane look around itself first, and only the lanes that stay unsettled (far from
+// every reference point) go on cooperatively.  (An exhaustive-scan escape for workgroups of scattered queries inside this kernel was tried:
+// its 32 KiB of LDS cut the occupancy and cost the common cases 50 %; uniformly scattered queries, which the frame loop never issues, are
+// the one case where the exhaustive scan would be faster, 4.4 against 8.2 ms for 1.9 M.)  GRID = false: the exhaustive LDS-tiled scan, for reference sets too small
+// for a grid (and AVC_KNN_BRUTE=1, which the tests use to hold the grid search to it bit for bit).
 template <int K, bool GRID>
-__device__ __forceinline__ bool knn_any(const float *__restrict__ ref, int nr, const GridView &g, float qx, float qy, float qz,
+__device__ __forceinline__ void knn_any(const float *__restrict__ ref, int nr, const GridView &g, float qx, float qy, float qz,
                                         float (&bd)[K], int (&bi)[K])
 {
     if constexpr (GRID) {
         const GridHdr *hdr = g.hdr;
         const int cx = cell_coord(qx, hdr->ox, hdr->inv_h, hdr->nx), cy = cell_coord(qy, hdr->oy, hdr->inv_h, hdr->ny),
                   cz = cell_coord(qz, hdr->oz, hdr->inv_h, hdr->nz);
-        const int box = (wave_maxi(cx) - wave_mini(cx) + 1) * (wave_maxi(cy) - wave_mini(cy) + 1) * (wave_maxi(cz) - wave_mini(cz) + 1);
-        const bool scattered = __syncthreads_or(g.scatter_div * box > hdr->ncell);
-        if (threadIdx.x == 0) g.flags[blockIdx.x] = scattered;
-        if (scattered) return false;
-        knn_grid_scan<K>(hdr, g.start, g.sorted, qx, qy, qz, bd, bi);
+        const int bx = wave_maxi(cx) - wave_mini(cx) + 1, by = wave_maxi(cy) - wave_mini(cy) + 1, bz = wave_maxi(cz) - wave_mini(cz) + 1;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { bd[k] = __builtin_inff(); bi[k] = 0x7fffffff; }
+        bool settled = false;
+        if ((bx + 2) * (by + 2) * (bz + 2) > g.lane_box) settled = knn_lane_ring1<K>(hdr, g.start, g.sorted, qx, qy, qz, bd, bi);
+        if (__all(settled)) return;
+        knn_grid_scan<K>(hdr, g.start, g.sorted, qx, qy, qz, bd, bi, settled);
     } else {
         __shared__ float4 lds[REF_TILE];
-        if (g.flags && !g.flags[blockIdx.x]) return false;
         knn_scan<K>(ref, nr, qx, qy, qz, bd, bi, lds);
     }
-    return true;
 }
 
 template <int K, bool GRID>
@@ -340,7 +383,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ q, i
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ii = i < nq ? i : nq - 1;
     float bd[K]; int bi[K];
-    if (!knn_any<K, GRID>(ref, nr, g, q[3 * ii], q[3 * ii + 1], q[3 * ii + 2], bd, bi)) return;
+    knn_any<K, GRID>(ref, nr, g, q[3 * ii], q[3 * ii + 1], q[3 * ii + 2], bd, bi);
     if (i < nq) {
 #pragma unroll
         for (int k = 0; k < K; ++k) { if (d2) d2[i * K + k] = bd[k]; if (idx) idx[i * K + k] = bi[k]; }
@@ -354,7 +397,7 @@ __global__ __launch_bounds__(256) void lbs_kernel(const float *__restrict__ pts,
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ii = i < n ? i : n - 1;
     float bd[4]; int bi[4];
-    if (!knn_any<4, GRID>(cano_v, nv, g, pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2], bd, bi)) return;
+    knn_any<4, GRID>(cano_v, nv, g, pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2], bd, bi);
     if (i >= n) return;
     // weights = exp(-dists / (2 r^2)), r = 0.05; weights /= sum + 1e-16     (smpl_util.py:34-36)
     const float denom = (float)(2 * 0.05 * 0.05);
@@ -427,13 +470,13 @@ __global__ __launch_bounds__(256) void skinning_kernel(const float *__restrict__
 // Builds the grid over `ref` in the context's scratch (stream-ordered; no host synchronisation).
 static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, GridView &g, hipStream_t s)
 {
-    g = GridView{nullptr, nullptr, nullptr, nullptr, 0};
+    g = GridView{nullptr, nullptr, nullptr, 0};
     if (nr < GRID_MIN_REFS || getenv("AVC_KNN_BRUTE")) return AVC_OK;
     // cells per axis: about one occupied cell per few reference points for surface-like sets (6890 -> 32, 1e6 -> 128)
     const int axis = std::min(GRID_MAX_AXIS, std::max(8, (int)(1.7 * cbrt((double)nr))));
     const size_t ncell = (size_t)axis * axis * axis;
     const size_t cells = (ncell + 64 + 1) & ~(size_t)1;      // even: the two int arrays together stay a multiple of 16 bytes, so `sorted` (float4) is aligned
-    const size_t bytes = 256 + 2 * sizeof(int) * cells + sizeof(float4) * ((size_t)nr + 8) + (size_t)((nq + 255) / 256);
+    const size_t bytes = 256 + 2 * sizeof(int) * cells + sizeof(float4) * ((size_t)nr + 8);
     if (ctx->knn_scratch_bytes < bytes) {
         if (ctx->knn_scratch) AVC_HIP(hipFree(ctx->knn_scratch));
         ctx->knn_scratch = nullptr; ctx->knn_scratch_bytes = 0;
@@ -456,10 +499,8 @@ static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, Gri
     hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, hdr, start, cursor);
     hipLaunchKernelGGL(grid_scatter_kernel, blocks, threads, 0, s, ref, nr, hdr, cursor, sorted);
     AVC_HIP(hipGetLastError());
-    // Workgroups with scattered queries fall back to the exhaustive scan only while that is affordable; beyond it the
-    // grid search (which then degenerates into one pass over the sorted array) is the exhaustive scan.
-    const char *sd = getenv("AVC_KNN_SCATTER_DIV");     // debugging knob: 0 = never fall back
-    g = GridView{hdr, start, sorted, reinterpret_cast<uint8_t *>(sorted + nr + 8), sd ? atoi(sd) : (nr <= GRID_FALLBACK_REFS ? 4 : 0)};
+    const char *path = getenv("AVC_KNN_PATH");          // debugging / test knob: "lane" or "wave" forces one search for every wave
+    g = GridView{hdr, start, sorted, path && !strcmp(path, "lane") ? 0 : (path && !strcmp(path, "wave") ? 0x7fffffff : LANE_BOX)};
     return AVC_OK;
 }
 
@@ -471,7 +512,7 @@ int knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, 
     const dim3 grid((unsigned)((nq + 255) / 256)), block(256);
     switch (K) {
 #define CASE(k) case k: if (g.hdr) hipLaunchKernelGGL((knn_kernel<k, true>), grid, block, 0, s, q, nq, ref, nr, g, d2, idx); \
-                       hipLaunchKernelGGL((knn_kernel<k, false>), grid, block, 0, s, q, nq, ref, nr, g, d2, idx); break;
+                       else hipLaunchKernelGGL((knn_kernel<k, false>), grid, block, 0, s, q, nq, ref, nr, g, d2, idx); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
         default: set_error("avc_knn: unsupported K %d", K); return AVC_ERR_ARG;
@@ -487,7 +528,7 @@ int calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v
     if (int rc = make_grid(ctx, cano_v, nv, n, g, s)) return rc;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (g.hdr) hipLaunchKernelGGL(lbs_kernel<true>, grid, block, 0, s, pts, n, cano_v, skin_w, nv, g, lbs);
-    hipLaunchKernelGGL(lbs_kernel<false>, grid, block, 0, s, pts, n, cano_v, skin_w, nv, g, lbs);
+    else hipLaunchKernelGGL(lbs_kernel<false>, grid, block, 0, s, pts, n, cano_v, skin_w, nv, g, lbs);
     AVC_HIP(hipGetLastError());
     return AVC_OK;
 }

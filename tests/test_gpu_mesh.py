@@ -145,6 +145,11 @@ def test_knn_grid_equals_brute_force(body, K, monkeypatch):
         d_b, i_b = su.knn_points(qt, rt, K=K)
         monkeypatch.delenv('AVC_KNN_BRUTE')
         assert torch.equal(i_g, i_b) and torch.equal(d_g, d_b)
+        for path in ('lane', 'wave'):                                          # each of the two grid searches on its own, every wave
+            monkeypatch.setenv('AVC_KNN_PATH', path)
+            d_p, i_p = su.knn_points(qt, rt, K=K)
+            monkeypatch.delenv('AVC_KNN_PATH')
+            assert torch.equal(i_p, i_b) and torch.equal(d_p, d_b), path
         assert bool((d_g[0, :, 1:] >= d_g[0, :, :-1]).all())
         if K > 1:                                                              # ties resolved towards the lower index
             tie = d_g[0, :, 1:] == d_g[0, :, :-1]
@@ -170,6 +175,11 @@ def test_knn_large_reference_set(body, K, monkeypatch):
     d_b, i_b = su.knn_points(qt, rt, K=K)
     monkeypatch.delenv('AVC_KNN_BRUTE')
     assert torch.equal(i_g, i_b) and torch.equal(d_g, d_b)
+    for path in ('lane', 'wave'):
+        monkeypatch.setenv('AVC_KNN_PATH', path)
+        d_p, i_p = su.knn_points(qt, rt, K=K)
+        monkeypatch.delenv('AVC_KNN_PATH')
+        assert torch.equal(i_p, i_b) and torch.equal(d_p, d_b), path
     dd = torch.cdist(qt[0, :2000].double(), rt[0].double()) ** 2                # an independent check of a sample
     assert float((dd.min(1).values - d_g[0, :2000, 0].double()).abs().max()) < 1e-6
 
