@@ -442,9 +442,11 @@ __device__ __forceinline__ void vertex_position(const McArgs &a, int z, int y, i
 
 struct CellRec { uint32_t li, row, face0; int32_t cvid; };     // one per crossed cell, in traversal order
 
-// Creators only describe their vertices (cell, edge) in LDS, in output order; then the whole workgroup shares the
+// Creators only describe their vertices (cell, edge), in output order; then the whole workgroup shares the
 // position / normal evaluation, one vertex per thread per round: the 64-tap normal stencil is by far the most
-// expensive part, and vertices cluster in few cells of a tile.
+// expensive part, and vertices cluster in few cells of a tile.  The descriptor of vertex id waits in the first word of
+// the vertex's own output slot (verts[3 * id], overwritten by the position): a worst-case LDS array (13 per cell,
+// 26 KiB) held the kernel at 3 workgroups per CU.
 __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, const unsigned *__restrict__ tile_voff, const unsigned *__restrict__ tile_toff,
                                                        const unsigned *__restrict__ tile_coff, unsigned total_v, unsigned total_t,
                                                        int32_t *__restrict__ edge_map, CellRec *__restrict__ cells,
@@ -452,7 +454,6 @@ __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, con
 {
     __shared__ uint32_t tab[mc::BLOB_WORDS];
     __shared__ unsigned red[4];
-    __shared__ uint16_t desc[13 * TILE];     // (tile-local cell << 4) | edge id, in output order
     load_tables(a.tables, tab);
     const int yx = a.n1 * a.n2;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, con
                 seen |= 1u << ed;
                 if (!(creator & (1u << ed))) continue;
                 const int32_t id = (int32_t)(vbase + loc);
-                desc[loc] = (uint16_t)(((threadIdx.x * 4 + k) << 4) | ed);
+                reinterpret_cast<uint32_t *>(verts)[3 * (size_t)id] = (uint32_t)(((threadIdx.x * 4 + k) << 4) | ed);     // (tile-local cell << 4) | edge id
                 ++loc;
                 if (ed == 12) { cvid = id; continue; }
                 int dx, dy, dz, axis;
@@ -507,9 +508,9 @@ __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, con
             cells[cloc] = r;
             floc += n / 3; ++cloc;
         }
-        __syncthreads();
+        __syncthreads();          // (workgroup-scope fence: the descriptors are visible)
         for (unsigned j = threadIdx.x; j < total; j += 256) {
-            const unsigned d = desc[j];
+            const unsigned d = reinterpret_cast<const uint32_t *>(verts)[3 * ((size_t)vbase + j)];
             const int64_t li = (int64_t)tile * TILE + (d >> 4);
             const int z = (int)(li / yx), rem = (int)(li - (int64_t)z * yx);
             float vidx[3], out[3];
@@ -525,7 +526,6 @@ __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, con
                 normals[3 * id + 0] = n[0]; normals[3 * id + 1] = n[1]; normals[3 * id + 2] = n[2];
             }
         }
-        __syncthreads();      // the descriptors are rewritten by the next tile
     }
 }
 
