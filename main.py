@@ -86,10 +86,12 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
     else:
         raise TypeError('Invalid frame_idx!')
 
-    for i in frames:
-        items = to_cuda(ds[i * img_num_per_pose + view_idx], add_batch=True)      # main.py:349-351
+    load = lambda i: to_cuda(ds[i * img_num_per_pose + view_idx], add_batch=True)     # main.py:349-351
+    nxt = load(frames[0]) if frames else None
+    for n, i in enumerate(frames):
+        items, nxt = nxt, (load(frames[n + 1]) if n + 1 < len(frames) else None)  # one frame of look-ahead: its U-Net is queued behind this frame's query
         data_idx = int(items['data_idx'])
-        a = pipe.avatar_frame(items)                                              # step 1
+        a = pipe.avatar_frame(items, next_items=nxt)                              # step 1
         save = {'cano_v': a['cano_v'], 'cano_vn': a['cano_vn'], 'f': a['f'], 'live_v': a.get('live_v'), 'live_vn': a.get('live_vn')}
         if w_recon:
             # step 2: canonical normal fusion (main.py:405-433)

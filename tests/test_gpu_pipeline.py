@@ -132,6 +132,30 @@ def test_avatar_frame_64_matches_oracle(pipe64):
     assert out2['cano_v'].shape[0] > 0 and not torch.equal(out2['occ_volume'], out['occ_volume'])
 
 
+def test_next_frame_lookahead_changes_nothing(pipe64):
+    """avatar_frame(items, next_items=...) queues the next frame's U-Net behind this frame's query; the next call must recognise its input,
+    skip the U-Net and return bit for bit what a plain call returns -- and ignore the look-ahead when another frame arrives instead."""
+    from avatarcap_amd.dataset import to_cuda
+    ds = pipe64.ds
+    f0, f1 = to_cuda(ds[0], add_batch=True), to_cuda(ds[1], add_batch=True)
+    plain0, plain1 = pipe64.avatar_frame(f0), pipe64.avatar_frame(f1)
+    calls = []
+    unet = pipe64.network.warping_field.unet
+    hook = unet.register_forward_hook(lambda *a: calls.append(1))
+    try:
+        a0 = pipe64.avatar_frame(f0, next_items=f1)
+        assert len(calls) == 2 and pipe64._next_map is not None                 # this frame's map and the next one's
+        a1 = pipe64.avatar_frame(f1)
+        assert len(calls) == 2 and pipe64._next_map is None                     # no third U-Net pass
+        for k in ('occ_volume', 'cano_v', 'cano_vn', 'f', 'live_v', 'live_vn'):
+            assert torch.equal(a0[k], plain0[k]) and torch.equal(a1[k], plain1[k]), k
+        pipe64.avatar_frame(f0, next_items=f1)
+        b0 = pipe64.avatar_frame(f0)                                            # not the announced frame: computed afresh
+        assert len(calls) == 5 and torch.equal(b0['occ_volume'], plain0['occ_volume']) and torch.equal(b0['f'], plain0['f'])
+    finally:
+        hook.remove()
+
+
 def test_recon_frame_64(pipe64):
     from avatarcap_amd.dataset import to_cuda
     from oracle import avatarcap_oracle as orc
