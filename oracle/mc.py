@@ -1,5 +1,5 @@
 """ctypes wrapper over oracle/mc_oracle.c -- TEST INFRASTRUCTURE ONLY.  The C file restates scikit-image's Lewiner
-marching cubes and is pinned against the real library (tests/golden/mc_golden.npz, tools/mc_fuzz.py; see its header).
+marching cubes and is pinned against the real library (tests/golden/mc_golden.npz, tests/tools/mc_fuzz.py; see its header).
 `build()` compiles with gcc into oracle/_build/."""
 from __future__ import annotations
 

@@ -11,7 +11,7 @@ listed in the 0.18 release notes).  The GPU box never runs this script; it only 
 Stored per case k:  vol_k (float32 volume), iso_k, spacing_k (float32 x3), verts_k (V,3) float32 and
 faces_k (F,3) int32 exactly as the library returns them (gradient_direction='descent', allow_degenerate=True).
 Cases: white noise (every case and sub-case of the algorithm that random data reaches: 36 of the 38 tiling tables;
-12.1.2 and 13.5.2 did not occur in 4e5 directed trials nor in 1.9e7 fuzzed cells, tools/mc_fuzz.py), small integers and plateaus
+12.1.2 and 13.5.2 did not occur in 4e5 directed trials nor in 1.9e7 fuzzed cells, tests/tools/mc_fuzz.py), small integers and plateaus
 (ties of the face / interior tests, values equal to iso), analytic bodies (sphere, torus, two spheres),
 anisotropic spacing, non-cubic shapes, the minimum 2x2x2 volume, scaled noise (1e-6 .. 1e3).
 """

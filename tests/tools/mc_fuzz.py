@@ -1,7 +1,7 @@
 #!/opt/conda/bin/python3.9
 """Differential test of oracle/mc_oracle.c against the real scikit-image (conda env of the build container).
 
-Run:  /opt/conda/bin/python3.9 tools/mc_fuzz.py [n_volumes] [seed]
+Run:  /opt/conda/bin/python3.9 tests/tools/mc_fuzz.py [n_volumes] [seed]
 Random volumes of several kinds (white noise = every case / sub-case; small integers = ties of the face /
 interior tests and values equal to iso; smooth fields; flat plateaus) go through
 `skimage.measure.marching_cubes` and through the oracle; vertices and faces must agree exactly."""
@@ -14,7 +14,7 @@ import warnings
 import numpy as np
 
 warnings.filterwarnings('ignore')
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SO = os.path.join(ROOT, 'oracle', '_build', 'libmc_oracle.so')
 
 

@@ -5,7 +5,7 @@ same as rounding that layer's weights to fp16 (11 significant bits); dropping w_
 affine layer at a time in the fp64 oracle and reports what the occupancy (and the warping offset) move by, on the golden network and on the
 three other seeds / gains tests/test_gpu_query.py uses.  A layer could run on two passes if its worst case stayed under a 5e-5 budget.
 
-    python tools/pass_budget.py            (CPU, ~2 min)
+    python tests/tools/pass_budget.py            (CPU, ~2 min)
 """
 import sys
 import numpy as np
