@@ -19,8 +19,9 @@
 //   scan           : exclusive scan of the tile sums (one workgroup), totals to the host
 //   pass B  verts  : per non-empty tile: resolve the cells again, in-tile scan, number the new vertices, record
 //                    their ids in the edge map (3 ints per grid point, sparsely written), write one 16-byte
-//                    record per crossed cell {cell, table row, first face, centre-vertex id}; then the whole
-//                    workgroup evaluates positions + normals, one vertex per thread
+//                    record per crossed cell {cell, table row, first face, centre-vertex id} and, into each new
+//                    vertex's output slot, which (cell, edge) it is
+//   pass B' eval   : one thread per vertex: position (the library's fp64 formula) + normal (64-tap stencil)
 //   pass C  faces  : one thread per crossed cell: ids from the edge map -> triangles
 // HBM-bound: the volume is read twice (passes A, B; B skips empty tiles) + 24 B/vertex + 12 B/face written.
 // The 18 KB of look-up tables live in LDS.  Face / interior tests and the interpolation run in fp64 exactly as
@@ -374,28 +375,38 @@ __device__ __forceinline__ void vertex_normal(const McArgs &a, const EmitArgs &e
         pix = fminf(fmaxf(pix, 0.0f), (float)(dim[c] - 1));
         axis_weights(pix, dim[c], ib[c], wS[c], wD[c]);
     }
+    // conv3d's zero padding: a tap outside the volume contributes nothing -- its weight is zeroed and its address clamped, so that all 64 loads are
+    // unconditional and in flight together (one memory latency per vertex instead of one per (i, j) row of the stencil)
+    int off[3][4];
+    const int stride[3] = {a.n1 * a.n2, a.n2, 1};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int idx = ib[c] + m;
+            const bool in = idx >= 0 && idx < dim[c];
+            if (!in) { wS[c][m] = 0.f; wD[c][m] = 0.f; }
+            off[c][m] = (in ? idx : 0) * stride[c];
+        }
+    float val[4][4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) val[i][j][k] = a.vol[(int64_t)off[0][i] + off[1][j] + off[2][k]];
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    const int yz = a.n1 * a.n2;
-    for (int i = 0; i < 4; ++i) {
-        const int xi = ib[0] + i;
-        if (xi < 0 || xi >= a.n0) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int yj = ib[1] + j;
-            if (yj < 0 || yj >= a.n1) continue;
             float sS = 0.f, sD = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int zk = ib[2] + k;
-                if (zk < 0 || zk >= a.n2) continue;
-                const float val = a.vol[(int64_t)xi * yz + yj * a.n2 + zk];
-                sS += val * wS[2][k];
-                sD += val * wD[2][k];
-            }
+            for (int k = 0; k < 4; ++k) { sS += val[i][j][k] * wS[2][k]; sD += val[i][j][k] * wD[2][k]; }
             gx += wD[0][i] * wS[1][j] * sS;
             gy += wS[0][i] * wD[1][j] * sS;
             gz += wS[0][i] * wS[1][j] * sD;
         }
-    }
     gx /= 32.0f * e.vox[0]; gy /= 32.0f * e.vox[1]; gz /= 32.0f * e.vox[2];     // recon_util.py:18-20
     const float nn = sqrtf(gx * gx + gy * gy + gz * gz);                          // :45-47 (no epsilon)
     nrm[0] = -(gx / nn); nrm[1] = -(gy / nn); nrm[2] = -(gz / nn);                // :68
@@ -442,15 +453,13 @@ __device__ __forceinline__ void vertex_position(const McArgs &a, int z, int y, i
 
 struct CellRec { uint32_t li, row, face0; int32_t cvid; };     // one per crossed cell, in traversal order
 
-// Creators only describe their vertices (cell, edge), in output order; then the whole workgroup shares the
-// position / normal evaluation, one vertex per thread per round: the 64-tap normal stencil is by far the most
-// expensive part, and vertices cluster in few cells of a tile.  The descriptor of vertex id waits in the first word of
-// the vertex's own output slot (verts[3 * id], overwritten by the position): a worst-case LDS array (13 per cell,
-// 26 KiB) held the kernel at 3 workgroups per CU.
+// Pass B only NUMBERS: creators describe their vertices -- (cell << 4) | edge id, 64 bits, in output order -- in the first two words of the
+// vertex's own output slot (verts[3 * id]); positions and normals are evaluated by pass B' below, one vertex per thread.  (First cut: descriptors
+// in a worst-case LDS array and the evaluation at the end of this kernel, by the lanes of the tile's workgroup: the case logic's 170 registers
+// held the 64-tap normal stencil at three waves per SIMD, and half of the lanes had no vertex.)
 __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, const unsigned *__restrict__ tile_voff, const unsigned *__restrict__ tile_toff,
                                                        const unsigned *__restrict__ tile_coff, unsigned total_v, unsigned total_t,
-                                                       int32_t *__restrict__ edge_map, CellRec *__restrict__ cells,
-                                                       float *__restrict__ verts, float *__restrict__ normals)
+                                                       int32_t *__restrict__ edge_map, CellRec *__restrict__ cells, float *__restrict__ verts)
 {
     __shared__ uint32_t tab[mc::BLOB_WORDS];
     __shared__ unsigned red[4];
@@ -496,7 +505,8 @@ __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, con
                 seen |= 1u << ed;
                 if (!(creator & (1u << ed))) continue;
                 const int32_t id = (int32_t)(vbase + loc);
-                reinterpret_cast<uint32_t *>(verts)[3 * (size_t)id] = (uint32_t)(((threadIdx.x * 4 + k) << 4) | ed);     // (tile-local cell << 4) | edge id
+                const uint64_t d = ((uint64_t)li << 4) | (uint64_t)ed;
+                reinterpret_cast<uint32_t *>(verts)[3 * (size_t)id] = (uint32_t)d; reinterpret_cast<uint32_t *>(verts)[3 * (size_t)id + 1] = (uint32_t)(d >> 32);
                 ++loc;
                 if (ed == 12) { cvid = id; continue; }
                 int dx, dy, dz, axis;
@@ -508,23 +518,28 @@ __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, con
             cells[cloc] = r;
             floc += n / 3; ++cloc;
         }
-        __syncthreads();          // (workgroup-scope fence: the descriptors are visible)
-        for (unsigned j = threadIdx.x; j < total; j += 256) {
-            const unsigned d = reinterpret_cast<const uint32_t *>(verts)[3 * ((size_t)vbase + j)];
-            const int64_t li = (int64_t)tile * TILE + (d >> 4);
-            const int z = (int)(li / yx), rem = (int)(li - (int64_t)z * yx);
-            float vidx[3], out[3];
-            vertex_position(a, z, rem / a.n2, rem % a.n2, (int)(d & 15u), vidx);
+    }
+}
+
+// ---------------- pass B': positions + normals, one vertex per thread ----------------
+__global__ __launch_bounds__(256) void mc_eval_kernel(McArgs a, EmitArgs e, unsigned total_v, float *__restrict__ verts, float *__restrict__ normals)
+{
+    const int yx = a.n1 * a.n2;
+    for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total_v; id += (size_t)gridDim.x * 256) {
+        const uint32_t *dw = reinterpret_cast<const uint32_t *>(verts) + 3 * id;
+        const uint64_t d = (uint64_t)dw[0] | ((uint64_t)dw[1] << 32);
+        const int64_t li = (int64_t)(d >> 4);
+        const int z = (int)(li / yx), rem = (int)(li - (int64_t)z * yx);
+        float vidx[3], out[3];
+        vertex_position(a, z, rem / a.n2, rem % a.n2, (int)(d & 15u), vidx);
 #pragma unroll
-            for (int c = 0; c < 3; ++c)     // vertices = mc * voxel + b0 + 0.5 * voxel   (library: * spacing; recon_util.py:65), float32
-                out[c] = __fadd_rn(__fadd_rn(__fmul_rn(vidx[c], e.vox[c]), e.b0[c]), __fmul_rn(0.5f, e.vox[c]));
-            const size_t id = (size_t)vbase + j;
-            verts[3 * id + 0] = out[0]; verts[3 * id + 1] = out[1]; verts[3 * id + 2] = out[2];
-            if (normals) {
-                float n[3];
-                vertex_normal(a, e, vidx, n);
-                normals[3 * id + 0] = n[0]; normals[3 * id + 1] = n[1]; normals[3 * id + 2] = n[2];
-            }
+        for (int c = 0; c < 3; ++c)     // vertices = mc * voxel + b0 + 0.5 * voxel   (library: * spacing; recon_util.py:65), float32
+            out[c] = __fadd_rn(__fadd_rn(__fmul_rn(vidx[c], e.vox[c]), e.b0[c]), __fmul_rn(0.5f, e.vox[c]));
+        verts[3 * id + 0] = out[0]; verts[3 * id + 1] = out[1]; verts[3 * id + 2] = out[2];
+        if (normals) {
+            float n[3];
+            vertex_normal(a, e, vidx, n);
+            normals[3 * id + 0] = n[0]; normals[3 * id + 1] = n[1]; normals[3 * id + 2] = n[2];
         }
     }
 }
@@ -614,7 +629,9 @@ int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float
         e.vox[c] = e.len[c] / (float)res[c];
     }
     hipLaunchKernelGGL(mc_verts_kernel, dim3(grid), dim3(256), 0, s, a, e, tile_v, tile_t, tile_c, (unsigned)h_tot[0], (unsigned)h_tot[1],
-                       edge_map, cells, verts, normals);
+                       edge_map, cells, verts);
+    const int egrid = (int)std::min<unsigned long long>((h_tot[0] + 255ull) / 256ull, (unsigned long long)ctx->num_cus * 16ull);
+    hipLaunchKernelGGL(mc_eval_kernel, dim3(egrid), dim3(256), 0, s, a, e, (unsigned)h_tot[0], verts, normals);
     const unsigned ncells = (unsigned)h_tot[2];
     const int fgrid = (int)std::min<unsigned>((ncells + 255u) / 256u, (unsigned)ctx->num_cus * 8u);
     hipLaunchKernelGGL(mc_faces_kernel, dim3(fgrid), dim3(256), 0, s, a, cells, ncells, edge_map, faces);

@@ -1,0 +1,18 @@
+"""Scratch timing of recon_mesh_device (marching cubes + normals) on a smooth-noise 256^3 volume, with and without normals."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, '.')
+from avatarcap_amd import config, synthetic as syn
+config.cfg = config.default_cfg(); config.device = torch.device('cuda')
+from avatarcap_amd.utils import recon_util
+res = [int(a) for a in (sys.argv[1:4] or (256, 256, 256))]
+cells = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+rs = np.random.RandomState(0)
+noise = torch.from_numpy(rs.randn(cells, cells, cells).astype(np.float32)).cuda()
+vol = torch.nn.functional.interpolate(noise[None, None], size=res, mode='trilinear')[0, 0].contiguous().reshape(-1)
+for wn in (True, False):
+    v, f, n = recon_util.recon_mesh_device(vol, res, syn.CANO_BOUNDS, iso_value=0.0, with_normals=wn); torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(10): v, f, n = recon_util.recon_mesh_device(vol, res, syn.CANO_BOUNDS, iso_value=0.0, with_normals=wn)
+    torch.cuda.synchronize()
+    print(f'res {res} normals={wn}: {(time.time()-t)/10*1e3:.3f} ms  {v.shape[0]} vertices {f.shape[0]} faces', flush=True)
