@@ -34,6 +34,8 @@ struct PackedNet {
     std::vector<ChunkDesc> chunks;
     std::vector<float> bias;          // per-row bias, pre-scaled by 2^sw, padded to the tile grid
     std::vector<float> oscale;        // 2^-sw per layer
+    std::vector<float> colw;          // column-folded stream only: [conv1 | conv5][256][64] fp32 weights of the 64 pose-feature columns (fused_mlp.hip)
+    float *d_colw = nullptr;
     void *d_stream = nullptr;
     ChunkDesc *d_chunks = nullptr;
     float *d_bias = nullptr;
@@ -51,6 +53,7 @@ struct avc_ctx {
     int num_cus = 256;
     avc::PackedNet warp_tmpl;      // warp + template packed as ONE stream (avatar query), geometry only (shared.6 folded into geo.0)
     avc::PackedNet warp_tmpl_clr;  // the same with the colour head (shared.6 kept)
+    avc::PackedNet warp_tmpl_fold; // warp_tmpl for dense launches whose tiles lie in one (x, y) column: conv1 / conv5 without their 64 feature columns
     avc::PackedNet tmpl_only;      // template alone (pts_space == 'temp'), geometry only
     avc::PackedNet tmpl_only_clr;
     avc::PackedNet recon;
@@ -71,6 +74,7 @@ struct avc_ctx {
     void *gn_scratch = nullptr; size_t gn_scratch_bytes = 0;       // GroupNorm slice sums
     void *scatter_scratch = nullptr; size_t scatter_scratch_bytes = 0;   // block counts of avc_scatter_volume
     void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
+    void *col_scratch = nullptr; size_t col_scratch_bytes = 0;     // per-column terms of a column-folded dense query (512 floats per column)
     avc::Timing timing;
     int check_range = 0;                 // avc_set_range_check
     unsigned *range_flag_dev = nullptr;

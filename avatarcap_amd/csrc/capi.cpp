@@ -37,7 +37,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
 {
     if (!ctx) return AVC_OK;
     hipSetDevice(ctx->device);
-    release(ctx->warp_tmpl); release(ctx->warp_tmpl_clr); release(ctx->tmpl_only); release(ctx->tmpl_only_clr); release(ctx->recon);
+    release(ctx->warp_tmpl); release(ctx->warp_tmpl_clr); release(ctx->warp_tmpl_fold); release(ctx->tmpl_only); release(ctx->tmpl_only_clr); release(ctx->recon);
     if (ctx->pose_feat_hwc) hipFree(ctx->pose_feat_hwc);
     if (ctx->img_feat_hwc) hipFree(ctx->img_feat_hwc);
     if (ctx->mc_scratch) hipFree(ctx->mc_scratch);
@@ -47,6 +47,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->mc_tables_dev) hipFree(ctx->mc_tables_dev);
     if (ctx->raster_scratch) hipFree(ctx->raster_scratch);
     if (ctx->knn_scratch) hipFree(ctx->knn_scratch);
+    if (ctx->col_scratch) hipFree(ctx->col_scratch);
     if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
     release_fusion_graph(ctx);
     if (ctx->fusion_scratch) hipFree(ctx->fusion_scratch);

@@ -107,6 +107,7 @@ struct QueryParams {
     const float *gx, *gy, *gz;
     unsigned gry, grz;
     unsigned *range_flag;    // AVC_CHECK_RANGE builds: set to 1 when a value left the fp16 range
+    const float *colterms;   // column-folded dense launches: per (x, y) column 512 floats [conv1 | conv5] (column_terms_kernel), else null
 };
 
 __device__ __forceinline__ void load_point(const QueryParams &p, int64_t pidx, float pt[3])
@@ -529,8 +530,10 @@ struct Pending {
 template <int NT, int KS0, int KS1, int ACT, int NEXT_BYTES, class In0, class In1, class Bias, class Pre>
 __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
                                       Frag *__restrict__ out, Bias &bias, int h,
-                                      Pre &&pre, f32x16 *__restrict__ pend)
+                                      Pre &&pre, f32x16 *__restrict__ pend, const float *jump = nullptr)
 {
+    // `jump`: where the bias blocks continue after this layer's last pair, when not at the following block of the table (column-folded
+    // launches take conv1's and conv5's blocks from the per-column table and everything else from the layer table)
     constexpr int NPAIR = NT / 2;
     constexpr int B0 = chunk_bytes(KS0, 2), B1 = chunk_bytes(KS1, 2);
     constexpr int NS = KS0 < 16 ? KS0 : 16;
@@ -540,6 +543,7 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
         constexpr int p = decltype(pc)::value;
         f32x16 acc[2];
         bias.take(acc, 2, h);
+        if constexpr (p == NPAIR - 1) { if (jump) bias.rewind(jump); }
         constexpr int after0 = KS1 > 0 ? B1 : (p + 1 < NPAIR ? B0 : NEXT_BYTES);
         if constexpr (p == 0) {
             chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc, auto rc) {
@@ -739,21 +743,74 @@ constexpr int B_MAIN = chunk_bytes(16, 2);       // 64 KiB: two tiles x 16 k-ste
 constexpr int B_IN67 = chunk_bytes(layout::IN67_KS, 2);
 constexpr int B_PE = chunk_bytes(layout::PE_KS, 2);
 constexpr int B_HEAD16 = chunk_bytes(16, 1), B_HEAD8 = chunk_bytes(8, 1);
+constexpr int B_XYZ = chunk_bytes(1, 2);         // column-folded launches: conv1 / the input part of conv5 are the xyz k-step alone
 
-template <bool WARP, bool COLOUR>
+// ---- column folding of a DENSE launch -----------------------------------------------------------------------------------------------
+// The points of a dense grid run along the last axis, and the pose feature of WarpingField.query (arch_avatar.py:125-133) is sampled at
+// (x, y) only: the 128 points of a tile share it when the last axis holds a multiple of 128 points.  What conv1 and conv5 (the skip
+// connection, mlp.py:106) do with those 64 channels is then one vector per COLUMN and layer -- W[:, feat] f(x, y) + b, fp32, 65,536 columns
+// at 256^3 -- computed once by column_terms_kernel and handed to the two layers as their accumulator init in place of the bias.  Their
+// K shrinks from 5 k-steps to the xyz k-step: 192 of the 4,920 MFMAs of a tile, and the per-tile gather, split and parking of the 64
+// channels, are gone.  Same algebra as the reference, different rounding (fp32 dot products instead of three fp16 products): a folded
+// launch agrees with the point-by-point query to ~1e-6, not bit for bit (tests/test_gpu_query.py).
+constexpr int COLW = 2 * 256 * 64;               // floats of PackedNet::colw: [conv1 | conv5][out channel][feature channel]
+__global__ __launch_bounds__(256) void column_terms_kernel(const float *__restrict__ feat, int H, int W, const float *__restrict__ gx,
+                                                           const float *__restrict__ gy, int nx, int ny, float cx, float cy,
+                                                           const float *__restrict__ colw, const float *__restrict__ bias1,
+                                                           const float *__restrict__ bias5, float *__restrict__ out)
+{
+    constexpr int CPB = 4;                       // columns per trip
+    __shared__ __attribute__((aligned(16))) float f[CPB][64];
+    const int o = threadIdx.x;
+    float w1[64], w5[64];
+#pragma unroll
+    for (int c = 0; c < 64; c += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(colw + (size_t)o * 64 + c), b = *reinterpret_cast<const f32x4 *>(colw + 256 * 64 + (size_t)o * 64 + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { w1[c + i] = a[i]; w5[c + i] = b[i]; }
+    }
+    const float b1 = bias1[o], b5 = bias5[o];
+    const int ncol = nx * ny;
+    for (int c0 = blockIdx.x * CPB; c0 < ncol; c0 += gridDim.x * CPB) {
+        {   // the bilinear sample of arch_avatar.py:125-133, as the point-by-point kernel takes it: thread = (column, channel)
+            const int q = threadIdx.x >> 6, ch = threadIdx.x & 63, col = min(c0 + q, ncol - 1);
+            const Bilinear bl = bilinear_setup<64>(feat, H, W, gx[col / ny] - cx, -(gy[col % ny] - cy), 0);
+            f[q][ch] = bl.p00[ch] * bl.w00 + bl.p01[ch] * bl.w01 + bl.p10[ch] * bl.w10 + bl.p11[ch] * bl.w11;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CPB; ++q) {
+            if (c0 + q >= ncol) break;
+            float a1 = b1, a5 = b5;
+#pragma unroll
+            for (int c = 0; c < 64; c += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(&f[q][c]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a1 = __builtin_fmaf(w1[c + i], v[i], a1); a5 = __builtin_fmaf(w5[c + i], v[i], a5); }
+            }
+            out[(size_t)(c0 + q) * 512 + o] = a1;
+            out[(size_t)(c0 + q) * 512 + 256 + o] = a5;
+        }
+        __syncthreads();
+    }
+}
+
+template <bool WARP, bool COLOUR, bool FOLD = false>
 __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
 {
+    static_assert(!FOLD || (WARP && !COLOUR), "column folding: the geometry-only warped query of a dense grid");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    constexpr int B_FIRST = WARP ? B_IN67 : B_PE;       // first chunk of a pass (the prefetcher wraps to it)
+    constexpr int B_FIRST = WARP ? (FOLD ? B_XYZ : B_IN67) : B_PE;       // first chunk of a pass (the prefetcher wraps to it)
 
     Stream s = stream_init(p, wave, lane, B_FIRST);
 #if AVC_DBG_TIMING
     const long long tk0 = clock64();
 #endif
     BiasQueue bias;
-    bias.next = p.bias;
+    const unsigned tiles_per_col = FOLD ? p.grz / TILE_PTS : 1u;
+    bias.next = FOLD ? p.colterms + (size_t)(blockIdx.x / tiles_per_col) * 512 : p.bias;
     bias.fetch(h);                       // first block; afterwards every chunk fetches its successor's
 
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
@@ -777,25 +834,41 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         if constexpr (WARP) {
             // ---- WarpingField.query (arch_avatar.py:113-140) ----
             Frag S4;                         // k-step 4: raw xyz (pos_encoding 0); k-steps 0..3 are parked in LDS
-            {
+            if constexpr (!FOLD) {
                 const Bilinear bl = bilinear_setup<64>(p.feat, p.H, p.W, pt[0] - p.cx, -(pt[1] - p.cy), 32 * h);   // :125-133
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { Frag f; bilinear_frag(bl, 8 * k, f, s.range); park_store(park, k, f); __builtin_amdgcn_sched_barrier(0); }
+            }
+            {
                 float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (h == 0) { z[0] = pt[0]; z[1] = pt[1]; z[2] = pt[2]; }
                 split8(z, S4.hi, S4.lo, s.range);
             }
             const ParkIn S{park, &S4};
-            const RegIn RX{X}, RY{Y};
+            const RegIn RX{X}, RY{Y}, R4{&S4};
 #if AVC_DBG_TIMING
             s.t_pro += clock64() - tp0;
 #endif
             using SP = Pending<ACT_SOFTPLUS, 8>;
-            dense<8, layout::IN67_KS, 0, ACT_SOFTPLUS, B_MAIN>(s, S, S, X, bias, h, NoSide{}, pa);                       // conv1+bn1
+            // column-folded launch: conv1's and conv5's blocks come from this tile's column, everything else from the layer table
+            const float *after1 = nullptr, *col5 = nullptr, *after5 = nullptr;
+            if constexpr (FOLD) {
+                const float *col = p.colterms + (size_t)(tile / tiles_per_col) * 512;
+                after1 = bias_head + 256; col5 = col + 256; after5 = bias_head + 5 * 256;
+                const int64_t nt = tile + gridDim.x < p.ntiles ? tile + gridDim.x : p.ntiles - 1;
+                bias_head = p.colterms + (size_t)(nt / tiles_per_col) * 512;                                               // where the next tile starts
+                asm volatile("" : "+s"(after1), "+s"(col5), "+s"(after5), "+s"(bias_head));
+                dense<8, 1, 0, ACT_SOFTPLUS, B_MAIN>(s, R4, R4, X, bias, h, NoSide{}, pa, after1);                                // conv1+bn1 on xyz (+ column term)
+            } else {
+                dense<8, layout::IN67_KS, 0, ACT_SOFTPLUS, B_MAIN>(s, S, S, X, bias, h, NoSide{}, pa);                   // conv1+bn1
+            }
             dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                        // conv2
             dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RY, RY, X, bias, h, SP{pb, Y + 12, &s.range}, pa);                        // conv3
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                        // conv4
-            dense<8, 16, layout::IN67_KS, ACT_SOFTPLUS, B_MAIN>(s, RY, S, X, bias, h, SP{pb, Y + 12, &s.range}, pa);           // conv5 on [x0|x4]
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5);                  // conv4
+            if constexpr (FOLD)
+                dense<8, 16, 1, ACT_SOFTPLUS, B_MAIN>(s, RY, R4, X, bias, h, SP{pb, Y + 12, &s.range}, pa, after5);            // conv5 on [xyz | x4] (+ column term)
+            else
+                dense<8, 16, layout::IN67_KS, ACT_SOFTPLUS, B_MAIN>(s, RY, S, X, bias, h, SP{pb, Y + 12, &s.range}, pa);       // conv5 on [x0|x4]
             dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                        // conv6
             dense<8, 16, 0, ACT_SOFTPLUS, B_HEAD16>(s, RY, RY, X, bias, h, SP{pb, Y + 12, &s.range}, pa);                      // conv7
             const f32x16 o = head<16, B_PE, false>(s, X, bias, bias_head, h, SP{pa, X + 12, &s.range});                                  // out_layer_coord_affine
@@ -996,7 +1069,9 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
                   float *occ, float *offset, float *rgba, bool template_only, hipStream_t s)
 {
     const bool colour = rgba != nullptr;
-    PackedNet &net = template_only ? (colour ? ctx->tmpl_only_clr : ctx->tmpl_only) : (colour ? ctx->warp_tmpl_clr : ctx->warp_tmpl);
+    // a dense grid whose last axis holds a multiple of 128 points: every tile lies in one (x, y) column (see column_terms_kernel)
+    const bool fold = grid && !template_only && !colour && grid->res[2] % TILE_PTS == 0 && ctx->warp_tmpl_fold.ready && !getenv("AVC_NO_FOLD");
+    PackedNet &net = template_only ? (colour ? ctx->tmpl_only_clr : ctx->tmpl_only) : (colour ? ctx->warp_tmpl_clr : (fold ? ctx->warp_tmpl_fold : ctx->warp_tmpl));
     AVC_REQUIRE(!colour || net.ready || !(template_only ? ctx->tmpl_only : ctx->warp_tmpl).ready, AVC_ERR_STATE,
                 "avatar query: rgba requested but clr_mlp weights were not packed");
     AVC_REQUIRE(net.ready, AVC_ERR_STATE, "avatar query: weights not packed (call avc_pack_warp_weights and avc_pack_template_weights)");
@@ -1015,16 +1090,33 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
     const int grid_dim = (int)std::min<int64_t>(p.ntiles, gb && atoi(gb) > 0 ? atoi(gb) : ctx->num_cus);
     rc = range_begin(ctx, s);
     if (rc) return rc;
+    if (fold) {
+        const size_t ncol = (size_t)grid->res[0] * grid->res[1], bytes = (ncol * 512 + 64) * sizeof(float);
+        if (ctx->col_scratch_bytes < bytes) {
+            if (ctx->col_scratch) AVC_HIP(hipFree(ctx->col_scratch));
+            ctx->col_scratch = nullptr; ctx->col_scratch_bytes = 0;
+            AVC_HIP(hipMalloc(&ctx->col_scratch, bytes));
+            ctx->col_scratch_bytes = bytes;
+        }
+        p.colterms = static_cast<const float *>(ctx->col_scratch);
+    }
     hipEvent_t e0, e1;
-    timing_begin(ctx, 0, s, e0, e1);
-#define LAUNCH(W_, C_)                                                                              \
-    do {                                                                                            \
-        rc = set_lds(avatar_kernel<W_, C_>);                                                        \
-        if (rc) return rc;                                                                          \
-        hipLaunchKernelGGL((avatar_kernel<W_, C_>), dim3(grid_dim), dim3(256), LDS_BYTES, s, p);   \
+    timing_begin(ctx, 0, s, e0, e1);           // (a folded launch is timed with its column pass)
+#define LAUNCH(W_, C_, F_)                                                                              \
+    do {                                                                                                \
+        rc = set_lds(avatar_kernel<W_, C_, F_>);                                                        \
+        if (rc) return rc;                                                                              \
+        hipLaunchKernelGGL((avatar_kernel<W_, C_, F_>), dim3(grid_dim), dim3(256), LDS_BYTES, s, p);   \
     } while (0)
-    if (template_only) { if (colour) LAUNCH(false, true); else LAUNCH(false, false); }
-    else               { if (colour) LAUNCH(true, true);  else LAUNCH(true, false); }
+    if (template_only) { if (colour) LAUNCH(false, true, false); else LAUNCH(false, false, false); }
+    else if (colour) LAUNCH(true, true, false);
+    else if (fold) {
+        const int ncol = grid->res[0] * grid->res[1];
+        hipLaunchKernelGGL(column_terms_kernel, dim3(std::min((ncol + 3) / 4, ctx->num_cus * 4)), dim3(256), 0, s, p.feat, p.H, p.W, p.gx, p.gy,
+                           (int)grid->res[0], (int)grid->res[1], p.cx, p.cy, (const float *)net.d_colw, p.bias, p.bias + 4 * 256,
+                           static_cast<float *>(ctx->col_scratch));
+        LAUNCH(true, false, true);
+    } else LAUNCH(true, false, false);
 #undef LAUNCH
     AVC_HIP(hipGetLastError());
     timing_end(ctx, 0, s, e0, e1);

@@ -32,7 +32,7 @@ struct Seg { int ks; std::function<int(int)> col; };   // slot -> column of W (o
 struct Builder {
     PackedNet &net;
     bool overflow = false;
-    explicit Builder(PackedNet &n) : net(n) { net.stream.clear(); net.chunks.clear(); net.bias.clear(); net.oscale.clear(); }
+    explicit Builder(PackedNet &n) : net(n) { net.stream.clear(); net.chunks.clear(); net.bias.clear(); net.oscale.clear(); net.colw.clear(); }
 
     // W: (cout, cin) row-major effective weights, b: (cout).  tpc = tiles per chunk (accumulators
     // live at once in the kernel), kspc = k-steps per chunk.
@@ -89,6 +89,10 @@ Seg seg_in67(int col_offset = 0)
 {
     return Seg{layout::IN67_KS, [col_offset](int s) { int c = layout::in67_column(s); return c < 0 ? -1 : col_offset + c; }};
 }
+Seg seg_xyz()       // the xyz k-step of the 67-wide input alone (column-folded streams)
+{
+    return Seg{1, [](int s) { return layout::in67_column(4 * 16 + s); }};
+}
 Seg seg_pe(int col_offset = 0)
 {
     return Seg{layout::PE_KS, [col_offset](int s) { int c = layout::pe_column(s); return c < 0 ? -1 : col_offset + c; }};
@@ -129,7 +133,8 @@ void release(PackedNet &net)
     if (net.d_stream) hipFree(net.d_stream);
     if (net.d_chunks) hipFree(net.d_chunks);
     if (net.d_bias) hipFree(net.d_bias);
-    net.d_stream = nullptr; net.d_chunks = nullptr; net.d_bias = nullptr; net.ready = false;
+    if (net.d_colw) hipFree(net.d_colw);
+    net.d_stream = nullptr; net.d_chunks = nullptr; net.d_bias = nullptr; net.d_colw = nullptr; net.ready = false;
 }
 
 int upload(PackedNet &net)
@@ -142,6 +147,10 @@ int upload(PackedNet &net)
     AVC_HIP(hipMemcpy(net.d_stream, net.stream.data(), net.stream.size(), hipMemcpyHostToDevice));
     AVC_HIP(hipMemcpy(net.d_chunks, net.chunks.data(), net.chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
     AVC_HIP(hipMemcpy(net.d_bias, net.bias.data(), net.bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!net.colw.empty()) {
+        AVC_HIP(hipMalloc((void **)&net.d_colw, net.colw.size() * sizeof(float)));
+        AVC_HIP(hipMemcpy(net.d_colw, net.colw.data(), net.colw.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     net.ready = true;
     return AVC_OK;
 }
@@ -153,7 +162,7 @@ int upload(PackedNet &net)
 // bias are pre-multiplied by log2(e) (the accumulator becomes m) and every consumer of a Softplus output
 // absorbs the missing ln(2) into its weight columns.  For a Softplus layer fed by a Softplus layer the
 // two factors cancel (log2 e * ln 2 = 1): only the bias changes.
-static void add_warp(Builder &B, const avc_ctx::Staged &w)
+static void add_warp(Builder &B, const avc_ctx::Staged &w, bool fold = false)
 {
     const double LOG2E = 1.4426950408889634074, LN2 = 0.69314718055994530942;
     auto scaled = [](std::vector<double> v, double f, int cin = 0, int c0 = 0, int c1 = -1) {
@@ -161,10 +170,21 @@ static void add_warp(Builder &B, const avc_ctx::Staged &w)
         for (size_t i = 0; i < v.size(); ++i) { const int c = (int)(i % cin); if (c >= c0 && c < c1) v[i] *= f; }
         return v;
     };
-    B.layer(scaled(w.W[0], LOG2E), scaled(w.b[0], LOG2E), 256, 67, {seg_in67()}, 2, 16);                 // conv1 (raw inputs)
+    // fold: a dense launch whose tiles lie in one (x, y) column gets the 64 pose-feature columns of conv1 / conv5 as a per-column accumulator
+    // init (column_terms_kernel, fused_mlp.hip): the stream keeps the xyz k-step only, the fp32 weights of the 64 columns go to net.colw
+    const std::vector<double> W1 = scaled(w.W[0], LOG2E), W5 = scaled(w.W[4], LOG2E, 323, 0, 67);
+    if (fold) {
+        B.net.colw.assign((size_t)2 * 256 * 64, 0.0f);
+        for (int o = 0; o < 256; ++o)
+            for (int c = 0; c < 64; ++c) {
+                B.net.colw[(size_t)o * 64 + c] = (float)W1[(size_t)o * 67 + 3 + c];                       // columns [xyz(3) | feat(64)] (arch_avatar.py:136)
+                B.net.colw[(size_t)(256 + o) * 64 + c] = (float)W5[(size_t)o * 323 + 3 + c];              // conv5 sees cat([x0, x4]) (mlp.py:106)
+            }
+    }
+    B.layer(W1, scaled(w.b[0], LOG2E), 256, 67, {fold ? seg_xyz() : seg_in67()}, 2, 16);                   // conv1 (raw inputs)
     for (int i = 1; i <= 3; ++i) B.layer(w.W[i], scaled(w.b[i], LOG2E), 256, 256, {seg_d(16)}, 2, 16);      // conv2..4
-    B.layer(scaled(w.W[4], LOG2E, 323, 0, 67), scaled(w.b[4], LOG2E), 256, 323,
-            {seg_d(16, 67), seg_in67()}, 2, 16);                                 // conv5: cat([x0 (raw), x4 (softplus)]) (mlp.py:106)
+    B.layer(W5, scaled(w.b[4], LOG2E), 256, 323,
+            {seg_d(16, 67), fold ? seg_xyz() : seg_in67()}, 2, 16);              // conv5: cat([x0 (raw), x4 (softplus)]) (mlp.py:106)
     for (int i = 5; i <= 6; ++i) B.layer(w.W[i], scaled(w.b[i], LOG2E), 256, 256, {seg_d(16)}, 2, 16);      // conv6..7
     B.layer(scaled(w.W[7], LN2), w.b[7], 3, 256, {seg_d(16)}, 1, 16);             // out_layer_coord_affine (linear consumer)
 }
@@ -205,9 +225,9 @@ static void add_template(Builder &B, const avc_ctx::Staged &t, bool colour)
 int pack_avatar(avc_ctx *ctx)
 {
     const bool has_clr = ctx->tmpl_st.W.size() == 12;
-    auto build = [&](PackedNet &net, bool warp, bool colour) -> int {
+    auto build = [&](PackedNet &net, bool warp, bool colour, bool fold = false) -> int {
         Builder B(net);
-        if (warp) add_warp(B, ctx->warp_st);
+        if (warp) add_warp(B, ctx->warp_st, fold);
         add_template(B, ctx->tmpl_st, colour);
         AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
         net.has_colour = colour;
@@ -221,6 +241,7 @@ int pack_avatar(avc_ctx *ctx)
     if (ctx->warp_set && ctx->tmpl_set) {
         int rc = build(ctx->warp_tmpl, true, false);
         if (rc) return rc;
+        if ((rc = build(ctx->warp_tmpl_fold, true, false, true))) return rc;
         if (has_clr && (rc = build(ctx->warp_tmpl_clr, true, true))) return rc;
     }
     return AVC_OK;

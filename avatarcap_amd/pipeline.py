@@ -55,8 +55,10 @@ class FramePipeline:
         else:
             wf.precompute_conv(items)                                        # :359
         if getattr(self.ds, 'valid_mode', None) == 'dense' and items['cano_pts'].shape[1] == self.ds.valid_u8.numel():
-            # every grid point is queried: the kernel generates the points from the grid index (no 12 B/point read) and the
-            # offsets, which :360-364 never read, are not written -- bit-identical occupancy (tests/test_gpu_pipeline.py)
+            # every grid point is queried: the kernel generates the points from the grid index (no 12 B/point read), the offsets,
+            # which :360-364 never read, are not written, and -- when the last axis holds a multiple of 128 points -- the 64 pose-feature
+            # columns of conv1 / conv5 enter as one fp32 vector per (x, y) column (fused_mlp.hip: column folding; ~1e-6 from the
+            # point-by-point query, bit-identical to it otherwise: tests/test_gpu_query.py)
             out = self.occ_net.query_grid(items, self.ds.grid_axes, self.vol_res)
         else:
             out = self.occ_net.query(items)                                  # :360

@@ -44,13 +44,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_POINT = 1_773_568          # warp 428,288 + shared 425,472 + geo 33,024 MAC
-MFMA_ISSUED_PER_POINT = 4920 * 32 * 32 * 16 * 2 / 32   # 4920 v_mfma_f32_32x32x16_f16 per 32 points (3 split passes,
-                                                        # tile padding, shared.6 folded into geo.0: DESIGN.md section 2)
+MFMA_ISSUED_PER_POINT = 4728 * 32 * 32 * 16 * 2 / 32   # 4728 v_mfma_f32_32x32x16_f16 per 32 points (3 split passes, tile padding, shared.6 folded
+                                                        # into geo.0, the 64 feature columns of conv1 / conv5 folded per grid column: DESIGN.md section 2)
 PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 SUSTAINED_F16_TFLOPS = 1673.0      # what this part sustains on split-fp16 MFMAs fed from LDS once its clock manager has
                                     # settled (1.6 GHz, pipe 99 % busy): profiles/r01_ubench_mfma_clock.md -- information only
-HBM_TRAFFIC_BYTES_256 = 0.174e9     # per dense 256^3 launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc (profiles/r02_pmc_avatar.md):
-                                    # 67.1 MB of occupancy written (exact) + the feature map per XCD and what share of the weight stream left L2;
+HBM_TRAFFIC_BYTES_256 = 0.512e9     # per dense 256^3 launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc (profiles/r02_pmc_avatar.md):
+                                    # 67.1 MB of occupancy written (exact), the feature map per XCD, what share of the weight stream left L2, and the
+                                    # per-column table of the column-folded launch (131 MB written by the column pass, read back 2 KB per tile);
                                     # round 1's 1.98e9 also read 201 MB of points and wrote 201 MB of offsets nobody reads
 
 
@@ -298,7 +299,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_TFLOPS,
                          'traffic': HBM_TRAFFIC_BYTES_256 if res == 256 else None, 'traffic_source': 'profiles/r02_pmc_avatar.md (FETCH_SIZE x2 + WRITE_SIZE)',
-                         'kernel': 'avc::avatar_kernel<true,false>', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
+                         'kernel': 'avc::avatar_kernel<true,false,true> (+ its column_terms_kernel pass, timed together)', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
                          'algorithmic_flop_per_launch': N * FLOP_PER_POINT,
                          'mfma_issued_tflops': N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0,
                          'mfma_util': (N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 / PEAK_F16_TFLOPS) if avg_ms.value > 0 else 0.0,

@@ -45,7 +45,12 @@ def test_sampled_occupancy_matches_oracle_and_is_batch_independent(frame):
     perm = torch.from_numpy(rs.permutation(vol.numel())[:200_003]).cuda()
     sub = dict(items); sub['cano_pts'] = ds.infer_pts[perm][None].contiguous()
     again = pipe.occ_net.query(sub)['cano_pts_ov'][0, :, 0]
-    assert torch.equal(again, vol[perm])
+    # (the dense launch of the frame is column-folded -- fp32 column terms for the 64 feature columns of conv1 / conv5 -- and agrees with the
+    # point-by-point kernel to rounding; within one kernel the independence is bitwise)
+    assert float((again - vol[perm]).abs().max()) < 2e-5                               # (each is within ~1e-5 of the fp64 oracle)
+    back = torch.flip(perm[:70_001], [0])
+    sub['cano_pts'] = ds.infer_pts[back][None].contiguous()
+    assert torch.equal(pipe.occ_net.query(sub)['cano_pts_ov'][0, :, 0], torch.flip(again[:70_001], [0]))
 
 
 def test_mesh_topology_at_full_size(frame):

@@ -224,6 +224,33 @@ def test_grid_query_equals_point_query(net):
         OccupancyNet(net).query_grid(batch, volume_axes(syn.CANO_BOUNDS, (19, 23, 31), 'cuda'), res)
 
 
+@pytest.mark.parametrize('res', [(3, 5, 128), (2, 3, 256), (1, 1, 384)])
+def test_column_folded_grid_query(net, res, monkeypatch):
+    """A dense grid whose last axis holds a multiple of 128 points is evaluated column-folded: the 64 pose-feature columns of conv1 / conv5 enter
+    as one fp32 vector per (x, y) column instead of through the split-fp16 products (fused_mlp.hip, column_terms_kernel).  Same algebra, other
+    rounding: a few 1e-6 from the point-by-point query (each ~1e-5 from the fp64 oracle), bit-identical to it when the folding is switched off."""
+    from avatarcap_amd.network.arch_avatar import OccupancyNet
+    from avatarcap_amd.grid import generate_volume_points_np, volume_axes
+    from oracle import avatarcap_oracle as orc
+    config.if_type = 'sdf'
+    fmap = gi.pose_feat_map()
+    net.warping_field.pose_feat_map = _t(fmap[None])
+    pts_np = generate_volume_points_np(syn.CANO_BOUNDS, res)
+    batch = _batch(pts_np)
+    a = OccupancyNet(net).query(batch)
+    g = OccupancyNet(net).query_grid(batch, volume_axes(syn.CANO_BOUNDS, res, 'cuda'), res, want_offset=True)
+    d_occ, d_off = maxabs(g['cano_pts_ov'].cpu().numpy(), a['cano_pts_ov'].cpu().numpy()), maxabs(g['nonrigid_offset'].cpu().numpy(), a['nonrigid_offset'].cpu().numpy())
+    print(f'res {res}: folded vs point-by-point: occupancy {d_occ:.2e}, offsets {d_off:.2e}')
+    assert 0 < d_occ < 2e-5 and d_off < 2e-5                                   # (0 < : the folded path really ran; each path is ~1e-5 from fp64)
+    ref = orc.occupancy_query(pts_np, fmap, gi.center(), geotex_sd())
+    assert maxabs(g['cano_pts_ov'][0].cpu().numpy(), ref['cano_pts_ov']) < TOL and maxabs(g['nonrigid_offset'][0].cpu().numpy(), ref['nonrigid_offset']) < TOL
+    g2 = OccupancyNet(net).query_grid(batch, volume_axes(syn.CANO_BOUNDS, res, 'cuda'), res)
+    assert torch.equal(g2['cano_pts_ov'], g['cano_pts_ov'])                    # deterministic, with or without the offsets written
+    monkeypatch.setenv('AVC_NO_FOLD', '1')
+    u = OccupancyNet(net).query_grid(batch, volume_axes(syn.CANO_BOUNDS, res, 'cuda'), res, want_offset=True)
+    assert torch.equal(u['cano_pts_ov'], a['cano_pts_ov']) and torch.equal(u['nonrigid_offset'], a['nonrigid_offset'])
+
+
 def test_range_check_trips_on_fp16_overflow():
     """config.check_range -> avc_set_range_check: the same network with its warp MLP scaled until a post-activation value leaves
     the fp16 range must raise AVC_ERR_RANGE; the unscaled network must pass the check with bit-identical outputs."""

@@ -10,13 +10,16 @@ from avatarcap_amd.network.arch_avatar import GeoTexAvatar, OccupancyNet
 net = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume()).to('cuda').eval()
 net.load_state_dict({k: torch.from_numpy(v) for k, v in geotex_sd().items()})
 net.warping_field.pose_feat_map = torch.from_numpy(gi.pose_feat_map()[None]).cuda()
-from avatarcap_amd.grid import generate_volume_points
+from avatarcap_amd.grid import generate_volume_points, volume_axes
+GRID = 'grid' in sys.argv[1:]          # the dense launch of the frame loop: points generated from the grid index (column-folded at these sizes)
 for res in (128, 256):
     pts = generate_volume_points(syn.CANO_BOUNDS, (res, res, res), 'cuda')[None]
     batch = {'cano_pts': pts, 'cano_smpl_center': torch.from_numpy(gi.center()[None]).cuda()}
-    o = OccupancyNet(net).query(batch); torch.cuda.synchronize()
+    ax = volume_axes(syn.CANO_BOUNDS, (res, res, res), 'cuda')
+    run = (lambda: OccupancyNet(net).query_grid(batch, ax, (res, res, res))) if GRID else (lambda: OccupancyNet(net).query(batch))
+    o = run(); torch.cuda.synchronize()
     t0 = time.time(); reps = 3
-    for _ in range(reps): o = OccupancyNet(net).query(batch)
+    for _ in range(reps): o = run()
     torch.cuda.synchronize(); dt = (time.time() - t0) / reps
     n = res ** 3
     print(f'res {res}: {dt*1e3:.2f} ms  {n/dt/1e6:.1f} Mpts/s  {n*1773568/dt/1e12:.1f} TFLOP/s algorithmic  ({n*1773568*3/dt/1e12:.0f} issued)', flush=True)

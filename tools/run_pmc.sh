@@ -11,15 +11,16 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "FETCH_SIZE TCC_REQ" \
          "WRITE_SIZE TCC_HIT TCC_MISS" ; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv --kernel-include-regex avatar_kernel -d $OUT/p$i -o p$i -- python tools/pmc_probe.py $RES 1 > $OUT/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv --kernel-include-regex 'avatar_kernel|column_terms_kernel' -d $OUT/p$i -o p$i -- python tools/pmc_probe.py $RES 1 > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections
 agg = collections.OrderedDict()
 for f in sorted(glob.glob('$OUT/p*/*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        if 'avatar_kernel' not in r['Kernel_Name']: continue
-        k = r['Counter_Name']; agg.setdefault(k, []).append(float(r['Counter_Value']))
+        name = r['Kernel_Name']
+        if 'avatar_kernel' not in name and 'column_terms_kernel' not in name: continue
+        k = ('col:' if 'column_terms_kernel' in name else '') + r['Counter_Name']; agg.setdefault(k, []).append(float(r['Counter_Value']))
 with open('$OUT/summary.txt', 'w') as out:
     for k, v in agg.items():
         # counters are reported per dispatch (possibly per dimension instance); sum instances of the LAST dispatch group
