@@ -102,7 +102,10 @@ int avc_avatar_query(avc_ctx *ctx, const float *pts_dev, int64_t n, const float 
  * WITHOUT materialising the (N,3) point array (201 MB at 256^3): point i = x*Ry*Rz + y*Rz + z has the coordinates
  * (axis_x[x], axis_y[y], axis_z[z]), where axis_a[k] = linspace(0,1,R_a)[k] * (b1_a - b0_a) + b0_a in float32 -- the caller
  * builds the three tables with the reference's own arithmetic (avatarcap_amd/grid.py: volume_axes), so the points are
- * bit-identical to the reference's.  Outputs as above; offset_out_dev may be NULL (main.py:360-364 never reads it). */
+ * bit-identical to the reference's.  Outputs as above; offset_out_dev may be NULL (main.py:360-364 never reads it).
+ * When R_z is a multiple of 128 the launch is column-folded: the 64 pose-feature columns of the warping field's conv1 / conv5 enter as one fp32
+ * vector per (x, y) column instead of per point (same algebra, other rounding: a few 1e-6 from avc_avatar_query on the same points, which an
+ * unfolded launch -- any other R_z, or AVC_NO_FOLD=1 in the environment -- reproduces bit for bit).  Scratch: 2 KB per column in the context. */
 int avc_avatar_query_grid(avc_ctx *ctx, const float *axis_x_dev, const float *axis_y_dev, const float *axis_z_dev,
                           const int32_t res[3], const float center[3], int occupancy_sigmoid,
                           float *occ_out_dev, float *offset_out_dev, avc_stream stream);
