@@ -120,6 +120,7 @@ class AvatarCapDataset:
         ov = 2. * inside[~self.infer_pts_flag].to(torch.float32) - 1.                                        # [0, 1] -> [-1, 1]
         self.invalid_pts_ov = ov.to(self.device)
         self.valid_u8 = self.infer_pts_flag.to(torch.uint8).contiguous()
+        self.valid_idx = torch.nonzero(self.infer_pts_flag, as_tuple=False)[:, 0].to(torch.int32).contiguous()     # flat grid indices of infer_pts, same order
         self.valid_mode = 'band'
         # what FramePipeline reads from its dataset
         self.body = {'cano_smpl_v': self.cano_smpl.posed_vertices.astype(np.float32), 'skin_weights': self.smpl_params.weights}

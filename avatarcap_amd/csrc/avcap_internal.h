@@ -88,7 +88,7 @@ int upload(PackedNet &net);
 void release(PackedNet &net);
 // fused_mlp.hip
 // dense-grid point generator of the queries (pts == nullptr): three per-axis coordinate tables on the device
-struct GridDesc { const float *x, *y, *z; int32_t res[3]; };
+struct GridDesc { const float *x, *y, *z; int32_t res[3]; const int32_t *idx = nullptr; };   // idx: optional subset (flat indices, device) of the grid's points
 namespace plain {       // fused_mlp.hip
 int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], int occ_sigmoid,
                   float *occ, float *offset, float *rgba, bool template_only, hipStream_t s);

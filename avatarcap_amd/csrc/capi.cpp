@@ -175,6 +175,18 @@ int avc_avatar_query_grid(avc_ctx *ctx, const float *axis_x, const float *axis_y
     return run_avatar(ctx, nullptr, &g, (int64_t)res[0] * res[1] * res[2], center, occupancy_sigmoid, occ, offset, nullptr, false, (hipStream_t)stream);
 }
 
+int avc_avatar_query_grid_subset(avc_ctx *ctx, const float *axis_x, const float *axis_y, const float *axis_z, const int32_t res[3], const int32_t *index,
+                                 int64_t n, const float center[3], int occupancy_sigmoid, float *occ, float *offset, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && axis_x && axis_y && axis_z && res && center && n >= 0 && (n == 0 || (index && occ)), AVC_ERR_ARG,
+                "avc_avatar_query_grid_subset: NULL argument or negative n");
+    AVC_REQUIRE(res[0] >= 1 && res[1] >= 1 && res[2] >= 1, AVC_ERR_ARG, "avc_avatar_query_grid_subset: every resolution must be >= 1");
+    AVC_HIP(hipSetDevice(ctx->device));
+    GridDesc g{axis_x, axis_y, axis_z, {res[0], res[1], res[2]}};
+    g.idx = index;
+    return run_avatar(ctx, nullptr, &g, n, center, occupancy_sigmoid, occ, offset, nullptr, false, (hipStream_t)stream);
+}
+
 int avc_template_query(avc_ctx *ctx, const float *pts, int64_t n, int occupancy_sigmoid, float *occ, float *rgba, avc_stream stream)
 {
     AVC_REQUIRE(ctx && n >= 0 && (n == 0 || (pts && occ)), AVC_ERR_ARG, "avc_template_query: NULL argument or negative n");

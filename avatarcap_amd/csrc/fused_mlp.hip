@@ -106,19 +106,22 @@ struct QueryParams {
     // AvatarCapDataset.generate_volume_points (dataset/avatarcap_dataset.py:312-326); the three axis tables hold lin * (b1 - b0) + b0
     const float *gx, *gy, *gz;
     unsigned gry, grz;
+    const int32_t *gidx;     // dense-grid mode, optional: the launch covers the n grid points gidx[0..n) (the valid band) instead of all of them
     unsigned *range_flag;    // AVC_CHECK_RANGE builds: set to 1 when a value left the fp16 range
     const float *colterms;   // column-folded dense launches: per (x, y) column 512 floats [conv1 | conv5] (column_terms_kernel), else null
 };
 
-__device__ __forceinline__ void load_point(const QueryParams &p, int64_t pidx, float pt[3])
+__device__ __forceinline__ unsigned load_point(const QueryParams &p, int64_t pidx, float pt[3])
 {
+    // returns the point's (x, y) column of the grid (grid modes), 0 otherwise
     if (p.pts) {
         pt[0] = p.pts[pidx * 3 + 0]; pt[1] = p.pts[pidx * 3 + 1]; pt[2] = p.pts[pidx * 3 + 2];
-    } else {
-        const unsigned i = (unsigned)pidx, yz = p.gry * p.grz;
-        const unsigned ix = i / yz, r = i - ix * yz, iy = r / p.grz, iz = r - iy * p.grz;
-        pt[0] = p.gx[ix]; pt[1] = p.gy[iy]; pt[2] = p.gz[iz];
+        return 0u;
     }
+    const unsigned i = p.gidx ? (unsigned)p.gidx[pidx] : (unsigned)pidx, yz = p.gry * p.grz;
+    const unsigned ix = i / yz, r = i - ix * yz, iy = r / p.grz, iz = r - iy * p.grz;
+    pt[0] = p.gx[ix]; pt[1] = p.gy[iy]; pt[2] = p.gz[iz];
+    return ix * p.gry + iy;
 }
 
 // running max of the magnitudes that go through an fp16 split (AVC_CHECK_RANGE builds only)
@@ -394,7 +397,7 @@ struct BiasDirect {
         p += 32 * ntiles;
     }
     __device__ __forceinline__ void after_barrier(int) {}
-    __device__ __forceinline__ void rewind(const float *) {}
+    __device__ __forceinline__ void rewind(const float *, unsigned = 0) {}
 };
 struct BiasQueue {
     const float *next;       // block the registers were loaded from
@@ -407,7 +410,35 @@ struct BiasQueue {
         next += 32 * ntiles;
     }
     __device__ __forceinline__ void after_barrier(int h) { fetch(h); }
-    __device__ __forceinline__ void rewind(const float *head) { next = head; }
+    __device__ __forceinline__ void rewind(const float *head, unsigned = 0) { next = head; }
+};
+// The same queue when a block may come from a table indexed PER LANE (column-folded launches over a subset of the grid: the 32 points of a wave
+// lie in whatever columns the valid band gives them): `lane` is added to every address of the current block, 0 for the layer table.
+struct BiasQueueLane {
+    const float *next;
+    unsigned lane;           // byte offset of this lane's row of the per-column table (0: the layer table)
+    f32x16 nb[2];
+    __device__ __forceinline__ f32x16 tile(const float *rows, int h) const
+    {
+        f32x16 a;
+        const char *base = reinterpret_cast<const char *>(rows + 4 * h) + lane;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(
+                (const __attribute__((address_space(1))) char *)base + 32 * m);
+            a[4 * m + 0] = v[0]; a[4 * m + 1] = v[1]; a[4 * m + 2] = v[2]; a[4 * m + 3] = v[3];
+        }
+        return a;
+    }
+    __device__ __forceinline__ void fetch(int h) { nb[0] = tile(next, h); nb[1] = tile(next + 32, h); }
+    __device__ __forceinline__ void take(f32x16 *acc, int ntiles, int)
+    {
+        acc[0] = nb[0];
+        if (ntiles > 1) acc[1] = nb[1];
+        next += 32 * ntiles;
+    }
+    __device__ __forceinline__ void after_barrier(int h) { fetch(h); }
+    __device__ __forceinline__ void rewind(const float *head, unsigned lane_off = 0) { next = head; lane = lane_off; }
 };
 
 __device__ __forceinline__ float softplus_f(float m)
@@ -530,7 +561,7 @@ struct Pending {
 template <int NT, int KS0, int KS1, int ACT, int NEXT_BYTES, class In0, class In1, class Bias, class Pre>
 __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
                                       Frag *__restrict__ out, Bias &bias, int h,
-                                      Pre &&pre, f32x16 *__restrict__ pend, const float *jump = nullptr)
+                                      Pre &&pre, f32x16 *__restrict__ pend, const float *jump = nullptr, unsigned jump_lane = 0)
 {
     // `jump`: where the bias blocks continue after this layer's last pair, when not at the following block of the table (column-folded
     // launches take conv1's and conv5's blocks from the per-column table and everything else from the layer table)
@@ -543,7 +574,7 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
         constexpr int p = decltype(pc)::value;
         f32x16 acc[2];
         bias.take(acc, 2, h);
-        if constexpr (p == NPAIR - 1) { if (jump) bias.rewind(jump); }
+        if constexpr (p == NPAIR - 1) { if (jump) bias.rewind(jump, jump_lane); }
         constexpr int after0 = KS1 > 0 ? B1 : (p + 1 < NPAIR ? B0 : NEXT_BYTES);
         if constexpr (p == 0) {
             chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc, auto rc) {
@@ -576,12 +607,12 @@ __device__ __forceinline__ void flush(const f32x16 *__restrict__ pend, Frag *__r
 // one-tile linear head (rows 0..31 of which only the first few are real): the three products of a
 // k-step go to three accumulators, so no MFMA depends on its predecessor.  Same slot structure as chunk().
 template <int KS, int NEXT_BYTES, bool LAST, class Bias, class Pre>
-__device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, Bias &bias, const float *bias_head, int h, Pre &&pre)
+__device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, Bias &bias, const float *bias_head, int h, Pre &&pre, unsigned head_lane = 0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x16 a0, a1, a2;
     bias.take(&a0, 1, h);
-    if constexpr (LAST) bias.rewind(bias_head);      // the next block is the first one of the next point tile
+    if constexpr (LAST) bias.rewind(bias_head, head_lane);      // the next block is the first one of the next point tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a1[r] = 0.f; a2[r] = 0.f; }
     pf_drain();
@@ -795,7 +826,9 @@ __global__ __launch_bounds__(256) void column_terms_kernel(const float *__restri
     }
 }
 
-template <bool WARP, bool COLOUR, bool FOLD = false>
+// FOLD: 0 = point by point; 1 = column-folded dense grid (every tile in one column: wave-uniform column blocks); 2 = column-folded SUBSET of the
+// grid (p.gidx, the valid band: the 32 points of a wave lie in whatever columns they lie, their column blocks are gathered per lane)
+template <bool WARP, bool COLOUR, int FOLD = 0>
 __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
 {
     static_assert(!FOLD || (WARP && !COLOUR), "column folding: the geometry-only warped query of a dense grid");
@@ -808,9 +841,18 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
 #if AVC_DBG_TIMING
     const long long tk0 = clock64();
 #endif
-    BiasQueue bias;
-    const unsigned tiles_per_col = FOLD ? p.grz / TILE_PTS : 1u;
-    bias.next = FOLD ? p.colterms + (size_t)(blockIdx.x / tiles_per_col) * 512 : p.bias;
+    using BiasQ = std::conditional_t<FOLD == 2, BiasQueueLane, BiasQueue>;
+    BiasQ bias;
+    const unsigned tiles_per_col = FOLD == 1 ? p.grz / TILE_PTS : 1u;
+    float pt_next[3];                    // FOLD == 2: the next tile's point is loaded a tile ahead (its column decides where the bias queue continues)
+    unsigned col_next = 0;
+    if constexpr (FOLD == 2) {
+        const int64_t i0 = (int64_t)blockIdx.x * TILE_PTS + wave * 32 + j;
+        col_next = load_point(p, i0 < p.n ? i0 : p.n - 1, pt_next);
+        bias.rewind(p.colterms, col_next * 2048u);
+    } else {
+        bias.rewind(FOLD == 1 ? p.colterms + (size_t)(blockIdx.x / tiles_per_col) * 512 : p.bias);
+    }
     bias.fetch(h);                       // first block; afterwards every chunk fetches its successor's
 
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
@@ -820,7 +862,15 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         const long long tp0 = clock64();
 #endif
         float pt[3];
-        load_point(p, pidx, pt);
+        unsigned col = 0;
+        if constexpr (FOLD == 2) {
+            pt[0] = pt_next[0]; pt[1] = pt_next[1]; pt[2] = pt_next[2]; col = col_next;
+            const int64_t nt = tile + gridDim.x < p.ntiles ? tile + gridDim.x : tile;
+            const int64_t in = nt * TILE_PTS + wave * 32 + j;
+            col_next = load_point(p, in < p.n ? in : p.n - 1, pt_next);
+        } else {
+            load_point(p, pidx, pt);
+        }
 
         Frag X[16], Y[16];
         unsigned park = PARK_BASE + wave * PARK_PER_WAVE + lane * 16;
@@ -828,13 +878,14 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         f32x16 pa[2], pb[2];             // deferred accumulators of a layer's last tile pair (ping/pong)
         const float *bias_head = p.bias;
         asm volatile("" : "+s"(bias_head));   // opaque per tile: keeps bias addresses from being hoisted out of the loop
+        unsigned head_lane = 0;              // FOLD == 2: the next tile's per-lane row of the column table
         float q[3] = {pt[0], pt[1], pt[2]};
         float off[3] = {0.f, 0.f, 0.f};
 
         if constexpr (WARP) {
             // ---- WarpingField.query (arch_avatar.py:113-140) ----
             Frag S4;                         // k-step 4: raw xyz (pos_encoding 0); k-steps 0..3 are parked in LDS
-            if constexpr (!FOLD) {
+            if constexpr (FOLD == 0) {
                 const Bilinear bl = bilinear_setup<64>(p.feat, p.H, p.W, pt[0] - p.cx, -(pt[1] - p.cy), 32 * h);   // :125-133
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { Frag f; bilinear_frag(bl, 8 * k, f, s.range); park_store(park, k, f); __builtin_amdgcn_sched_barrier(0); }
@@ -850,13 +901,19 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             s.t_pro += clock64() - tp0;
 #endif
             using SP = Pending<ACT_SOFTPLUS, 8>;
-            // column-folded launch: conv1's and conv5's blocks come from this tile's column, everything else from the layer table
+            // column-folded launch: conv1's and conv5's blocks come from the column table, everything else from the layer table
             const float *after1 = nullptr, *col5 = nullptr, *after5 = nullptr;
-            if constexpr (FOLD) {
-                const float *col = p.colterms + (size_t)(tile / tiles_per_col) * 512;
-                after1 = bias_head + 256; col5 = col + 256; after5 = bias_head + 5 * 256;
-                const int64_t nt = tile + gridDim.x < p.ntiles ? tile + gridDim.x : p.ntiles - 1;
-                bias_head = p.colterms + (size_t)(nt / tiles_per_col) * 512;                                               // where the next tile starts
+            unsigned lane5 = 0;
+            if constexpr (FOLD != 0) {
+                after1 = bias_head + 256; after5 = bias_head + 5 * 256;
+                if constexpr (FOLD == 1) {
+                    col5 = p.colterms + (size_t)(tile / tiles_per_col) * 512 + 256;
+                    const int64_t nt = tile + gridDim.x < p.ntiles ? tile + gridDim.x : p.ntiles - 1;
+                    bias_head = p.colterms + (size_t)(nt / tiles_per_col) * 512;                                           // where the next tile starts
+                } else {
+                    col5 = p.colterms + 256; lane5 = col * 2048u;
+                    bias_head = p.colterms; head_lane = col_next * 2048u;
+                }
                 asm volatile("" : "+s"(after1), "+s"(col5), "+s"(after5), "+s"(bias_head));
                 dense<8, 1, 0, ACT_SOFTPLUS, B_MAIN>(s, R4, R4, X, bias, h, NoSide{}, pa, after1);                                // conv1+bn1 on xyz (+ column term)
             } else {
@@ -864,8 +921,8 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             }
             dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                        // conv2
             dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RY, RY, X, bias, h, SP{pb, Y + 12, &s.range}, pa);                        // conv3
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5);                  // conv4
-            if constexpr (FOLD)
+            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5, lane5);           // conv4
+            if constexpr (FOLD != 0)
                 dense<8, 16, 1, ACT_SOFTPLUS, B_MAIN>(s, RY, R4, X, bias, h, SP{pb, Y + 12, &s.range}, pa, after5);            // conv5 on [xyz | x4] (+ column term)
             else
                 dense<8, 16, layout::IN67_KS, ACT_SOFTPLUS, B_MAIN>(s, RY, S, X, bias, h, SP{pb, Y + 12, &s.range}, pa);       // conv5 on [x0|x4]
@@ -902,7 +959,7 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         } else {
             // geometry only: pack.cpp folded shared.6 (linear) into geo.0 -- one 256->128 layer instead of two
             dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TY, TY, X, bias, h, RP{pb, Y + 12, &s.range}, pa);                              // geo 0 o shared 6
-            g = head<8, B_FIRST, true>(s, X, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pa, X + 4, &s.range});                      // geo 1
+            g = head<8, B_FIRST, true>(s, X, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pa, X + 4, &s.range}, head_lane);           // geo 1
         }
 
         const bool writer = (h == 0) && (pidx_raw < p.n);
@@ -1034,8 +1091,10 @@ static int fill_points(QueryParams &p, avc_ctx *ctx, const float *pts, const Gri
     p.pts = pts; p.n = n;
     if (grid) {
         AVC_REQUIRE(grid->x && grid->y && grid->z && grid->res[0] > 0 && grid->res[1] > 0 && grid->res[2] > 0, AVC_ERR_ARG, "%s: bad grid descriptor", who);
-        AVC_REQUIRE((int64_t)grid->res[0] * grid->res[1] * grid->res[2] == n && n < ((int64_t)1 << 31), AVC_ERR_ARG,
+        const int64_t total = (int64_t)grid->res[0] * grid->res[1] * grid->res[2];
+        AVC_REQUIRE(total < ((int64_t)1 << 31) && (grid->idx ? n <= total : n == total), AVC_ERR_ARG,
                     "%s: grid of %d x %d x %d points does not match n = %lld (or exceeds 2^31)", who, grid->res[0], grid->res[1], grid->res[2], (long long)n);
+        p.gidx = grid->idx;
         p.pts = nullptr; p.gx = grid->x; p.gy = grid->y; p.gz = grid->z; p.gry = (unsigned)grid->res[1]; p.grz = (unsigned)grid->res[2];
     }
 #if AVC_CHECK_RANGE
@@ -1069,8 +1128,10 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
                   float *occ, float *offset, float *rgba, bool template_only, hipStream_t s)
 {
     const bool colour = rgba != nullptr;
-    // a dense grid whose last axis holds a multiple of 128 points: every tile lies in one (x, y) column (see column_terms_kernel)
-    const bool fold = grid && !template_only && !colour && grid->res[2] % TILE_PTS == 0 && ctx->warp_tmpl_fold.ready && !getenv("AVC_NO_FOLD");
+    // a dense grid whose last axis holds a multiple of 128 points: every tile lies in one (x, y) column (see column_terms_kernel); a SUBSET of a grid
+    // (grid->idx: the valid band) is folded whatever its shape, the column blocks then being gathered per lane
+    const bool can_fold = grid && !template_only && !colour && ctx->warp_tmpl_fold.ready && !getenv("AVC_NO_FOLD");
+    const int fold = !can_fold ? 0 : (grid->idx ? 2 : (grid->res[2] % TILE_PTS == 0 ? 1 : 0));
     PackedNet &net = template_only ? (colour ? ctx->tmpl_only_clr : ctx->tmpl_only) : (colour ? ctx->warp_tmpl_clr : (fold ? ctx->warp_tmpl_fold : ctx->warp_tmpl));
     AVC_REQUIRE(!colour || net.ready || !(template_only ? ctx->tmpl_only : ctx->warp_tmpl).ready, AVC_ERR_STATE,
                 "avatar query: rgba requested but clr_mlp weights were not packed");
@@ -1108,15 +1169,15 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
         if (rc) return rc;                                                                              \
         hipLaunchKernelGGL((avatar_kernel<W_, C_, F_>), dim3(grid_dim), dim3(256), LDS_BYTES, s, p);   \
     } while (0)
-    if (template_only) { if (colour) LAUNCH(false, true, false); else LAUNCH(false, false, false); }
-    else if (colour) LAUNCH(true, true, false);
+    if (template_only) { if (colour) LAUNCH(false, true, 0); else LAUNCH(false, false, 0); }
+    else if (colour) LAUNCH(true, true, 0);
     else if (fold) {
         const int ncol = grid->res[0] * grid->res[1];
         hipLaunchKernelGGL(column_terms_kernel, dim3(std::min((ncol + 3) / 4, ctx->num_cus * 4)), dim3(256), 0, s, p.feat, p.H, p.W, p.gx, p.gy,
                            (int)grid->res[0], (int)grid->res[1], p.cx, p.cy, (const float *)net.d_colw, p.bias, p.bias + 4 * 256,
                            static_cast<float *>(ctx->col_scratch));
-        LAUNCH(true, false, true);
-    } else LAUNCH(true, false, false);
+        if (fold == 2) LAUNCH(true, false, 2); else LAUNCH(true, false, 1);
+    } else LAUNCH(true, false, 0);
 #undef LAUNCH
     AVC_HIP(hipGetLastError());
     timing_end(ctx, 0, s, e0, e1);

@@ -58,6 +58,8 @@ class SyntheticTestDataset:
         else:
             raise ValueError("valid must be 'dense' or 'band'")
         self.valid_u8 = self.infer_pts_flag.to(torch.uint8).contiguous()
+        # flat grid indices of infer_pts, same order (the band is queried by index: avc_avatar_query_grid_subset); a dense frame needs none
+        self.valid_idx = None if valid == 'dense' else torch.nonzero(self.infer_pts_flag, as_tuple=False)[:, 0].to(torch.int32).contiguous()
 
     def __len__(self):
         return self.n_frames

@@ -290,13 +290,15 @@ class OccupancyNet:
         occ, off, _ = self.net._avatar_query(batch['cano_pts'], batch, want_offset=True, want_rgba=False)
         return {'cano_pts_ov': occ, 'nonrigid_offset': off}
 
-    def query_grid(self, batch, axes, res, want_offset=False):
-        """The same query on the whole dense grid without the (N,3) point tensor: `axes` = grid.volume_axes(bounds, res) (three device
-        tensors), point order as generate_volume_points.  Results are bit-identical to query() on the materialised points; the offsets
-        (which main.py:360-364 never reads) are only produced on request.  -> {'cano_pts_ov': (1,N,1)[, 'nonrigid_offset': (1,N,3)]}"""
+    def query_grid(self, batch, axes, res, want_offset=False, index=None):
+        """The same query on the dense grid without the (N,3) point tensor: `axes` = grid.volume_axes(bounds, res) (three device tensors), point order
+        as generate_volume_points; `index` (int32 device tensor of flat grid indices) restricts it to those points -- the valid band, in the order of
+        dataset.infer_pts.  The offsets (which main.py:360-364 never reads) are only produced on request.  Launches whose tiles share their (x, y)
+        column -- a last axis of a multiple of 128 points -- and all `index` launches are column-folded (fused_mlp.hip): a few 1e-6 from query() on the
+        materialised points; the others are bit-identical to it.  -> {'cano_pts_ov': (1,N,1)[, 'nonrigid_offset': (1,N,3)]}"""
         net = self.net
         res = [int(r) for r in res]
-        N = res[0] * res[1] * res[2]
+        N = res[0] * res[1] * res[2] if index is None else int(index.numel())
         dev = axes[0].device
         ctx = net._ctx(dev)
         if config.if_type not in ('sdf', 'occupancy'):
@@ -307,10 +309,16 @@ class OccupancyNet:
         for a, r in zip(axes, res):
             if a.numel() != r:
                 raise ValueError(f'query_grid: axis table of {a.numel()} entries for a resolution of {r}')
-        _lib.check(_lib.lib().avc_avatar_query_grid(
-            ctx, _lib.dev_ptr(axes[0], name='axis_x'), _lib.dev_ptr(axes[1], name='axis_y'), _lib.dev_ptr(axes[2], name='axis_z'),
-            (C.c_int32 * 3)(*res), _lib.f3(batch['cano_smpl_center'][0]), 1 if config.if_type == 'occupancy' else 0,
-            occ.data_ptr(), off.data_ptr() if want_offset else None, _lib.stream_ptr(dev)))
+        ax = (_lib.dev_ptr(axes[0], name='axis_x'), _lib.dev_ptr(axes[1], name='axis_y'), _lib.dev_ptr(axes[2], name='axis_z'))
+        sig = 1 if config.if_type == 'occupancy' else 0
+        if index is None:
+            _lib.check(_lib.lib().avc_avatar_query_grid(ctx, *ax, (C.c_int32 * 3)(*res), _lib.f3(batch['cano_smpl_center'][0]), sig,
+                                                        occ.data_ptr(), off.data_ptr() if want_offset else None, _lib.stream_ptr(dev)))
+        else:
+            if index.dtype != torch.int32 or not index.is_contiguous() or index.device != dev:
+                raise TypeError('query_grid: index must be a contiguous int32 tensor on the device of the axis tables')
+            _lib.check(_lib.lib().avc_avatar_query_grid_subset(ctx, *ax, (C.c_int32 * 3)(*res), index.data_ptr(), N, _lib.f3(batch['cano_smpl_center'][0]), sig,
+                                                               occ.data_ptr(), off.data_ptr() if want_offset else None, _lib.stream_ptr(dev)))
         out = {'cano_pts_ov': occ}
         if want_offset:
             out['nonrigid_offset'] = off

@@ -60,6 +60,10 @@ class FramePipeline:
             # columns of conv1 / conv5 enter as one fp32 vector per (x, y) column (fused_mlp.hip: column folding; ~1e-6 from the
             # point-by-point query, bit-identical to it otherwise: tests/test_gpu_query.py)
             out = self.occ_net.query_grid(items, self.ds.grid_axes, self.vol_res)
+        elif (getattr(self.ds, 'valid_idx', None) is not None and items['cano_pts'].shape[0] == 1 and items['cano_pts'].shape[1] == self.ds.valid_idx.numel()
+              and items['cano_pts'].data_ptr() == self.ds.infer_pts.data_ptr()):
+            # the dataset's valid band (items['cano_pts'] IS dataset.infer_pts): the same points by their grid indices -- no coordinates read, column-folded
+            out = self.occ_net.query_grid(items, self.ds.grid_axes, self.vol_res, index=self.ds.valid_idx)
         else:
             out = self.occ_net.query(items)                                  # :360
         if next_items is not None:
@@ -86,8 +90,13 @@ class FramePipeline:
         self.network.warping_field.precompute_conv(items)
         n = items['cano_pts'].shape[1]
         lo, hi = shard_range(n, rank, world)
-        sub = dict(items); sub['cano_pts'] = items['cano_pts'][:, lo:hi].contiguous()
-        local = self.occ_net.query(sub)['cano_pts_ov'][0, :, 0] if hi > lo else torch.empty(0, device=items['cano_pts'].device)
+        if hi <= lo:
+            local = torch.empty(0, device=items['cano_pts'].device)
+        elif getattr(self.ds, 'valid_idx', None) is not None and n == self.ds.valid_idx.numel() and items['cano_pts'].data_ptr() == self.ds.infer_pts.data_ptr():
+            local = self.occ_net.query_grid(items, self.ds.grid_axes, self.vol_res, index=self.ds.valid_idx[lo:hi].contiguous())['cano_pts_ov'][0, :, 0]   # as avatar_frame
+        else:
+            sub = dict(items); sub['cano_pts'] = items['cano_pts'][:, lo:hi].contiguous()
+            local = self.occ_net.query(sub)['cano_pts_ov'][0, :, 0]
         values = all_gather_slabs(local, n, group)
         vol = fill_volume(values, self.ds.valid_u8, self.ds.invalid_pts_ov)
         v, f, nrm = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds, iso_value=config.iso_value)

@@ -110,6 +110,14 @@ int avc_avatar_query_grid(avc_ctx *ctx, const float *axis_x_dev, const float *ax
                           const int32_t res[3], const float center[3], int occupancy_sigmoid,
                           float *occ_out_dev, float *offset_out_dev, avc_stream stream);
 
+/* The query on a SUBSET of that grid -- the valid band of the reference's test loop (avatarcap_dataset.py:114-116: infer_pts = vol_pts[infer_pts_flag],
+ * queried at main.py:360) -- given as `n` flat grid indices (index_dev[k] = x*Ry*Rz + y*Rz + z, int32, any order): output k belongs to grid point
+ * index_dev[k], coordinates as in avc_avatar_query_grid.  The launch is column-folded like a dense one (each point takes its column's vector), so it agrees
+ * with avc_avatar_query on the same points to a few 1e-6 (bit for bit with AVC_NO_FOLD=1), and the 12 bytes per point of coordinates are never read. */
+int avc_avatar_query_grid_subset(avc_ctx *ctx, const float *axis_x_dev, const float *axis_y_dev, const float *axis_z_dev,
+                                 const int32_t res[3], const int32_t *index_dev, int64_t n, const float center[3],
+                                 int occupancy_sigmoid, float *occ_out_dev, float *offset_out_dev, avc_stream stream);
+
 /* Numeric range.  The fused queries evaluate every float32 product as three fp16 x fp16 products with float32 accumulation
  * (DESIGN.md section 2): weights are split on the host -- a packed weight above 3e4 in magnitude is refused with AVC_ERR_ARG --
  * and every sampled feature, positional-encoding value and post-activation value is split on the fly, which requires
