@@ -1130,7 +1130,11 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
     const bool colour = rgba != nullptr;
     // a dense grid whose last axis holds a multiple of 128 points: every tile lies in one (x, y) column (see column_terms_kernel); a SUBSET of a grid
     // (grid->idx: the valid band) is folded whatever its shape, the column blocks then being gathered per lane
+#if AVC_CHECK_RANGE
+    const bool can_fold = false;               // the range-checked flavour (a debugging aid) keeps to the point-by-point kernels: half the build time
+#else
     const bool can_fold = grid && !template_only && !colour && ctx->warp_tmpl_fold.ready && !getenv("AVC_NO_FOLD");
+#endif
     const int fold = !can_fold ? 0 : (grid->idx ? 2 : (grid->res[2] % TILE_PTS == 0 ? 1 : 0));
     PackedNet &net = template_only ? (colour ? ctx->tmpl_only_clr : ctx->tmpl_only) : (colour ? ctx->warp_tmpl_clr : (fold ? ctx->warp_tmpl_fold : ctx->warp_tmpl));
     AVC_REQUIRE(!colour || net.ready || !(template_only ? ctx->tmpl_only : ctx->warp_tmpl).ready, AVC_ERR_STATE,
@@ -1176,7 +1180,9 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
         hipLaunchKernelGGL(column_terms_kernel, dim3(std::min((ncol + 3) / 4, ctx->num_cus * 4)), dim3(256), 0, s, p.feat, p.H, p.W, p.gx, p.gy,
                            (int)grid->res[0], (int)grid->res[1], p.cx, p.cy, (const float *)net.d_colw, p.bias, p.bias + 4 * 256,
                            static_cast<float *>(ctx->col_scratch));
+#if !AVC_CHECK_RANGE
         if (fold == 2) LAUNCH(true, false, 2); else LAUNCH(true, false, 1);
+#endif
     } else LAUNCH(true, false, 0);
 #undef LAUNCH
     AVC_HIP(hipGetLastError());
