@@ -20,7 +20,9 @@ The JSON line also carries:
   roofline     -- the dominant kernel (avatar_kernel): algorithmic FLOP/launch (1,773,568 per point,
                   SURVEY.md 8(d)) / mean launch time measured with HIP events on the launch stream,
                   against the dense fp16 MFMA peak (the kernel issues 3 fp16 MFMA passes per fp32
-                  product, so `mfma_util` = 2.84 x frac is the matrix-pipe utilisation; `traffic` is the
+                  product -- 4,728 MFMAs per 32 points once the 64 pose-feature columns of conv1 / conv5 are folded per
+                  grid column, DESIGN.md 2.5 -- so `mfma_util` = 2.73 x frac is the matrix-pipe utilisation; the launch
+                  time includes the column pass that feeds the folded kernel; `traffic` is the
                   HBM byte count of the committed rocprofv3 --pmc pass, profiles/r02_pmc_avatar.md;
                   `sustained_mfma_tflops_measured` is the rate a pure MFMA + LDS-read loop holds on this part
                   under its power-managed clock, profiles/r01_ubench_mfma_clock.md -- information, not `peak`).
