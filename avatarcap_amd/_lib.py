@@ -62,6 +62,8 @@ _SIGNATURES = {
     'avc_skinning': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_timing_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'avc_timing_read': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    'avc_timing_read_cycles': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    'avc_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
 }
 
 _lib = None
@@ -131,6 +133,11 @@ def apply_range_check(ctx_handle: int) -> None:
     """config.check_range -> avc_set_range_check (include/avcap.h 'numeric range')."""
     from . import config
     check(lib().avc_set_range_check(ctx_handle, 1 if getattr(config, 'check_range', False) else 0))
+
+
+def set_option(name: str, value: int, device=None) -> None:
+    """avc_set_option on the device's context (include/avcap.h 'switches of a context')."""
+    check(lib().avc_set_option(ctx(device), name.encode(), int(value)))
 
 
 def stream_ptr(device=None) -> int:

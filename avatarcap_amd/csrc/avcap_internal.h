@@ -44,7 +44,19 @@ struct PackedNet {
 };
 
 struct Timing { bool enabled = false; double total_ms[2] = {0, 0}; int64_t launches[2] = {0, 0};
-                std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[2]; };
+                std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[2];
+                // shader-clock stamps of timed launches: workgroup 0 writes (s_memtime at entry, at exit) into slot `launch % CLK_SLOTS`
+                static constexpr int CLK_SLOTS = 64;
+                long long *clk_dev[2] = {nullptr, nullptr}; int64_t clk_count[2] = {0, 0}; };
+
+// Switches of a context (avc_set_option).  Their defaults are read from the environment ONCE, by avc_ctx_create; no entry point reads the
+// environment afterwards.
+struct Options {
+    int column_fold = 1;      // dense / band launches of the avatar query take conv1 / conv5's pose-feature part per (x, y) column (AVC_NO_FOLD=1 -> 0)
+    int mlp_blocks = 0;       // persistent workgroups of the fused queries; 0 = one per CU (AVC_MLP_BLOCKS)
+    int knn_search = 0;       // 0 automatic, 1 per-lane grid search, 2 cooperative grid search, 3 exhaustive scan (AVC_KNN_PATH=lane|wave, AVC_KNN_BRUTE=1)
+    int fusion_graph = 1;     // normal-fusion iterations replayed as a hipGraph (AVC_FUSION_NO_GRAPH=1 -> 0)
+};
 
 }  // namespace avc
 
@@ -76,6 +88,7 @@ struct avc_ctx {
     void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
     void *col_scratch = nullptr; size_t col_scratch_bytes = 0;     // per-column terms of a column-folded dense query (512 floats per column)
     avc::Timing timing;
+    avc::Options opt;
     int check_range = 0;                 // avc_set_range_check
     unsigned *range_flag_dev = nullptr;
 };

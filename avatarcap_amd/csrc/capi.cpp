@@ -1,5 +1,7 @@
 // C ABI of libavcap_hip.so (include/avcap.h): argument checking, context state, dispatch.
 #include <cstring>
+#include <cstdlib>
+#include <algorithm>
 
 #include "avcap_internal.h"
 
@@ -29,6 +31,12 @@ int avc_ctx_create(int device, avc_ctx **ctx_out)
     avc_ctx *c = new avc_ctx();
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
+    // defaults of the context's switches: the environment is read here, once, and nowhere else (avc_set_option changes them afterwards)
+    if (getenv("AVC_NO_FOLD")) c->opt.column_fold = 0;
+    if (const char *e = getenv("AVC_MLP_BLOCKS")) c->opt.mlp_blocks = atoi(e) > 0 ? atoi(e) : 0;
+    if (getenv("AVC_KNN_BRUTE")) c->opt.knn_search = 3;
+    else if (const char *e = getenv("AVC_KNN_PATH")) c->opt.knn_search = !strcmp(e, "lane") ? 1 : (!strcmp(e, "wave") ? 2 : 0);
+    if (getenv("AVC_FUSION_NO_GRAPH")) c->opt.fusion_graph = 0;
     *ctx_out = c;
     return AVC_OK;
 }
@@ -51,8 +59,10 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
     release_fusion_graph(ctx);
     if (ctx->fusion_scratch) hipFree(ctx->fusion_scratch);
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < 2; ++w) {
         for (auto &pr : ctx->timing.pending[w]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+        if (ctx->timing.clk_dev[w]) hipFree(ctx->timing.clk_dev[w]);
+    }
     delete ctx;
     return AVC_OK;
 }
@@ -310,6 +320,17 @@ int avc_skinning(avc_ctx *ctx, const float *pts, const float *nrm, int64_t n, co
     return skinning(pts, nrm, n, lbs, jm, po, no, mo, (hipStream_t)stream);
 }
 
+int avc_set_option(avc_ctx *ctx, const char *name, int value)
+{
+    AVC_REQUIRE(ctx && name, AVC_ERR_ARG, "avc_set_option: NULL argument");
+    if (!strcmp(name, "column_fold")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: column_fold is 0 or 1"); ctx->opt.column_fold = value; }
+    else if (!strcmp(name, "mlp_blocks")) { AVC_REQUIRE(value >= 0, AVC_ERR_ARG, "avc_set_option: mlp_blocks >= 0 (0: one workgroup per CU)"); ctx->opt.mlp_blocks = value; }
+    else if (!strcmp(name, "knn_search")) { AVC_REQUIRE(value >= 0 && value <= 3, AVC_ERR_ARG, "avc_set_option: knn_search is 0 (auto), 1 (lane), 2 (wave) or 3 (exhaustive)"); ctx->opt.knn_search = value; }
+    else if (!strcmp(name, "fusion_graph")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: fusion_graph is 0 or 1"); ctx->opt.fusion_graph = value; }
+    else AVC_REQUIRE(false, AVC_ERR_ARG, "avc_set_option: unknown option '%s'", name);
+    return AVC_OK;
+}
+
 int avc_timing_enable(avc_ctx *ctx, int enable)
 {
     AVC_REQUIRE(ctx, AVC_ERR_ARG, "avc_timing_enable: NULL ctx");
@@ -332,6 +353,25 @@ int avc_timing_read(avc_ctx *ctx, int which, double *avg_ms, int64_t *launches, 
     *launches = t.launches[which];
     *avg_ms = t.launches[which] ? t.total_ms[which] / t.launches[which] : 0.0;
     if (reset) { t.total_ms[which] = 0; t.launches[which] = 0; }
+    return AVC_OK;
+}
+
+int avc_timing_read_cycles(avc_ctx *ctx, int which, double *avg_cycles, int64_t *launches)
+{
+    AVC_REQUIRE(ctx && (which == 0 || which == 1) && avg_cycles && launches, AVC_ERR_ARG, "avc_timing_read_cycles: bad argument");
+    auto &t = ctx->timing;
+    *avg_cycles = 0.0; *launches = 0;
+    const int64_t n = std::min<int64_t>(t.clk_count[which], Timing::CLK_SLOTS);
+    if (n > 0 && t.clk_dev[which]) {
+        AVC_HIP(hipSetDevice(ctx->device));
+        AVC_HIP(hipDeviceSynchronize());
+        std::vector<long long> h(2 * n);
+        AVC_HIP(hipMemcpy(h.data(), t.clk_dev[which], sizeof(long long) * 2 * n, hipMemcpyDeviceToHost));
+        double sum = 0;
+        for (int64_t i = 0; i < n; ++i) sum += (double)(h[2 * i + 1] - h[2 * i]);
+        *avg_cycles = sum / n; *launches = n;
+    }
+    t.clk_count[which] = 0;
     return AVC_OK;
 }
 

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <stdint.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "avcap_internal.h"
@@ -109,6 +110,7 @@ struct QueryParams {
     const int32_t *gidx;     // dense-grid mode, optional: the launch covers the n grid points gidx[0..n) (the valid band) instead of all of them
     unsigned *range_flag;    // AVC_CHECK_RANGE builds: set to 1 when a value left the fp16 range
     const float *colterms;   // column-folded dense launches: per (x, y) column 512 floats [conv1 | conv5] (column_terms_kernel), else null
+    long long *clk;          // timed launches (avc_timing_enable): workgroup 0 stores its s_memtime at entry and exit here, else null
 };
 
 __device__ __forceinline__ unsigned load_point(const QueryParams &p, int64_t pidx, float pt[3])
@@ -180,6 +182,17 @@ struct ParkIn {
         }
     }
 };
+// Two providers back to back: k-steps 0 .. N0-1 are provider A's k-steps OFF .. OFF+N0-1, the following ones provider B's from 0 (the second chunk of
+// a layer with a concatenated input: the tail of the hidden activations, then the raw network input -- see dense()).
+template <int OFF, int N0, class A, class B>
+struct CatIn {
+    const A &a; const B &b;
+    template <int K> __device__ __forceinline__ Frag get() const
+    {
+        if constexpr (K < N0) return a.template get<OFF + K>();
+        else return b.template get<K - N0>();
+    }
+};
 __device__ __forceinline__ void park_store(unsigned base, int k, const Frag &f)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,8 +216,23 @@ struct Stream {
     long long t_bar = 0;     // cycles spent waiting at chunk barriers
     long long t_drain = 0;   // ... of which waiting for this wave's own LDS-DMA pieces (s_waitcnt vmcnt(0))
     long long t_pro = 0;     // cycles of the per-tile prologues (point load, gathers, positional encoding) and output stores
+    long long *stamp = nullptr;   // AVC_DBG_TIMING == 2, last tile of the workgroup only: (entry, drained, released) s_memtime of every chunk / head
+    unsigned nstamp = 0;
 #endif
 };
+
+#if AVC_DBG_TIMING
+// three timestamps per chunk step of the workgroup's LAST tile, lane 0 of every wave (tools/timing_probe.py turns them into profiles/r03_avatar_time_split.md)
+__device__ __forceinline__ void stamp3(Stream &s, long long t0, long long t1, long long t2)
+{
+#if AVC_DBG_TIMING >= 2
+    if (s.stamp) {
+        if (s.lane_off == 0) { s.stamp[3 * s.nstamp] = t0; s.stamp[3 * s.nstamp + 1] = t1; s.stamp[3 * s.nstamp + 2] = t2; }
+        ++s.nstamp;
+    }
+#endif
+}
+#endif
 
 // The next chunk travels L2 -> LDS by LDS-DMA in its BUFFER form, `buffer_load_dwordx4 v_off32, s[rsrc], s_off offen lds`: the data never
 // touches a VGPR, there is no ds_write, and the only per-lane operand is one 32-bit offset register (lane * 16) that never changes.
@@ -283,13 +311,16 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
 #endif
     pf_drain();
 #if AVC_DBG_TIMING
-    s.t_drain += clock64() - tb0;
+    const long long tb1 = clock64();
+    s.t_drain += tb1 - tb0;
 #endif
 #if !AVC_DBG_NO_BARRIER
     __syncthreads();
 #endif
 #if AVC_DBG_TIMING
-    s.t_bar += clock64() - tb0;
+    const long long tb2 = clock64();
+    s.t_bar += tb2 - tb0;
+    stamp3(s, tb0, tb1, tb2);
 #endif
     // Values every address of this chunk derives from are made opaque HERE, after the barrier: with
     // everything unrolled and compile-time, the compiler otherwise hoists the address arithmetic of all
@@ -308,6 +339,7 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
     // live (32 registers; holding a whole 8-tile k-step and its successor was 128, and the recon kernel spilled 350 registers for it).
     constexpr int T2 = TPC >= 2 ? 2 : 1, G = TPC / T2, Q = KS * G;
     static_assert(TPC == 1 || TPC % 2 == 0, "tiles per chunk: 1 or even");
+    constexpr bool SIDE = TPC == 2 || (T2 == 2 && !std::is_same<typename std::decay<Side>::type, NoSide>::value);   // side(step, region) hooks behind every MFMA
     half8 ah[2][T2], al[2][T2];
     Frag b[2];
     b[0] = in.template get<0>();
@@ -340,7 +372,7 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
         static_for<T2>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].hi), a2[t], 0, 0, 0);
-            if constexpr (TPC == 2) { side(qc, RegionC<t>{}); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (SIDE) { side(qc, RegionC<t>{}); __builtin_amdgcn_sched_barrier(0); }
         });
         __builtin_amdgcn_sched_barrier(0);
         // ---- slot 1
@@ -348,7 +380,7 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
         static_for<T2>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].lo), a2[t], 0, 0, 0);
-            if constexpr (TPC == 2) { side(qc, RegionC<2 + t>{}); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (SIDE) { side(qc, RegionC<2 + t>{}); __builtin_amdgcn_sched_barrier(0); }
         });
         __builtin_amdgcn_sched_barrier(0);
         // ---- slot 2
@@ -356,7 +388,7 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
         static_for<T2>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], as_half8(b[cur].hi), a2[t], 0, 0, 0);
-            if constexpr (TPC == 2) { side(qc, RegionC<4 + t>{}); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (SIDE) { side(qc, RegionC<4 + t>{}); __builtin_amdgcn_sched_barrier(0); }
         });
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -399,10 +431,39 @@ struct BiasDirect {
     __device__ __forceinline__ void after_barrier(int) {}
     __device__ __forceinline__ void rewind(const float *, unsigned = 0) {}
 };
+// The queue's loads are BUFFER loads: resource built from the (wave-uniform) block pointer, one per-lane byte offset register that never changes
+// (16 h, plus the lane's column row in BiasQueueLane) and immediates.  The flat form `global_load_dwordx4 v, v_off, s[base:base+1]` of round 2 had its
+// address registers parked in AGPRs by the allocator and read back in front of every load: two v_accvgpr_read per load, ~900 per point tile.
+// (declared as the LLVM intrinsic itself: hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128 selects a ONE-dword load for the 128-bit result)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ f32x4 raw_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ __forceinline__ f32x16 bias_tile_buf(i32x4 rs, unsigned voff, int byte0)
+{
+    f32x16 a;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const f32x4 v = raw_buffer_load_f32x4(rs, (int)voff + byte0 + 32 * m, 0, 0);
+        a[4 * m + 0] = v[0]; a[4 * m + 1] = v[1]; a[4 * m + 2] = v[2]; a[4 * m + 3] = v[3];
+    }
+    return a;
+}
+__device__ __forceinline__ i32x4 bias_rsrc(const float *block)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(block);
+    i32x4 rs;
+    rs[0] = (int)(unsigned)a; rs[1] = (int)((unsigned)(a >> 32) & 0xffffu);     // base, stride 0
+    rs[2] = -16; rs[3] = 0x00027000;                                              // raw buffer, offsets up to 4 GiB
+    return rs;
+}
 struct BiasQueue {
     const float *next;       // block the registers were loaded from
+    unsigned hoff;           // 16 h: rows d_row(r, h) = (r & 3) + 8 (r >> 2) + 4 h of a tile are four 16-byte pieces, 32 bytes apart, from byte 16 h
     f32x16 nb[2];
-    __device__ __forceinline__ void fetch(int h) { nb[0] = bias_tile(next, h); nb[1] = bias_tile(next + 32, h); }
+    __device__ __forceinline__ void fetch(int)
+    {
+        const i32x4 rs = bias_rsrc(next);
+        nb[0] = bias_tile_buf(rs, hoff, 0); nb[1] = bias_tile_buf(rs, hoff, 128);
+    }
     __device__ __forceinline__ void take(f32x16 *acc, int ntiles, int)
     {
         acc[0] = nb[0];
@@ -411,26 +472,23 @@ struct BiasQueue {
     }
     __device__ __forceinline__ void after_barrier(int h) { fetch(h); }
     __device__ __forceinline__ void rewind(const float *head, unsigned = 0) { next = head; }
+    // tile `t` of the current block's layer, loaded directly (wide layers: tiles 2..7 are requested early, tiles 0 / 1 come through the queue)
+    __device__ __forceinline__ f32x16 tile_at(int t) const { return bias_tile_buf(bias_rsrc(next), hoff, 128 * t); }
+    __device__ __forceinline__ void skip(int nfloats) { next += nfloats; }
 };
 // The same queue when a block may come from a table indexed PER LANE (column-folded launches over a subset of the grid: the 32 points of a wave
 // lie in whatever columns the valid band gives them): `lane` is added to every address of the current block, 0 for the layer table.
 struct BiasQueueLane {
     const float *next;
+    unsigned hoff;
     unsigned lane;           // byte offset of this lane's row of the per-column table (0: the layer table)
     f32x16 nb[2];
-    __device__ __forceinline__ f32x16 tile(const float *rows, int h) const
+    __device__ __forceinline__ void fetch(int)
     {
-        f32x16 a;
-        const char *base = reinterpret_cast<const char *>(rows + 4 * h) + lane;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(
-                (const __attribute__((address_space(1))) char *)base + 32 * m);
-            a[4 * m + 0] = v[0]; a[4 * m + 1] = v[1]; a[4 * m + 2] = v[2]; a[4 * m + 3] = v[3];
-        }
-        return a;
+        const i32x4 rs = bias_rsrc(next);
+        const unsigned v = hoff + lane;
+        nb[0] = bias_tile_buf(rs, v, 0); nb[1] = bias_tile_buf(rs, v, 128);
     }
-    __device__ __forceinline__ void fetch(int h) { nb[0] = tile(next, h); nb[1] = tile(next + 32, h); }
     __device__ __forceinline__ void take(f32x16 *acc, int ntiles, int)
     {
         acc[0] = nb[0];
@@ -439,7 +497,18 @@ struct BiasQueueLane {
     }
     __device__ __forceinline__ void after_barrier(int h) { fetch(h); }
     __device__ __forceinline__ void rewind(const float *head, unsigned lane_off = 0) { next = head; lane = lane_off; }
+    __device__ __forceinline__ f32x16 tile_at(int t) const { return bias_tile_buf(bias_rsrc(next), hoff + lane, 128 * t); }
+    __device__ __forceinline__ void skip(int nfloats) { next += nfloats; }
 };
+
+// max(x, 0) as a signed-integer max on the bit pattern (negative floats are negative integers; -0 and negative NaNs -> +0): one v_max_i32 with an
+// inline constant.  fmaxf() would put a canonicalising v_max_f32 in front, and an inline-asm v_max_f32 (round 2) is opaque to the hazard recogniser,
+// which then pads every use of a transcendental result behind it with an s_nop.
+__device__ __forceinline__ float relu_bits(float x)
+{
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
 
 __device__ __forceinline__ float softplus_f(float m)
 {
@@ -451,15 +520,13 @@ __device__ __forceinline__ float softplus_f(float m)
     // returns x, the reference's threshold branch; nothing overflows), absolute error ~1e-7.
     // The max is a bare v_max_f32: fmaxf() would add a canonicalising v_max in front of it, and at one
     // wave per SIMD every VALU instruction costs ~2.5 cycles of MFMA issue (tools/ubench/mfma_fill.hip).
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(m));
-    return r + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-__builtin_fabsf(m)));
+    return relu_bits(m) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-__builtin_fabsf(m)));
 }
 
 template <int ACT>
 __device__ __forceinline__ float act_f(float x)
 {
-    if constexpr (ACT == ACT_RELU) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; }   // bare max, no canonicalise
+    if constexpr (ACT == ACT_RELU) return relu_bits(x);
     else if constexpr (ACT == ACT_LEAKY) return x > 0.0f ? x : 0.02f * x;     // network/mlp.py:11
     else if constexpr (ACT == ACT_SOFTPLUS) return softplus_f(x);
     else return x;
@@ -519,10 +586,7 @@ __device__ __forceinline__ void epi_part(const f32x16 *__restrict__ acc, Frag *_
                 else if constexpr (R == 1) { e0 = e0 + 1.0f; e1 = e1 + 1.0f; }
                 else if constexpr (R == 2) { e0 = __builtin_amdgcn_logf(e0); e1 = __builtin_amdgcn_logf(e1); }
                 else if constexpr (R == 3) {
-                    float r0, r1;
-                    asm("v_max_f32 %0, 0, %1" : "=v"(r0) : "v"(x0));          // bare max (fmaxf would canonicalise first)
-                    asm("v_max_f32 %0, 0, %1" : "=v"(r1) : "v"(x1));
-                    x0 = r0 + e0; x1 = r1 + e1;
+                    x0 = relu_bits(x0) + e0; x1 = relu_bits(x1) + e1;
                 }
                 else if constexpr (R == 4) cvt();
                 else { unsigned l; asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
@@ -555,9 +619,15 @@ struct Pending {
 // ------------------------------------------------------------------------------------------
 // NT output tiles (even), evaluated two at a time; up to two input segments accumulate into the
 // same tiles (the reference's torch.cat on the channel axis).  The epilogue of pair p runs inside
-// the first chunk of pair p+1; the last pair's accumulators are handed back in `pend` and the caller
+// the chunk(s) of pair p+1; the last pair's accumulators are handed back in `pend` and the caller
 // schedules their epilogue (Pending) into whatever chunk comes next.  `pre` is such deferred work
 // from the previous layer.  NEXT_BYTES = size of the chunk that follows this layer in the stream.
+// A layer with a second segment (KS1 k-steps of raw network input behind KS0 k-steps of hidden activations: conv5, shared.4, recon fc2) walks a
+// pair's KS0 + KS1 k-steps as TWO chunks of about equal size -- the units of a pair are one k-major run in the stream, so where it is cut is the
+// kernel's choice.  Round 2 cut it at the segment boundary: a 64 KiB chunk followed by one of 1 .. 5 k-steps, whose 6 .. 30 MFMAs had to cover the
+// LDS-DMA of the NEXT 64 KiB chunk: 1.4 k cycles for 6 MFMAs (profiles/r03_avatar_time_split.md).
+constexpr int split_first_ks(int ks0, int ks1) { return ks1 > 0 ? (ks0 + ks1 + 1) / 2 : ks0; }
+constexpr int first_chunk_bytes(int ks0, int ks1) { return chunk_bytes(split_first_ks(ks0, ks1), 2); }
 template <int NT, int KS0, int KS1, int ACT, int NEXT_BYTES, class In0, class In1, class Bias, class Pre>
 __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
                                       Frag *__restrict__ out, Bias &bias, int h,
@@ -566,8 +636,10 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
     // `jump`: where the bias blocks continue after this layer's last pair, when not at the following block of the table (column-folded
     // launches take conv1's and conv5's blocks from the per-column table and everything else from the layer table)
     constexpr int NPAIR = NT / 2;
-    constexpr int B0 = chunk_bytes(KS0, 2), B1 = chunk_bytes(KS1, 2);
-    constexpr int NS = KS0 < 16 ? KS0 : 16;
+    constexpr int KT = KS0 + KS1, KA = split_first_ks(KS0, KS1), KB = KT - KA;
+    static_assert(KA <= KS0, "the first chunk of a pair stays inside the first segment");
+    constexpr int BA = chunk_bytes(KA, 2), BB = chunk_bytes(KB, 2);
+    constexpr int NS = KT < 16 ? KT : 16;
     f32x16 prev[2];
     EpiRegs<(16 + NS - 1) / NS> est;
     static_for<NPAIR>([&](auto pc) {
@@ -575,25 +647,58 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
         f32x16 acc[2];
         bias.take(acc, 2, h);
         if constexpr (p == NPAIR - 1) { if (jump) bias.rewind(jump, jump_lane); }
-        constexpr int after0 = KS1 > 0 ? B1 : (p + 1 < NPAIR ? B0 : NEXT_BYTES);
-        if constexpr (p == 0) {
-            chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc, auto rc) {
-                if constexpr (decltype(kc)::value == 0 && decltype(rc)::value == 5) bias.after_barrier(h);
-                pre(kc, rc);
+        constexpr int afterA = KB > 0 ? BB : (p + 1 < NPAIR ? BA : NEXT_BYTES);
+        chunk<KA, 2, afterA>(s, in0, acc, [&](auto kc, auto rc) {
+            if constexpr (decltype(kc)::value == 0 && decltype(rc)::value == 5) bias.after_barrier(h);
+            if constexpr (p == 0) pre(kc, rc);
+            else epi_part<ACT, NS, decltype(kc)::value, decltype(rc)::value>(prev, out + 4 * (p - 1), est, s.range);
+        });
+        if constexpr (KB > 0) {
+            constexpr int afterB = p + 1 < NPAIR ? BA : NEXT_BYTES;
+            const CatIn<KA, KS0 - KA, In0, In1> tail{in0, in1};
+            chunk<KB, 2, afterB>(s, tail, acc, [&](auto kc, auto rc) {
+                if constexpr (p > 0) epi_part<ACT, NS, KA + decltype(kc)::value, decltype(rc)::value>(prev, out + 4 * (p - 1), est, s.range);
             });
-        } else {
-            chunk<KS0, 2, after0>(s, in0, acc, [&](auto kc, auto rc) {
-                if constexpr (decltype(kc)::value == 0 && decltype(rc)::value == 5) bias.after_barrier(h);
-                epi_part<ACT, NS, decltype(kc)::value, decltype(rc)::value>(prev, out + 4 * (p - 1), est, s.range);
-            });
-        }
-        if constexpr (KS1 > 0) {
-            constexpr int after1 = p + 1 < NPAIR ? B0 : NEXT_BYTES;
-            chunk<KS1, 2, after1>(s, in1, acc, NoSide{});
         }
         prev[0] = acc[0]; prev[1] = acc[1];
     });
     pend[0] = prev[0]; pend[1] = prev[1];
+}
+
+// A layer with a SHORT K (conv1 of a column-folded launch: the xyz k-step; shared.0: the four k-steps of the positional encoding): all eight
+// output tiles in ONE chunk (wide8), instead of four chunks of 6 .. 24 MFMAs that each carried a full epilogue and a barrier (round 2: 7.8 k cycles
+// for conv1's 24 MFMAs).  Pair 0 is finished right away (flush), pairs 1 .. 3 inside the first chunk of the NEXT layer: pair q's four fragments
+// out[4q .. 4q+3] are produced during k-steps 4(q-1) .. 4(q-1)+3, one fragment per k-step, four k-steps before they are read.
+template <int ACT>
+struct PendWide {
+    const f32x16 *acc8;
+    Frag *out;
+    RangeTrack *range;
+    EpiRegs<4> st;
+    template <class KC, class RC>
+    __device__ __forceinline__ void operator()(KC, RC)
+    {
+        constexpr int k = KC::value;
+        if constexpr (k < 12) epi_part<ACT, 4, k % 4, RC::value>(acc8 + 2 * (1 + k / 4), out + 4 * (1 + k / 4), st, *range);
+    }
+};
+// bias blocks of a wide layer: tiles 2 .. 7 are requested directly -- call this EARLY, their latency then hides behind the prologue work in front
+// of the layer --, tiles 0 / 1 arrive through the queue (wide8)
+template <class Bias>
+__device__ __forceinline__ void wide_bias_early(const Bias &bias, f32x16 *acc8)
+{
+#pragma unroll
+    for (int t = 2; t < 8; ++t) acc8[t] = bias.tile_at(t);
+}
+template <int KS, int NEXT_BYTES, class In, class Bias>
+__device__ __forceinline__ void wide8(Stream &s, const In &in, f32x16 *__restrict__ acc8, Bias &bias, int h, const float *jump = nullptr, unsigned jump_lane = 0)
+{
+    bias.take(acc8, 2, h);
+    bias.skip(192);
+    if (jump) bias.rewind(jump, jump_lane);
+    chunk<KS, 8, NEXT_BYTES>(s, in, acc8, [&](auto qc, auto rc) {
+        if constexpr (decltype(qc)::value == 0 && decltype(rc)::value == 5) bias.after_barrier(h);
+    });
 }
 
 // run a deferred epilogue right away (no chunk to hide it in)
@@ -615,9 +720,21 @@ __device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, B
     if constexpr (LAST) bias.rewind(bias_head, head_lane);      // the next block is the first one of the next point tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a1[r] = 0.f; a2[r] = 0.f; }
+#if AVC_DBG_TIMING
+    const long long tb0 = clock64();
+#endif
     pf_drain();
+#if AVC_DBG_TIMING
+    const long long tb1 = clock64();
+    s.t_drain += tb1 - tb0;
+#endif
 #if !AVC_DBG_NO_BARRIER
     __syncthreads();
+#endif
+#if AVC_DBG_TIMING
+    const long long tb2 = clock64();
+    s.t_bar += tb2 - tb0;
+    stamp3(s, tb0, tb1, tb2);
 #endif
     unsigned base = s.parity * layout::SLOT_BYTES + s.lane_off;
     unsigned so = s.pf_off;
@@ -774,7 +891,9 @@ constexpr int B_MAIN = chunk_bytes(16, 2);       // 64 KiB: two tiles x 16 k-ste
 constexpr int B_IN67 = chunk_bytes(layout::IN67_KS, 2);
 constexpr int B_PE = chunk_bytes(layout::PE_KS, 2);
 constexpr int B_HEAD16 = chunk_bytes(16, 1), B_HEAD8 = chunk_bytes(8, 1);
-constexpr int B_XYZ = chunk_bytes(1, 2);         // column-folded launches: conv1 / the input part of conv5 are the xyz k-step alone
+constexpr int B_XYZ8 = chunk_bytes(1, 8);        // column-folded launches: conv1 is the xyz k-step alone, all eight tiles in one chunk (wide8)
+constexpr int B_PE8 = chunk_bytes(layout::PE_KS, 8);     // shared.0: four k-steps, all eight tiles in one chunk
+constexpr int B_CONV5 = first_chunk_bytes(16, layout::IN67_KS), B_CONV5F = first_chunk_bytes(16, 1), B_SHARED4 = first_chunk_bytes(16, layout::PE_KS);
 
 // ---- column folding of a DENSE launch -----------------------------------------------------------------------------------------------
 // The points of a dense grid run along the last axis, and the pose feature of WarpingField.query (arch_avatar.py:125-133) is sampled at
@@ -835,14 +954,13 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    constexpr int B_FIRST = WARP ? (FOLD ? B_XYZ : B_IN67) : B_PE;       // first chunk of a pass (the prefetcher wraps to it)
+    constexpr int B_FIRST = WARP ? (FOLD ? B_XYZ8 : B_IN67) : B_PE8;     // first chunk of a pass (the prefetcher wraps to it)
 
-    Stream s = stream_init(p, wave, lane, B_FIRST);
-#if AVC_DBG_TIMING
     const long long tk0 = clock64();
-#endif
+    Stream s = stream_init(p, wave, lane, B_FIRST);
     using BiasQ = std::conditional_t<FOLD == 2, BiasQueueLane, BiasQueue>;
     BiasQ bias;
+    bias.hoff = 16u * h;
     const unsigned tiles_per_col = FOLD == 1 ? p.grz / TILE_PTS : 1u;
     float pt_next[3];                    // FOLD == 2: the next tile's point is loaded a tile ahead (its column decides where the bias queue continues)
     unsigned col_next = 0;
@@ -860,6 +978,13 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         const int64_t pidx = pidx_raw < p.n ? pidx_raw : p.n - 1;
 #if AVC_DBG_TIMING
         const long long tp0 = clock64();
+#if AVC_DBG_TIMING >= 2
+        if (p.out1 && tile + gridDim.x >= p.ntiles) {      // the workgroup's last tile: stamp every chunk step (rows of 256 x int64 behind the 64 KiB summary area)
+            s.stamp = reinterpret_cast<long long *>(p.out1) + 8192 + (size_t)(blockIdx.x * 4 + wave) * 256;
+            s.nstamp = 0;
+            stamp3(s, tp0, tp0, tp0);                       // opening stamp: the tile's prologue lies between this one and the first chunk's entry
+        }
+#endif
 #endif
         float pt[3];
         unsigned col = 0;
@@ -876,6 +1001,8 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         unsigned park = PARK_BASE + wave * PARK_PER_WAVE + lane * 16;
         asm volatile("" : "+v"(park));   // opaque per tile: otherwise every park address is hoisted out of the loop as its own VGPR
         f32x16 pa[2], pb[2];             // deferred accumulators of a layer's last tile pair (ping/pong)
+        f32x16 w8[8];                    // the eight accumulators of a wide layer (conv1 of a folded launch, shared.0)
+        if constexpr (WARP && FOLD != 0) wide_bias_early(bias, w8);      // conv1's column blocks, tiles 2 .. 7: in flight during the prologue
         const float *bias_head = p.bias;
         asm volatile("" : "+s"(bias_head));   // opaque per tile: keeps bias addresses from being hoisted out of the loop
         unsigned head_lane = 0;              // FOLD == 2: the next tile's per-lane row of the column table
@@ -915,20 +1042,24 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
                     bias_head = p.colterms; head_lane = col_next * 2048u;
                 }
                 asm volatile("" : "+s"(after1), "+s"(col5), "+s"(after5), "+s"(bias_head));
-                dense<8, 1, 0, ACT_SOFTPLUS, B_MAIN>(s, R4, R4, X, bias, h, NoSide{}, pa, after1);                                // conv1+bn1 on xyz (+ column term)
+                wide8<1, B_MAIN>(s, R4, w8, bias, h, after1);                                                                       // conv1+bn1 on xyz (+ column term)
+                flush<ACT_SOFTPLUS>(w8, X, s.range);
+                dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, PendWide<ACT_SOFTPLUS>{w8, X, &s.range}, pb);         // conv2 (+ conv1's pairs 1 .. 3)
             } else {
                 dense<8, layout::IN67_KS, 0, ACT_SOFTPLUS, B_MAIN>(s, S, S, X, bias, h, NoSide{}, pa);                   // conv1+bn1
+                dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                    // conv2
             }
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                        // conv2
             dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RY, RY, X, bias, h, SP{pb, Y + 12, &s.range}, pa);                        // conv3
-            dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5, lane5);           // conv4
-            if constexpr (FOLD != 0)
+            if constexpr (FOLD != 0) {
+                dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5F>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5, lane5);     // conv4
                 dense<8, 16, 1, ACT_SOFTPLUS, B_MAIN>(s, RY, R4, X, bias, h, SP{pb, Y + 12, &s.range}, pa, after5);            // conv5 on [xyz | x4] (+ column term)
-            else
+            } else {
+                dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                   // conv4
                 dense<8, 16, layout::IN67_KS, ACT_SOFTPLUS, B_MAIN>(s, RY, S, X, bias, h, SP{pb, Y + 12, &s.range}, pa);       // conv5 on [x0|x4]
+            }
             dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                        // conv6
             dense<8, 16, 0, ACT_SOFTPLUS, B_HEAD16>(s, RY, RY, X, bias, h, SP{pb, Y + 12, &s.range}, pa);                      // conv7
-            const f32x16 o = head<16, B_PE, false>(s, X, bias, bias_head, h, SP{pa, X + 12, &s.range});                                  // out_layer_coord_affine
+            const f32x16 o = head<16, B_PE8, false>(s, X, bias, bias_head, h, SP{pa, X + 12, &s.range});                                 // out_layer_coord_affine
             // rows 0..2 live in lanes h == 0, regs 0..2: broadcast to the other half
             off[0] = __shfl(o[0], j, 64); off[1] = __shfl(o[1], j, 64); off[2] = __shfl(o[2], j, 64);
             q[0] = pt[0] + off[0]; q[1] = pt[1] + off[1]; q[2] = pt[2] + off[2];                                       // arch_avatar.py:372 (fp32 add)
@@ -938,6 +1069,7 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
 #if AVC_DBG_TIMING
         const long long tp1 = clock64();
 #endif
+        wide_bias_early(bias, w8);                                                                                              // shared.0's blocks, tiles 2 .. 7
         posenc(q, h, park, s.range);                                                                                            // :70 (parked in LDS)
         const ParkIn P{park, nullptr};
         const RegIn TX{X}, TY{Y};
@@ -945,10 +1077,11 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         s.t_pro += clock64() - tp1;
 #endif
         using RP = Pending<ACT_RELU, 8>;
-        dense<8, layout::PE_KS, 0, ACT_RELU, B_MAIN>(s, P, P, X, bias, h, NoSide{}, pa);                                 // shared 0
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12, &s.range}, pb);
+        wide8<layout::PE_KS, B_MAIN>(s, P, w8, bias, h);                                                                 // shared 0
+        flush<ACT_RELU>(w8, X, s.range);
+        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, PendWide<ACT_RELU>{w8, X, &s.range}, pb);               // shared 1 (+ shared 0's pairs 1 .. 3)
         dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TY, TY, X, bias, h, RP{pb, Y + 12, &s.range}, pa);
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12, &s.range}, pb);
+        dense<8, 16, 0, ACT_RELU, B_SHARED4>(s, TX, TX, Y, bias, h, RP{pa, X + 12, &s.range}, pb);
         dense<8, 16, layout::PE_KS, ACT_RELU, B_MAIN>(s, TY, P, X, bias, h, RP{pb, Y + 12, &s.range}, pa);                     // shared 4 on [x|x0]
         dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12, &s.range}, pb);                                                       // shared 5
         f32x16 g;
@@ -979,10 +1112,15 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         }
     }
     s.range.report(p);
+    if (p.clk && blockIdx.x == 0 && threadIdx.x == 0) { p.clk[0] = tk0; p.clk[1] = clock64(); }     // workgroup 0 is there from the first tile to the last
 #if AVC_DBG_TIMING
-    if (lane == 0 && p.out1) {     // debug: overwrite the head of the offsets buffer with (total, barrier) cycles per wave
-        long long *dbg = reinterpret_cast<long long *>(p.out1) + 4 * (blockIdx.x * 4 + wave);
-        dbg[0] = clock64() - tk0; dbg[1] = s.t_bar; dbg[2] = s.t_drain; dbg[3] = s.t_pro;
+    if (p.out1) {                  // debug: overwrite the head of the offsets buffer with (total, barrier, drain, prologue) cycles per wave
+        const long long tend = clock64();
+        stamp3(s, tend, tend, (long long)s.nstamp);     // closing stamp of the last tile + the number of chunk steps stamped
+        if (lane == 0) {
+            long long *dbg = reinterpret_cast<long long *>(p.out1) + 4 * (blockIdx.x * 4 + wave);
+            dbg[0] = tend - tk0; dbg[1] = s.t_bar; dbg[2] = s.t_drain; dbg[3] = s.t_pro;
+        }
     }
 #endif
 }
@@ -1001,6 +1139,7 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
 
+    const long long tk0 = clock64();
     Stream s = stream_init(p, wave, lane, B_IN33);
 
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
@@ -1044,7 +1183,7 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
         chunk<4, 8, B_WIDE4>(s, RegIn{X + 4}, acc, NoSide{});
         chunk<4, 8, B_WIDE4>(s, RegIn{X + 8}, acc, NoSide{});
         chunk<4, 8, B_WIDE_IN33>(s, RegIn{X + 12}, acc, NoSide{});
-        chunk<layout::IN33_KS, 8, B_MAIN>(s, RI, acc, NoSide{});
+        chunk<layout::IN33_KS, 8, first_chunk_bytes(16, layout::IN33_KS)>(s, RI, acc, NoSide{});
 #pragma unroll
         for (int t = 0; t < 8; t += 2) flush<ACT_LEAKY>(acc + t, Y + 2 * t, s.range);
         // fc2 on [x(256) | in(33)] -> 128
@@ -1053,15 +1192,19 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
         if (h == 0 && pidx_raw < p.n) p.out0[pidx_raw] = sigmoid_f(o[0]);                         // last_op sigmoid
     }
     s.range.report(p);
+    if (p.clk && blockIdx.x == 0 && threadIdx.x == 0) { p.clk[0] = tk0; p.clk[1] = clock64(); }
 }
 
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-static void timing_begin(avc_ctx *ctx, int which, hipStream_t s, hipEvent_t &e0, hipEvent_t &e1)
+static void timing_begin(avc_ctx *ctx, int which, hipStream_t s, hipEvent_t &e0, hipEvent_t &e1, QueryParams &p)
 {
     e0 = e1 = nullptr;
     if (!ctx->timing.enabled) return;
+    auto &t = ctx->timing;
+    if (!t.clk_dev[which] && hipMalloc((void **)&t.clk_dev[which], 2 * sizeof(long long) * Timing::CLK_SLOTS) != hipSuccess) t.clk_dev[which] = nullptr;
+    if (t.clk_dev[which]) p.clk = t.clk_dev[which] + 2 * (t.clk_count[which]++ % Timing::CLK_SLOTS);
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, s);
 }
@@ -1133,7 +1276,7 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
 #if AVC_CHECK_RANGE
     const bool can_fold = false;               // the range-checked flavour (a debugging aid) keeps to the point-by-point kernels: half the build time
 #else
-    const bool can_fold = grid && !template_only && !colour && ctx->warp_tmpl_fold.ready && !getenv("AVC_NO_FOLD");
+    const bool can_fold = grid && !template_only && !colour && ctx->warp_tmpl_fold.ready && ctx->opt.column_fold;
 #endif
     const int fold = !can_fold ? 0 : (grid->idx ? 2 : (grid->res[2] % TILE_PTS == 0 ? 1 : 0));
     PackedNet &net = template_only ? (colour ? ctx->tmpl_only_clr : ctx->tmpl_only) : (colour ? ctx->warp_tmpl_clr : (fold ? ctx->warp_tmpl_fold : ctx->warp_tmpl));
@@ -1151,8 +1294,7 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
     p.out0 = occ; p.out1 = offset; p.out2 = rgba; p.sigmoid_occ = occ_sigmoid;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;
     p.stream_bytes = bytes_until(net, net.chunks.size());
-    const char *gb = getenv("AVC_MLP_BLOCKS");           // experiment knob: persistent workgroups (default: one per CU)
-    const int grid_dim = (int)std::min<int64_t>(p.ntiles, gb && atoi(gb) > 0 ? atoi(gb) : ctx->num_cus);
+    const int grid_dim = (int)std::min<int64_t>(p.ntiles, ctx->opt.mlp_blocks > 0 ? ctx->opt.mlp_blocks : ctx->num_cus);   // persistent workgroups
     rc = range_begin(ctx, s);
     if (rc) return rc;
     if (fold) {
@@ -1166,7 +1308,7 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
         p.colterms = static_cast<const float *>(ctx->col_scratch);
     }
     hipEvent_t e0, e1;
-    timing_begin(ctx, 0, s, e0, e1);           // (a folded launch is timed with its column pass)
+    timing_begin(ctx, 0, s, e0, e1, p);        // (a folded launch is timed with its column pass)
 #define LAUNCH(W_, C_, F_)                                                                              \
     do {                                                                                                \
         rc = set_lds(avatar_kernel<W_, C_, F_>);                                                        \
@@ -1205,13 +1347,13 @@ int launch_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n
     p.stream_bytes = bytes_until(net, net.chunks.size());
     p.out0 = out;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;
-    const int grid_dim = (int)std::min<int64_t>(p.ntiles, ctx->num_cus);
+    const int grid_dim = (int)std::min<int64_t>(p.ntiles, ctx->opt.mlp_blocks > 0 ? ctx->opt.mlp_blocks : ctx->num_cus);
     rc = set_lds(recon_kernel);
     if (rc) return rc;
     rc = range_begin(ctx, s);
     if (rc) return rc;
     hipEvent_t e0, e1;
-    timing_begin(ctx, 1, s, e0, e1);
+    timing_begin(ctx, 1, s, e0, e1, p);
     hipLaunchKernelGGL(recon_kernel, dim3(grid_dim), dim3(256), LDS_BYTES, s, p);
     AVC_HIP(hipGetLastError());
     timing_end(ctx, 1, s, e0, e1);

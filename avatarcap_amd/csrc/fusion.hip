@@ -506,7 +506,7 @@ int merge_normal_images(avc_ctx *ctx, const float *src_in, const float *tar_in, 
     hipLaunchKernelGGL(fus_dt_cols_kernel, dim3((W + 63) / 64), dim3(64 * DT_SEGS), 0, s, B.dt_g, H, W, B.dtm);
     hipLaunchKernelGGL(fus_valid_kernel, grd, blk, 0, s, B.smask, B.emask, (int)np, B.valid, B.count);
     if (iter_num > 0) {
-        if (getenv("AVC_FUSION_NO_GRAPH")) {                                                     // A/B knob: plain launches
+        if (!ctx->opt.fusion_graph) {                                                            // avc_set_option "fusion_graph" 0: plain launches (A/B)
             if (int rc = fusion_iterations(B, H, W, iter_num, s, nullptr)) return rc;
         } else {
             if (!ctx->fusion_graph_exec || ctx->fusion_graph_H != H || ctx->fusion_graph_W != W || ctx->fusion_graph_iters != iter_num) {

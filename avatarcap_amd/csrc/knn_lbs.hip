@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void skinning_kernel(const float *__restrict__
 static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, GridView &g, hipStream_t s)
 {
     g = GridView{nullptr, nullptr, nullptr, 0};
-    if (nr < GRID_MIN_REFS || getenv("AVC_KNN_BRUTE")) return AVC_OK;
+    if (nr < GRID_MIN_REFS || ctx->opt.knn_search == 3) return AVC_OK;
     // cells per axis: about one occupied cell per few reference points for surface-like sets (6890 -> 32, 1e6 -> 128)
     const int axis = std::min(GRID_MAX_AXIS, std::max(8, (int)(1.7 * cbrt((double)nr))));
     const size_t ncell = (size_t)axis * axis * axis;
@@ -499,8 +499,8 @@ static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, Gri
     hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, hdr, start, cursor);
     hipLaunchKernelGGL(grid_scatter_kernel, blocks, threads, 0, s, ref, nr, hdr, cursor, sorted);
     AVC_HIP(hipGetLastError());
-    const char *path = getenv("AVC_KNN_PATH");          // debugging / test knob: "lane" or "wave" forces one search for every wave
-    g = GridView{hdr, start, sorted, path && !strcmp(path, "lane") ? 0 : (path && !strcmp(path, "wave") ? 0x7fffffff : LANE_BOX)};
+    // avc_set_option "knn_search" (debugging / test switch): 1 or 2 force the per-lane or the cooperative search on every wave
+    g = GridView{hdr, start, sorted, ctx->opt.knn_search == 1 ? 0 : (ctx->opt.knn_search == 2 ? 0x7fffffff : LANE_BOX)};
     return AVC_OK;
 }
 

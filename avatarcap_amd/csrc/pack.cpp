@@ -181,7 +181,7 @@ static void add_warp(Builder &B, const avc_ctx::Staged &w, bool fold = false)
                 B.net.colw[(size_t)(256 + o) * 64 + c] = (float)W5[(size_t)o * 323 + 3 + c];              // conv5 sees cat([x0, x4]) (mlp.py:106)
             }
     }
-    B.layer(W1, scaled(w.b[0], LOG2E), 256, 67, {fold ? seg_xyz() : seg_in67()}, 2, 16);                   // conv1 (raw inputs)
+    B.layer(W1, scaled(w.b[0], LOG2E), 256, 67, {fold ? seg_xyz() : seg_in67()}, fold ? 8 : 2, 16);        // conv1 (raw inputs; folded: one wide chunk)
     for (int i = 1; i <= 3; ++i) B.layer(w.W[i], scaled(w.b[i], LOG2E), 256, 256, {seg_d(16)}, 2, 16);      // conv2..4
     B.layer(W5, scaled(w.b[4], LOG2E), 256, 323,
             {seg_d(16, 67), fold ? seg_xyz() : seg_in67()}, 2, 16);              // conv5: cat([x0 (raw), x4 (softplus)]) (mlp.py:106)
@@ -194,7 +194,7 @@ static void add_warp(Builder &B, const avc_ctx::Staged &w, bool fold = false)
 // an exact identity that removes 65,536 of the 886,784 MAC per point (and one epilogue).
 static void add_template(Builder &B, const avc_ctx::Staged &t, bool colour)
 {
-    B.layer(t.W[0], t.b[0], 256, 63, {seg_pe()}, 2, 16);                         // shared 0
+    B.layer(t.W[0], t.b[0], 256, 63, {seg_pe()}, 8, 16);                         // shared 0: one wide chunk (k-major over all eight tiles)
     for (int i = 1; i <= 3; ++i) B.layer(t.W[i], t.b[i], 256, 256, {seg_d(16)}, 2, 16);
     B.layer(t.W[4], t.b[4], 256, 319, {seg_d(16), seg_pe(256)}, 2, 16);          // shared 4: cat([x, x0]) (mlp.py:61)
     B.layer(t.W[5], t.b[5], 256, 256, {seg_d(16)}, 2, 16);

@@ -233,6 +233,19 @@ int avc_skinning(avc_ctx *ctx, const float *pts_dev, const float *nrm_dev, int64
  * launches since the last reset; used by bench.py for roofline.achieved.  which: 0 avatar, 1 recon. */
 int avc_timing_enable(avc_ctx *ctx, int enable);
 int avc_timing_read(avc_ctx *ctx, int which, double *avg_ms_out, int64_t *launches_out, int reset);
+/* Shader cycles (s_memtime, workgroup 0 from its first tile to its last) of the same timed launches, averaged over the (at most 64) launches
+ * since the last call; synchronises the device.  cycles / ms = the shader clock the power manager held DURING the launch (bench.py's
+ * `roofline.clock_mhz`). */
+int avc_timing_read_cycles(avc_ctx *ctx, int which, double *avg_cycles_out, int64_t *launches_out);
+
+/* ---- switches of a context --------------------------------------------------------------------
+ * No entry point reads the environment: avc_ctx_create reads the defaults ONCE (AVC_NO_FOLD, AVC_MLP_BLOCKS, AVC_KNN_BRUTE / AVC_KNN_PATH,
+ * AVC_FUSION_NO_GRAPH), this call changes them afterwards.  Test / A-B switches; none changes what a caller may rely on:
+ *   "column_fold"  1 (default) | 0   avc_avatar_query_grid[_subset] without column folding: bit-identical to avc_avatar_query instead of ~1e-6 from it
+ *   "mlp_blocks"   0 (default: one persistent workgroup per CU) | n
+ *   "knn_search"   0 (default: per wave) | 1 per-lane grid search | 2 cooperative grid search | 3 exhaustive scan -- all four return the same bits
+ *   "fusion_graph" 1 (default: the fusion iterations replay a hipGraph) | 0 plain launches */
+int avc_set_option(avc_ctx *ctx, const char *name, int value);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import golden_inputs as gi
-from avatarcap_amd import config
+from avatarcap_amd import _lib, config
 from common import geotex_sd, maxabs
 
 pytestmark = pytest.mark.gpu
@@ -83,9 +83,9 @@ def test_lbs_at_full_vertex_count(frame, monkeypatch):
     pipe, ds, items, out = frame
     v = out['cano_v']
     lbs = smpl_util.calculate_lbs(v[None])
-    monkeypatch.setenv('AVC_KNN_BRUTE', '1')
+    _lib.set_option('knn_search', 3)
     lbs_b = smpl_util.calculate_lbs(v[None])
-    monkeypatch.delenv('AVC_KNN_BRUTE')
+    _lib.set_option('knn_search', 0)
     assert torch.equal(lbs, lbs_b)                                                    # grid search == exhaustive scan, bit for bit
     s = lbs[0].sum(1)
     d2, _ = smpl_util.knn_points(v[None], ds.cano_smpl_v.cuda()[None], K=1)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import golden_inputs as gi
-from avatarcap_amd import config, synthetic as syn
+from avatarcap_amd import _lib, config, synthetic as syn
 from common import maxabs
 
 pytestmark = pytest.mark.gpu
@@ -141,14 +141,14 @@ def test_knn_grid_equals_brute_force(body, K, monkeypatch):
     for refs in (ref, ref[:700], ref[:40]):
         qt, rt = _t(q[None]), _t(refs[None])
         d_g, i_g = su.knn_points(qt, rt, K=K)
-        monkeypatch.setenv('AVC_KNN_BRUTE', '1')
+        _lib.set_option('knn_search', 3)
         d_b, i_b = su.knn_points(qt, rt, K=K)
-        monkeypatch.delenv('AVC_KNN_BRUTE')
+        _lib.set_option('knn_search', 0)
         assert torch.equal(i_g, i_b) and torch.equal(d_g, d_b)
         for path in ('lane', 'wave'):                                          # each of the two grid searches on its own, every wave
-            monkeypatch.setenv('AVC_KNN_PATH', path)
+            _lib.set_option('knn_search', {'lane': 1, 'wave': 2}[path])
             d_p, i_p = su.knn_points(qt, rt, K=K)
-            monkeypatch.delenv('AVC_KNN_PATH')
+            _lib.set_option('knn_search', 0)
             assert torch.equal(i_p, i_b) and torch.equal(d_p, d_b), path
         assert bool((d_g[0, :, 1:] >= d_g[0, :, :-1]).all())
         if K > 1:                                                              # ties resolved towards the lower index
@@ -171,14 +171,14 @@ def test_knn_large_reference_set(body, K, monkeypatch):
     q[:30_000] = q[:30_000][np.lexsort(np.floor(q[:30_000] * 20).T)]          # spatially coherent, like mesh vertices
     qt, rt = _t(q[None]), _t(ref[None])
     d_g, i_g = su.knn_points(qt, rt, K=K)
-    monkeypatch.setenv('AVC_KNN_BRUTE', '1')
+    _lib.set_option('knn_search', 3)
     d_b, i_b = su.knn_points(qt, rt, K=K)
-    monkeypatch.delenv('AVC_KNN_BRUTE')
+    _lib.set_option('knn_search', 0)
     assert torch.equal(i_g, i_b) and torch.equal(d_g, d_b)
     for path in ('lane', 'wave'):
-        monkeypatch.setenv('AVC_KNN_PATH', path)
+        _lib.set_option('knn_search', {'lane': 1, 'wave': 2}[path])
         d_p, i_p = su.knn_points(qt, rt, K=K)
-        monkeypatch.delenv('AVC_KNN_PATH')
+        _lib.set_option('knn_search', 0)
         assert torch.equal(i_p, i_b) and torch.equal(d_p, d_b), path
     dd = torch.cdist(qt[0, :2000].double(), rt[0].double()) ** 2                # an independent check of a sample
     assert float((dd.min(1).values - d_g[0, :2000, 0].double()).abs().max()) < 1e-6

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import golden_inputs as gi
-from avatarcap_amd import config, synthetic as syn
+from avatarcap_amd import _lib, config, synthetic as syn
 from common import geotex_sd, recon_sd, maxabs
 
 pytestmark = pytest.mark.gpu
@@ -246,8 +246,11 @@ def test_column_folded_grid_query(net, res, monkeypatch):
     assert maxabs(g['cano_pts_ov'][0].cpu().numpy(), ref['cano_pts_ov']) < TOL and maxabs(g['nonrigid_offset'][0].cpu().numpy(), ref['nonrigid_offset']) < TOL
     g2 = OccupancyNet(net).query_grid(batch, volume_axes(syn.CANO_BOUNDS, res, 'cuda'), res)
     assert torch.equal(g2['cano_pts_ov'], g['cano_pts_ov'])                    # deterministic, with or without the offsets written
-    monkeypatch.setenv('AVC_NO_FOLD', '1')
-    u = OccupancyNet(net).query_grid(batch, volume_axes(syn.CANO_BOUNDS, res, 'cuda'), res, want_offset=True)
+    _lib.set_option('column_fold', 0)
+    try:
+        u = OccupancyNet(net).query_grid(batch, volume_axes(syn.CANO_BOUNDS, res, 'cuda'), res, want_offset=True)
+    finally:
+        _lib.set_option('column_fold', 1)
     assert torch.equal(u['cano_pts_ov'], a['cano_pts_ov']) and torch.equal(u['nonrigid_offset'], a['nonrigid_offset'])
 
 
@@ -280,8 +283,11 @@ def test_grid_subset_query(net, res, n, monkeypatch):
     # a point's value does not depend on which points share its launch: the same indices reversed
     back = OccupancyNet(net).query_grid(_batch(pts), ax, res, index=torch.flip(index, [0]).contiguous())
     assert torch.equal(torch.flip(back['cano_pts_ov'], [1]), g['cano_pts_ov'])
-    monkeypatch.setenv('AVC_NO_FOLD', '1')
-    u = OccupancyNet(net).query_grid(_batch(pts), ax, res, want_offset=True, index=index)
+    _lib.set_option('column_fold', 0)
+    try:
+        u = OccupancyNet(net).query_grid(_batch(pts), ax, res, want_offset=True, index=index)
+    finally:
+        _lib.set_option('column_fold', 1)
     assert torch.equal(u['cano_pts_ov'], a['cano_pts_ov']) and torch.equal(u['nonrigid_offset'], a['nonrigid_offset'])
     with pytest.raises(TypeError):
         OccupancyNet(net).query_grid(_batch(pts), ax, res, index=index.to(torch.int64))

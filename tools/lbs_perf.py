@@ -1,9 +1,9 @@
 """calculate_lbs timing: scattered queries (worst case for the wave-cooperative grid search) and queries in
 marching-cubes vertex order (the frame's case): the grid search as shipped (per-wave choice), each of its two searches forced
-(AVC_KNN_PATH=lane|wave), and the exhaustive scan (AVC_KNN_BRUTE=1)."""
+(avc_set_option knn_search 1 | 2), and the exhaustive scan (knn_search 3)."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
-from avatarcap_amd import config, synthetic as syn
+from avatarcap_amd import _lib, config, synthetic as syn
 config.cfg = config.default_cfg(); config.device = torch.device('cuda')
 from avatarcap_amd.utils.smpl_util import SmplUtil
 from avatarcap_amd.utils import recon_util
@@ -14,14 +14,12 @@ su = SmplUtil(body['skin_weights']); su.set_cano_smpl_vertices(torch.from_numpy(
 
 def timeit(name, pts):
     for mode in ('grid', 'lane', 'wave', 'brute'):
-        os.environ.pop('AVC_KNN_BRUTE', None); os.environ.pop('AVC_KNN_PATH', None)
-        if mode == 'brute': os.environ['AVC_KNN_BRUTE'] = '1'
-        elif mode != 'grid': os.environ['AVC_KNN_PATH'] = mode
+        _lib.set_option('knn_search', {'grid': 0, 'lane': 1, 'wave': 2, 'brute': 3}[mode])
         su.calculate_lbs(pts); torch.cuda.synchronize()
         t = time.time()
         for _ in range(5): su.calculate_lbs(pts)
         torch.cuda.synchronize(); print(f'{name:28s} n={pts.shape[1]:8d} {mode:5s}: {(time.time()-t)/5*1e3:7.3f} ms', flush=True)
-    os.environ.pop('AVC_KNN_BRUTE', None); os.environ.pop('AVC_KNN_PATH', None)
+    _lib.set_option('knn_search', 0)
 
 
 rs = np.random.RandomState(0)

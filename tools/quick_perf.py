@@ -18,8 +18,17 @@ for res in (128, 256):
     ax = volume_axes(syn.CANO_BOUNDS, (res, res, res), 'cuda')
     run = (lambda: OccupancyNet(net).query_grid(batch, ax, (res, res, res))) if GRID else (lambda: OccupancyNet(net).query(batch))
     o = run(); torch.cuda.synchronize()
+    import ctypes as C
+    from avatarcap_amd import _lib
+    ctx = _lib.ctx(torch.device('cuda', 0))
+    _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
     t0 = time.time(); reps = 3
     for _ in range(reps): o = run()
     torch.cuda.synchronize(); dt = (time.time() - t0) / reps
+    ms, nl, cyc = C.c_double(), C.c_int64(), C.c_double()
+    _lib.check(_lib.lib().avc_timing_read(ctx, 0, C.byref(ms), C.byref(nl), 1))
+    _lib.check(_lib.lib().avc_timing_read_cycles(ctx, 0, C.byref(cyc), C.byref(nl)))
+    _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
     n = res ** 3
-    print(f'res {res}: {dt*1e3:.2f} ms  {n/dt/1e6:.1f} Mpts/s  {n*1773568/dt/1e12:.1f} TFLOP/s algorithmic  ({n*1773568*3/dt/1e12:.0f} issued)', flush=True)
+    print(f'res {res}: {dt*1e3:.2f} ms  {n/dt/1e6:.1f} Mpts/s  {n*1773568/dt/1e12:.1f} TFLOP/s algorithmic  ({n*1773568*3/dt/1e12:.0f} issued)  '
+          f'device {ms.value:.2f} ms, {cyc.value:.4e} shader cycles = {cyc.value / max(ms.value, 1e-9) / 1e3:.0f} MHz', flush=True)
