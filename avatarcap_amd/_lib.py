@@ -44,6 +44,9 @@ _SIGNATURES = {
     'avc_set_range_check': (C.c_int, [C.c_void_p, C.c_int]),
     'avc_template_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_recon_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
+    'avc_recon_query_grid': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
+    'avc_recon_query_grid_subset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_int64,
+                                              C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
     'avc_group_norm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                  C.c_int, C.c_void_p, C.c_void_p]),
     'avc_scatter_volume': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -69,6 +69,7 @@ struct avc_ctx {
     avc::PackedNet tmpl_only;      // template alone (pts_space == 'temp'), geometry only
     avc::PackedNet tmpl_only_clr;
     avc::PackedNet recon;
+    avc::PackedNet recon_fold;     // the decoder for grid launches: the 32 image-feature columns of fc0 / fc1 / fc2 enter per (x, y) column (fused_mlp.hip)
     bool warp_set = false, tmpl_set = false;
     // staged host-side effective weights until both halves of the avatar net have arrived
     struct Staged { std::vector<std::vector<double>> W; std::vector<std::vector<double>> b; std::vector<int> cout, cin; };
@@ -87,6 +88,7 @@ struct avc_ctx {
     void *scatter_scratch = nullptr; size_t scatter_scratch_bytes = 0;   // block counts of avc_scatter_volume
     void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
     void *col_scratch = nullptr; size_t col_scratch_bytes = 0;     // per-column terms of a column-folded dense query (512 floats per column)
+    void *rcol_scratch = nullptr; size_t rcol_scratch_bytes = 0;   // ... of a column-folded recon query (896 floats per column)
     avc::Timing timing;
     avc::Options opt;
     int check_range = 0;                 // avc_set_range_check

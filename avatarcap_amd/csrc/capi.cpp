@@ -45,7 +45,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
 {
     if (!ctx) return AVC_OK;
     hipSetDevice(ctx->device);
-    release(ctx->warp_tmpl); release(ctx->warp_tmpl_clr); release(ctx->warp_tmpl_fold); release(ctx->tmpl_only); release(ctx->tmpl_only_clr); release(ctx->recon);
+    release(ctx->warp_tmpl); release(ctx->warp_tmpl_clr); release(ctx->warp_tmpl_fold); release(ctx->tmpl_only); release(ctx->tmpl_only_clr); release(ctx->recon); release(ctx->recon_fold);
     if (ctx->pose_feat_hwc) hipFree(ctx->pose_feat_hwc);
     if (ctx->img_feat_hwc) hipFree(ctx->img_feat_hwc);
     if (ctx->mc_scratch) hipFree(ctx->mc_scratch);
@@ -56,6 +56,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->raster_scratch) hipFree(ctx->raster_scratch);
     if (ctx->knn_scratch) hipFree(ctx->knn_scratch);
     if (ctx->col_scratch) hipFree(ctx->col_scratch);
+    if (ctx->rcol_scratch) hipFree(ctx->rcol_scratch);
     if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
     release_fusion_graph(ctx);
     if (ctx->fusion_scratch) hipFree(ctx->fusion_scratch);
@@ -210,6 +211,33 @@ int avc_recon_query(avc_ctx *ctx, const float *pts, int64_t n, const float cente
     AVC_HIP(hipSetDevice(ctx->device));
     return ctx->check_range ? checked::launch_recon(ctx, pts, nullptr, n, center, out, (hipStream_t)stream)
                             : plain::launch_recon(ctx, pts, nullptr, n, center, out, (hipStream_t)stream);
+}
+
+static int run_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], float *out, hipStream_t s)
+{
+    return ctx->check_range ? checked::launch_recon(ctx, pts, grid, n, center, out, s) : plain::launch_recon(ctx, pts, grid, n, center, out, s);
+}
+
+int avc_recon_query_grid(avc_ctx *ctx, const float *axis_x, const float *axis_y, const float *axis_z, const int32_t res[3], const float center[3],
+                         float *out, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && axis_x && axis_y && axis_z && res && center && out, AVC_ERR_ARG, "avc_recon_query_grid: NULL argument");
+    AVC_REQUIRE(res[0] >= 1 && res[1] >= 1 && res[2] >= 1, AVC_ERR_ARG, "avc_recon_query_grid: every resolution must be >= 1");
+    AVC_HIP(hipSetDevice(ctx->device));
+    const GridDesc g{axis_x, axis_y, axis_z, {res[0], res[1], res[2]}};
+    return run_recon(ctx, nullptr, &g, (int64_t)res[0] * res[1] * res[2], center, out, (hipStream_t)stream);
+}
+
+int avc_recon_query_grid_subset(avc_ctx *ctx, const float *axis_x, const float *axis_y, const float *axis_z, const int32_t res[3], const int32_t *index,
+                                int64_t n, const float center[3], float *out, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && axis_x && axis_y && axis_z && res && center && n >= 0 && (n == 0 || (index && out)), AVC_ERR_ARG,
+                "avc_recon_query_grid_subset: NULL argument or negative n");
+    AVC_REQUIRE(res[0] >= 1 && res[1] >= 1 && res[2] >= 1, AVC_ERR_ARG, "avc_recon_query_grid_subset: every resolution must be >= 1");
+    AVC_HIP(hipSetDevice(ctx->device));
+    GridDesc g{axis_x, axis_y, axis_z, {res[0], res[1], res[2]}};
+    g.idx = index;
+    return run_recon(ctx, nullptr, &g, n, center, out, (hipStream_t)stream);
 }
 
 int avc_set_range_check(avc_ctx *ctx, int enabled)

@@ -182,6 +182,10 @@ struct ParkIn {
         }
     }
 };
+struct SameIn {                      // every k-step takes the same fragment
+    const Frag *f;
+    template <int K> __device__ __forceinline__ Frag get() const { return *f; }
+};
 // Two providers back to back: k-steps 0 .. N0-1 are provider A's k-steps OFF .. OFF+N0-1, the following ones provider B's from 0 (the second chunk of
 // a layer with a concatenated input: the tail of the hidden activations, then the raw network input -- see dense()).
 template <int OFF, int N0, class A, class B>
@@ -301,8 +305,13 @@ __device__ __forceinline__ void pf_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 // cycles per MFMA when clustered in one slot and 36.3 when spread over the six MFMAs).  Slot 0 issues the LDS reads of the next k-step's
 // operands, every slot its share of the next chunk's LDS-DMA, and region r = 2 * slot + tile (TPC == 2) stage r of the PREVIOUS tile pair's
 // epilogue slice (`side(k, r)`: accumulator read -> activation -> fp16 split, six stages).
-template <int KS, int TPC, int NEXT_BYTES, class In, class Side>
-__device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restrict__ acc, Side &&side)
+// KACC: the accumulators of k-step k are acc[k * KACC ...] (0: every k-step accumulates into the same TPC tiles; 8: a chunk whose k-steps are
+// DIFFERENT layers fed by the same B operand -- the folded recon kernel's [fc0 half | fc1's z column] chunk)
+// `ap(step, tile, a_hi)` may replace the `hi` A fragment of one (step, tile) in the (hi, hi) pass: a k-step whose input has free slots -- the z k-step of
+// the folded recon kernel -- carries a per-column term there, as fp16 (hi, lo) halves in two K slots against 1.0 in the B operand (ColPatch below).
+struct NoPatch { template <class Q, class T> __device__ __forceinline__ half8 operator()(Q, T, half8 a) const { return a; } };
+template <int KS, int TPC, int NEXT_BYTES, int KACC = 0, class In, class Side, class AP = NoPatch>
+__device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restrict__ acc, Side &&side, AP &&ap = AP{})
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // acquire: every wave has stored its share of this chunk (ds_write) and finished reading the other slot
@@ -351,7 +360,7 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
     static_for<Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int cur = q & 1, nxt = cur ^ 1;
-        f32x16 *const a2 = acc + (q % G) * T2;
+        f32x16 *const a2 = acc + (q % G) * T2 + (q / G) * KACC;
         // ---- slot 0
         // ONE wait for this step's operands (requested a whole step ago), before the next step's reads go out: hipcc would otherwise put
         // a counted `s_waitcnt lgkmcnt(n)` in front of every MFMA that touches a freshly read fragment, four issue slots per step
@@ -371,7 +380,7 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
         pf_step<Q, NEXT_BYTES, 3 * q + 0>(s.rs, so, dst, s.lane_off, s.wave);
         static_for<T2>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], as_half8(b[cur].hi), a2[t], 0, 0, 0);
+            a2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap(qc, tc, ah[cur][t]), as_half8(b[cur].hi), a2[t], 0, 0, 0);
             if constexpr (SIDE) { side(qc, RegionC<t>{}); __builtin_amdgcn_sched_barrier(0); }
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -437,6 +446,7 @@ struct BiasDirect {
 // (declared as the LLVM intrinsic itself: hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128 selects a ONE-dword load for the 128-bit result)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ f32x4 raw_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float raw_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ __forceinline__ f32x16 bias_tile_buf(i32x4 rs, unsigned voff, int byte0)
 {
     f32x16 a;
@@ -527,7 +537,7 @@ template <int ACT>
 __device__ __forceinline__ float act_f(float x)
 {
     if constexpr (ACT == ACT_RELU) return relu_bits(x);
-    else if constexpr (ACT == ACT_LEAKY) return x > 0.0f ? x : 0.02f * x;     // network/mlp.py:11
+    else if constexpr (ACT == ACT_LEAKY) return __builtin_fmaxf(x, 0.02f * x);    // LeakyReLU(0.02), network/mlp.py:11: max(x, 0.02 x) -- one multiply, one max
     else if constexpr (ACT == ACT_SOFTPLUS) return softplus_f(x);
     else return x;
 }
@@ -628,11 +638,13 @@ struct Pending {
 // LDS-DMA of the NEXT 64 KiB chunk: 1.4 k cycles for 6 MFMAs (profiles/r03_avatar_time_split.md).
 constexpr int split_first_ks(int ks0, int ks1) { return ks1 > 0 ? (ks0 + ks1 + 1) / 2 : ks0; }
 constexpr int first_chunk_bytes(int ks0, int ks1) { return chunk_bytes(split_first_ks(ks0, ks1), 2); }
-template <int NT, int KS0, int KS1, int ACT, int NEXT_BYTES, class In0, class In1, class Bias, class Pre>
+struct NoPairPatch { template <class P, class T> __device__ __forceinline__ half8 operator()(P, T, half8 a) const { return a; } };
+template <int NT, int KS0, int KS1, int ACT, int NEXT_BYTES, class In0, class In1, class Bias, class Pre, class PP = NoPairPatch>
 __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
                                       Frag *__restrict__ out, Bias &bias, int h,
-                                      Pre &&pre, f32x16 *__restrict__ pend, const float *jump = nullptr, unsigned jump_lane = 0)
+                                      Pre &&pre, f32x16 *__restrict__ pend, const float *jump = nullptr, unsigned jump_lane = 0, PP &&ppatch = PP{})
 {
+    // `ppatch(pair, tile, a_hi)`: A-fragment patch of the FIRST k-step of the second segment (see chunk())
     // `jump`: where the bias blocks continue after this layer's last pair, when not at the following block of the table (column-folded
     // launches take conv1's and conv5's blocks from the per-column table and everything else from the layer table)
     constexpr int NPAIR = NT / 2;
@@ -657,7 +669,11 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
             constexpr int afterB = p + 1 < NPAIR ? BA : NEXT_BYTES;
             const CatIn<KA, KS0 - KA, In0, In1> tail{in0, in1};
             chunk<KB, 2, afterB>(s, tail, acc, [&](auto kc, auto rc) {
-                if constexpr (p > 0) epi_part<ACT, NS, KA + decltype(kc)::value, decltype(rc)::value>(prev, out + 4 * (p - 1), est, s.range);
+                if constexpr (p == 0) pre(std::integral_constant<int, KA + decltype(kc)::value>{}, rc);
+                else epi_part<ACT, NS, KA + decltype(kc)::value, decltype(rc)::value>(prev, out + 4 * (p - 1), est, s.range);
+            }, [&](auto qc, auto tc, half8 a) {
+                if constexpr (decltype(qc)::value == KS0 - KA) return ppatch(pc, tc, a);
+                else return a;
             });
         }
         prev[0] = acc[0]; prev[1] = acc[1];
@@ -1059,7 +1075,7 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             }
             dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                        // conv6
             dense<8, 16, 0, ACT_SOFTPLUS, B_HEAD16>(s, RY, RY, X, bias, h, SP{pb, Y + 12, &s.range}, pa);                      // conv7
-            const f32x16 o = head<16, B_PE8, false>(s, X, bias, bias_head, h, SP{pa, X + 12, &s.range});                                 // out_layer_coord_affine
+            const f32x16 o = head<16, COLOUR ? B_PE : B_PE8, false>(s, X, bias, bias_head, h, SP{pa, X + 12, &s.range});                                 // out_layer_coord_affine
             // rows 0..2 live in lanes h == 0, regs 0..2: broadcast to the other half
             off[0] = __shfl(o[0], j, 64); off[1] = __shfl(o[1], j, 64); off[2] = __shfl(o[2], j, 64);
             q[0] = pt[0] + off[0]; q[1] = pt[1] + off[1]; q[2] = pt[2] + off[2];                                       // arch_avatar.py:372 (fp32 add)
@@ -1069,7 +1085,8 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
 #if AVC_DBG_TIMING
         const long long tp1 = clock64();
 #endif
-        wide_bias_early(bias, w8);                                                                                              // shared.0's blocks, tiles 2 .. 7
+        constexpr bool WIDE0 = !(WARP && COLOUR);      // (the warped colour kernel sits at the register limit: it keeps shared.0 as four chunks of a tile pair)
+        if constexpr (WIDE0) wide_bias_early(bias, w8);                                                                         // shared.0's blocks, tiles 2 .. 7
         posenc(q, h, park, s.range);                                                                                            // :70 (parked in LDS)
         const ParkIn P{park, nullptr};
         const RegIn TX{X}, TY{Y};
@@ -1077,9 +1094,14 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         s.t_pro += clock64() - tp1;
 #endif
         using RP = Pending<ACT_RELU, 8>;
-        wide8<layout::PE_KS, B_MAIN>(s, P, w8, bias, h);                                                                 // shared 0
-        flush<ACT_RELU>(w8, X, s.range);
-        dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, PendWide<ACT_RELU>{w8, X, &s.range}, pb);               // shared 1 (+ shared 0's pairs 1 .. 3)
+        if constexpr (WIDE0) {
+            wide8<layout::PE_KS, B_MAIN>(s, P, w8, bias, h);                                                             // shared 0
+            flush<ACT_RELU>(w8, X, s.range);
+            dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, PendWide<ACT_RELU>{w8, X, &s.range}, pb);           // shared 1 (+ shared 0's pairs 1 .. 3)
+        } else {
+            dense<8, layout::PE_KS, 0, ACT_RELU, B_MAIN>(s, P, P, X, bias, h, NoSide{}, pa);                             // shared 0
+            dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TX, TX, Y, bias, h, RP{pa, X + 12, &s.range}, pb);                      // shared 1
+        }
         dense<8, 16, 0, ACT_RELU, B_MAIN>(s, TY, TY, X, bias, h, RP{pb, Y + 12, &s.range}, pa);
         dense<8, 16, 0, ACT_RELU, B_SHARED4>(s, TX, TX, Y, bias, h, RP{pa, X + 12, &s.range}, pb);
         dense<8, 16, layout::PE_KS, ACT_RELU, B_MAIN>(s, TY, P, X, bias, h, RP{pb, Y + 12, &s.range}, pa);                     // shared 4 on [x|x0]
@@ -1194,6 +1216,227 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
     s.range.report(p);
     if (p.clk && blockIdx.x == 0 && threadIdx.x == 0) { p.clk[0] = tk0; p.clk[1] = clock64(); }
 }
+
+// ---- column folding of the recon query on a grid ------------------------------------------------------------------------------------------
+// The decoder's input is [img_feat(32) at (x, y) | z] (arch_recon.py:63-70) and enters fc0, fc1 and fc2 (res_layers, mlp.py:61): on a grid the 32
+// feature channels are one vector per (x, y) column, so what the three layers do with them -- W[:, feat] f(x, y) + b, 896 = 512 + 256 + 128 rows --
+// is computed once per column in fp32 (recon_column_terms_kernel) and enters as the accumulator init; only the z column stays a k-step.
+// 1,068 instead of 1,236 MFMAs per 32 points, no per-point gather, and fc0 -- three k-steps for 512 outputs, epilogue-bound in the point-by-point
+// kernel -- becomes two wide chunks whose epilogues hide in fc1's chunks.  Same algebra as the reference, other rounding: ~1e-6 from recon_kernel<0>.
+constexpr int RCOL = 896;                         // floats per column: [fc0 rows 0..511 | fc1 | fc2], biases included
+__global__ __launch_bounds__(256) void recon_column_terms_kernel(const float *__restrict__ feat, int H, int W, const float *__restrict__ gx,
+                                                                 const float *__restrict__ gy, int nx, int ny, float cx, float cy,
+                                                                 const float *__restrict__ colw, float *__restrict__ out)
+{
+    // colw: [896][32] fp32 weights of the feature columns, then [896] biases
+    constexpr int CPB = 8;                        // columns per trip
+    __shared__ __attribute__((aligned(16))) float f[CPB][32];
+    const int o = threadIdx.x;
+    float w[4][32], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = o + 256 * r;
+        b[r] = row < RCOL ? colw[RCOL * 32 + row] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+            const f32x4 a = row < RCOL ? *reinterpret_cast<const f32x4 *>(colw + (size_t)row * 32 + c) : f32x4{0, 0, 0, 0};
+            w[r][c] = a[0]; w[r][c + 1] = a[1]; w[r][c + 2] = a[2]; w[r][c + 3] = a[3];
+        }
+    }
+    const int ncol = nx * ny;
+    for (int c0 = blockIdx.x * CPB; c0 < ncol; c0 += gridDim.x * CPB) {
+        {   // the bilinear sample of arch_recon.py:63-68 as recon_kernel<0> takes it: thread = (column, channel)
+            const int q = threadIdx.x >> 5, ch = threadIdx.x & 31, col = min(c0 + q, ncol - 1);
+            const Bilinear bl = bilinear_setup<32>(feat, H, W, gx[col / ny] - cx, -(gy[col % ny] - cy), 0);
+            f[q][ch] = bl.p00[ch] * bl.w00 + bl.p01[ch] * bl.w01 + bl.p10[ch] * bl.w10 + bl.p11[ch] * bl.w11;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CPB; ++q) {
+            if (c0 + q >= ncol) break;
+            float a[4] = {b[0], b[1], b[2], b[3]};
+#pragma unroll
+            for (int c = 0; c < 32; c += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(&f[q][c]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = __builtin_fmaf(w[r][c + i], v[i], a[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (o + 256 * r < RCOL) out[(size_t)(c0 + q) * RCOL + o + 256 * r] = a[r];
+        }
+        __syncthreads();
+    }
+}
+
+// accumulator inits out of registers, in consumption order (a BiasQueue whose blocks were all loaded ahead)
+struct BiasRegs {
+    const f32x16 *cur;
+    __device__ __forceinline__ void take(f32x16 *acc, int ntiles, int)
+    {
+        acc[0] = cur[0];
+        if (ntiles > 1) acc[1] = cur[1];
+        cur += ntiles;
+    }
+    __device__ __forceinline__ void after_barrier(int) {}
+    __device__ __forceinline__ void rewind(const float *, unsigned = 0) {}
+};
+
+template <class F>
+struct BiasRegsThen {                // BiasRegs whose after-the-barrier slot runs `then` (requests that must not sit in front of the chunk's vmcnt(0))
+    const f32x16 *cur;
+    F then;
+    __device__ __forceinline__ void take(f32x16 *acc, int ntiles, int) { acc[0] = cur[0]; if (ntiles > 1) acc[1] = cur[1]; cur += ntiles; }
+    __device__ __forceinline__ void after_barrier(int) { then(); }
+    __device__ __forceinline__ void rewind(const float *, unsigned = 0) {}
+};
+
+constexpr int B_Z8 = chunk_bytes(1, 8), B_ZZ8 = chunk_bytes(2, 8), B_FC2F = first_chunk_bytes(16, 1);
+
+// FOLD: 1 = dense grid whose tiles lie in one (x, y) column each; 2 = subset of the grid by flat indices (p.gidx), column blocks gathered per lane
+#if !AVC_CHECK_RANGE
+template <int FOLD>
+__global__ __launch_bounds__(256, 1) void recon_fold_kernel(const QueryParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const long long tk0 = clock64();
+    Stream s = stream_init(p, wave, lane, B_Z8);
+    const unsigned tiles_per_col = FOLD == 1 ? p.grz / TILE_PTS : 1u;
+    // How a column term reaches the accumulators: every layer that takes one also has the z k-step, whose input fragment uses ONE of its 16 K slots.
+    // The term c of (row, column) is split into fp16 halves (c_hi, c_lo) and put into K slots 2 and 3 of the `hi` A fragment of that k-step -- the second
+    // dword of the lane's four -- against 1.0 in slots 2 and 3 of the B operand: the (hi, hi) MFMA of the z k-step adds c_hi + c_lo = c (to 2^-22) for free.
+    // Accumulators start at zero, and what a lane fetches per 32-row tile is ONE float (row j of the tile: 256 bytes per wave-instruction) instead of the
+    // sixteen of an accumulator-init block (round-3 first cut: 4 x dwordx4 per tile, 1 KiB per instruction through the texture path whatever the
+    // duplication -- 2 k cycles per eight tiles, profiles/r03_recon_time_split.md).
+    float pt_next[3];
+    unsigned col_next = 0;
+    auto col_rsrc = [&](int64_t t) { return bias_rsrc(FOLD == 1 ? p.colterms + (size_t)(t / tiles_per_col) * RCOL : p.colterms); };
+    static_assert(FOLD == 1, "column terms ride the z k-step: one column per tile");
+    auto col_voff = [&](unsigned) { return 4u * j; };
+    auto fetch8 = [&](float *dst, const i32x4 &rs, unsigned voff, int first_row, int ntiles) {          // row j of `ntiles` consecutive tiles
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < ntiles) dst[t] = raw_buffer_load_f32(rs, (int)voff + 4 * (first_row + 32 * t), 0, 0);
+    };
+    auto split8p = [&](const float *c, unsigned *pd, int ntiles) {                                        // -> packed (c_hi | c_lo << 16)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < ntiles) {
+                const _Float16 hi = (_Float16)c[t], lo = (_Float16)(c[t] - (float)hi);
+                const half2_t hv = {hi, lo};
+                pd[t] = __builtin_bit_cast(unsigned, hv);
+            }
+    };
+    float cn[8];                          // fc0 rows 0..255 of the NEXT tile, requested behind the fc3 head of the current one
+    {
+        const int64_t i0 = (int64_t)blockIdx.x * TILE_PTS + wave * 32 + j;
+        col_next = load_point(p, i0 < p.n ? i0 : p.n - 1, pt_next);
+        fetch8(cn, col_rsrc(blockIdx.x), col_voff(col_next), 0, 8);
+    }
+
+    for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int64_t pidx_raw = tile * TILE_PTS + wave * 32 + j;
+#if AVC_DBG_TIMING >= 2
+        const long long tp0 = clock64();
+        if (tile + gridDim.x >= p.ntiles) {                 // as in avatar_kernel: stamps of the workgroup's last tile, behind the head of the OUTPUT buffer
+            s.stamp = reinterpret_cast<long long *>(p.out0) + 8192 + (size_t)(blockIdx.x * 4 + wave) * 256;
+            s.nstamp = 0;
+            stamp3(s, tp0, tp0, tp0);
+        }
+#endif
+        float pt[3] = {pt_next[0], pt_next[1], pt_next[2]};
+        const unsigned col = col_next;
+        const int64_t tile_n = tile + gridDim.x < p.ntiles ? tile + gridDim.x : tile;           // the tile this workgroup runs next (itself: the last one)
+        {
+            const int64_t in = tile_n * TILE_PTS + wave * 32 + j;
+            col_next = load_point(p, in < p.n ? in : p.n - 1, pt_next);
+        }
+        const float *cb = FOLD == 1 ? p.colterms + (size_t)(tile / tiles_per_col) * RCOL : p.colterms;
+        asm volatile("" : "+s"(cb));
+        const i32x4 crs = bias_rsrc(cb);
+        const unsigned voff = col_voff(col);
+        unsigned pd0[8], pdz[16], pd2[4];  // patches: fc0 rows 0..255 | [fc0 rows 256..511, fc1] | fc2
+        float cz[16], c2f[4];
+        split8p(cn, pd0, 8);
+        Frag Z;                            // the z k-step's B fragment: z in slot 0, 1.0 in slots 2 and 3 (lanes h == 0 hold slots 0..7)
+        {
+            float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (h == 0) { z[0] = pt[2] - p.cz; z[2] = 1.0f; z[3] = 1.0f; }                       // arch_recon.py:62,69
+            split8(z, Z.hi, Z.lo, s.range);
+        }
+        const SameIn RZ{&Z};
+        auto patched = [](half8 a, unsigned d) { u32x4 v = __builtin_bit_cast(u32x4, a); v[1] = d; return __builtin_bit_cast(half8, v); };
+        Frag X[16], Y[16];
+        using LP = Pending<ACT_LEAKY, 16>;
+        f32x16 acc16[16];                  // [0..7]: the 256-row half of fc0 in flight; [8..15]: fc1's accumulators
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc16[t][r] = 0.0f;
+        // fc0 rows 0..255: z column + column term, all eight tiles in one chunk
+        chunk<1, 8, B_WIDE4>(s, RZ, acc16, [&](auto qc, auto rc) {
+            if constexpr (decltype(qc)::value == 0 && decltype(rc)::value == 5) { fetch8(cz, crs, voff, 256, 8); fetch8(cz + 8, crs, voff, 512, 8); }
+        }, [&](auto qc, auto tc, half8 a) { return patched(a, pd0[2 * decltype(qc)::value + decltype(tc)::value]); });
+        flush<ACT_LEAKY>(acc16, X, s.range);
+        // fc1 over x[0..255]: chunk c consumes the fragments of fc0's pair c and finishes pair c + 1 in its shadow
+        chunk<4, 8, B_WIDE4>(s, RegIn{X}, acc16 + 8, LP{acc16 + 2, X + 4, &s.range});
+        chunk<4, 8, B_WIDE4>(s, RegIn{X + 4}, acc16 + 8, LP{acc16 + 4, X + 8, &s.range});
+        chunk<4, 8, B_WIDE4>(s, RegIn{X + 8}, acc16 + 8, LP{acc16 + 6, X + 12, &s.range});
+        chunk<4, 8, B_ZZ8>(s, RegIn{X + 12}, acc16 + 8, NoSide{});
+        split8p(cz, pdz, 8); split8p(cz + 8, pdz + 8, 8);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc16[t][r] = 0.0f;
+        // [fc0 rows 256..511 | fc1's z column]: two k-steps on the same B operand, two sets of accumulators, each with its column term
+        chunk<2, 8, B_WIDE4, 8>(s, RZ, acc16, [&](auto qc, auto rc) {
+            if constexpr (decltype(qc)::value == 0 && decltype(rc)::value == 5) fetch8(c2f, crs, voff, 768, 4);
+        }, [&](auto qc, auto tc, half8 a) { return patched(a, pdz[2 * decltype(qc)::value + decltype(tc)::value]); });
+        flush<ACT_LEAKY>(acc16, X, s.range);
+        chunk<4, 8, B_WIDE4>(s, RegIn{X}, acc16 + 8, LP{acc16 + 2, X + 4, &s.range});
+        chunk<4, 8, B_WIDE4>(s, RegIn{X + 4}, acc16 + 8, LP{acc16 + 4, X + 8, &s.range});
+        chunk<4, 8, B_WIDE4>(s, RegIn{X + 8}, acc16 + 8, LP{acc16 + 6, X + 12, &s.range});
+        f32x16 b3;                         // fc3's bias tile (layer table), requested a chunk ahead
+        chunk<4, 8, B_FC2F>(s, RegIn{X + 12}, acc16 + 8, [&](auto qc, auto rc) {
+            if constexpr (decltype(qc)::value == 0 && decltype(rc)::value == 5)
+                b3 = bias_tile_buf(bias_rsrc(p.bias), 16u * h, 4 * (5 * 256 + 128));              // fc3's block of the layer table (pack.cpp: pack_recon)
+        });
+        split8p(c2f, pd2, 4);
+        // fc1's eight tiles -> Y: pair 0 now, pairs 1..3 inside fc2
+        flush<ACT_LEAKY>(acc16 + 8, Y, s.range);
+        f32x16 zero2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero2[t][r] = 0.0f;
+        BiasRegs bias{zero2};
+        f32x16 pend[2];
+        dense<4, 16, 1, ACT_LEAKY, B_HEAD8>(s, RegIn{Y}, RZ, X, bias, h, PendWide<ACT_LEAKY>{acc16 + 8, Y, &s.range}, pend, nullptr, 0,
+                                            [&](auto pc, auto tc, half8 a) { return patched(a, pd2[2 * decltype(pc)::value + decltype(tc)::value]); });      // fc2 on [x(256) | z]
+        // the next tile's first column terms: requested right after the head's barrier, in flight during the fc3 head, the output store and the loop's turn-around
+        auto prefetch_next = [&]() { fetch8(cn, col_rsrc(tile_n), col_voff(col_next), 0, 8); };
+        BiasRegsThen<decltype(prefetch_next)> hbias{&b3, prefetch_next};
+        const f32x16 o = head<8, B_Z8, true>(s, X, hbias, p.bias, h, Pending<ACT_LEAKY, 4>{pend, X + 4, &s.range});
+        if (h == 0 && pidx_raw < p.n) p.out0[pidx_raw] = sigmoid_f(o[0]);                                                          // last_op sigmoid
+    }
+    s.range.report(p);
+    if (p.clk && blockIdx.x == 0 && threadIdx.x == 0) { p.clk[0] = tk0; p.clk[1] = clock64(); }
+#if AVC_DBG_TIMING >= 2
+    {
+        const long long tend = clock64();
+        stamp3(s, tend, tend, (long long)s.nstamp);
+        if (lane == 0) {
+            long long *dbg = reinterpret_cast<long long *>(p.out0) + 4 * (blockIdx.x * 4 + wave);
+            dbg[0] = tend - tk0; dbg[1] = s.t_bar; dbg[2] = s.t_drain; dbg[3] = s.t_pro;
+        }
+    }
+#endif
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // launchers
@@ -1334,7 +1577,13 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
 
 int launch_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], float *out, hipStream_t s)
 {
-    PackedNet &net = ctx->recon;
+    // a dense grid launch is column-folded (recon_fold_kernel) when its tiles lie in one (x, y) column each; everything else runs recon_kernel
+#if AVC_CHECK_RANGE
+    const int fold = 0;                    // the range-checked flavour keeps to the point-by-point kernel
+#else
+    const int fold = grid && !grid->idx && grid->res[2] % TILE_PTS == 0 && ctx->recon_fold.ready && ctx->opt.column_fold ? 1 : 0;
+#endif
+    PackedNet &net = fold ? ctx->recon_fold : ctx->recon;
     AVC_REQUIRE(net.ready, AVC_ERR_STATE, "recon query: weights not packed (call avc_pack_recon_weights)");
     AVC_REQUIRE(ctx->img_feat_hwc, AVC_ERR_STATE, "recon query: image feature map not set");
     if (n == 0) return AVC_OK;
@@ -1348,13 +1597,36 @@ int launch_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n
     p.out0 = out;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;
     const int grid_dim = (int)std::min<int64_t>(p.ntiles, ctx->opt.mlp_blocks > 0 ? ctx->opt.mlp_blocks : ctx->num_cus);
-    rc = set_lds(recon_kernel);
-    if (rc) return rc;
     rc = range_begin(ctx, s);
     if (rc) return rc;
+    if (fold) {
+        const size_t ncol = (size_t)grid->res[0] * grid->res[1], bytes = (ncol * RCOL + 64) * sizeof(float);
+        AVC_REQUIRE(ncol * RCOL * sizeof(float) < ((size_t)1 << 32) - 4096, AVC_ERR_ARG, "recon query: %zu columns exceed the 4 GiB column table of a folded launch", ncol);
+        if (ctx->rcol_scratch_bytes < bytes) {
+            if (ctx->rcol_scratch) AVC_HIP(hipFree(ctx->rcol_scratch));
+            ctx->rcol_scratch = nullptr; ctx->rcol_scratch_bytes = 0;
+            AVC_HIP(hipMalloc(&ctx->rcol_scratch, bytes));
+            ctx->rcol_scratch_bytes = bytes;
+        }
+        p.colterms = static_cast<const float *>(ctx->rcol_scratch);
+    }
     hipEvent_t e0, e1;
-    timing_begin(ctx, 1, s, e0, e1, p);
-    hipLaunchKernelGGL(recon_kernel, dim3(grid_dim), dim3(256), LDS_BYTES, s, p);
+    timing_begin(ctx, 1, s, e0, e1, p);        // (a folded launch is timed with its column pass)
+#if !AVC_CHECK_RANGE
+    if (fold) {
+        const int ncol = grid->res[0] * grid->res[1];
+        hipLaunchKernelGGL(recon_column_terms_kernel, dim3(std::min((ncol + 7) / 8, ctx->num_cus * 4)), dim3(256), 0, s, p.feat, p.H, p.W, p.gx, p.gy,
+                           (int)grid->res[0], (int)grid->res[1], p.cx, p.cy, (const float *)net.d_colw, static_cast<float *>(ctx->rcol_scratch));
+        rc = set_lds(recon_fold_kernel<1>);
+        if (rc) return rc;
+        hipLaunchKernelGGL(recon_fold_kernel<1>, dim3(grid_dim), dim3(256), LDS_BYTES, s, p);
+    } else
+#endif
+    {
+        rc = set_lds(recon_kernel);
+        if (rc) return rc;
+        hipLaunchKernelGGL(recon_kernel, dim3(grid_dim), dim3(256), LDS_BYTES, s, p);
+    }
     AVC_HIP(hipGetLastError());
     timing_end(ctx, 1, s, e0, e1);
     return range_end(ctx, s, "recon query");

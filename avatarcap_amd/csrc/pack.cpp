@@ -97,6 +97,10 @@ Seg seg_pe(int col_offset = 0)
 {
     return Seg{layout::PE_KS, [col_offset](int s) { int c = layout::pe_column(s); return c < 0 ? -1 : col_offset + c; }};
 }
+Seg seg_z33(int col_offset = 0)       // the z k-step of the 33-wide input alone (column-folded recon stream)
+{
+    return Seg{1, [col_offset](int s) { int c = layout::in33_column(2 * 16 + s); return c < 0 ? -1 : col_offset + c; }};
+}
 Seg seg_in33(int col_offset = 0)
 {
     return Seg{layout::IN33_KS, [col_offset](int s) { int c = layout::in33_column(s); return c < 0 ? -1 : col_offset + c; }};
@@ -192,9 +196,9 @@ static void add_warp(Builder &B, const avc_ctx::Staged &w, bool fold = false)
 // `colour` streams keep shared.6 (its output feeds both heads).  Geometry-only streams fold shared.6
 // (linear, no activation: mlp.py:46,64) into geo.0:  W_g0 (W_6 x + b_6) + b_g0 = (W_g0 W_6) x + (W_g0 b_6 + b_g0),
 // an exact identity that removes 65,536 of the 886,784 MAC per point (and one epilogue).
-static void add_template(Builder &B, const avc_ctx::Staged &t, bool colour)
+static void add_template(Builder &B, const avc_ctx::Staged &t, bool colour, bool warp)
 {
-    B.layer(t.W[0], t.b[0], 256, 63, {seg_pe()}, 8, 16);                         // shared 0: one wide chunk (k-major over all eight tiles)
+    B.layer(t.W[0], t.b[0], 256, 63, {seg_pe()}, warp && colour ? 2 : 8, 16);    // shared 0: one wide chunk (k-major over all eight tiles); the warped colour kernel keeps tile pairs
     for (int i = 1; i <= 3; ++i) B.layer(t.W[i], t.b[i], 256, 256, {seg_d(16)}, 2, 16);
     B.layer(t.W[4], t.b[4], 256, 319, {seg_d(16), seg_pe(256)}, 2, 16);          // shared 4: cat([x, x0]) (mlp.py:61)
     B.layer(t.W[5], t.b[5], 256, 256, {seg_d(16)}, 2, 16);
@@ -228,7 +232,7 @@ int pack_avatar(avc_ctx *ctx)
     auto build = [&](PackedNet &net, bool warp, bool colour, bool fold = false) -> int {
         Builder B(net);
         if (warp) add_warp(B, ctx->warp_st, fold);
-        add_template(B, ctx->tmpl_st, colour);
+        add_template(B, ctx->tmpl_st, colour, warp);
         AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
         net.has_colour = colour;
         return upload(net);
@@ -276,7 +280,30 @@ int pack_recon(avc_ctx *ctx, const avc_dense fc[4])
     B.layer(W[2], b[2], 128, 289, {seg_d(16), seg_in33(256)}, 2, 16);    // fc2: [x(256) | in(33)]
     B.layer(W[3], b[3], 1, 128, {seg_d(8)}, 1, 16);                      // fc3
     AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "recon weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
-    return upload(ctx->recon);
+    if (int rc = upload(ctx->recon)) return rc;
+
+    // The stream of recon_fold_kernel (grid launches): the 32 image-feature columns of fc0 / fc1 / fc2 leave the stream -- their fp32 weights go to
+    // colw, [fc0 (512) | fc1 (256) | fc2 (128)] rows x 32 columns, followed by the 896 biases, for recon_column_terms_kernel -- and only the z column
+    // stays a k-step.  Consumption order: fc0 rows 0..255 (8 tiles, one chunk); fc1 over x[0..255]; [fc0 rows 256..511 | fc1's z column] (one chunk of
+    // two k-steps); fc1 over x[256..511]; fc2 on [x | z]; fc3.  The layer-table bias blocks are unused except fc3's (offset 5 * 256 + 128).
+    Builder F(ctx->recon_fold);
+    F.layer(Wa, ba, 256, 33, {seg_z33()}, 8, 16);
+    F.layer(W[1], b[1], 256, 545, {seg_d(16, 0)}, 8, 4);
+    F.layer(Wb, bb, 256, 33, {seg_z33()}, 8, 16);
+    F.layer(W[1], zero256, 256, 545, {seg_z33(512)}, 8, 16);
+    F.layer(W[1], zero256, 256, 545, {seg_d(16, 256)}, 8, 4);
+    F.layer(W[2], b[2], 128, 289, {seg_d(16), seg_z33(256)}, 2, 16);
+    F.layer(W[3], b[3], 1, 128, {seg_d(8)}, 1, 16);
+    AVC_REQUIRE(!F.overflow, AVC_ERR_ARG, "recon weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
+    auto &cw = ctx->recon_fold.colw;
+    cw.assign((size_t)896 * 32 + 896, 0.0f);
+    const int row0[3] = {0, 512, 768}, nrow[3] = {512, 256, 128}, featc0[3] = {0, 512, 256};      // where [feat(32) | z] sits among each layer's input columns
+    for (int l = 0; l < 3; ++l)
+        for (int o = 0; o < nrow[l]; ++o) {
+            for (int c = 0; c < 32; ++c) cw[(size_t)(row0[l] + o) * 32 + c] = (float)W[l][(size_t)o * cin[l] + featc0[l] + c];
+            cw[(size_t)896 * 32 + row0[l] + o] = (float)b[l][o];
+        }
+    return upload(ctx->recon_fold);
 }
 
 }  // namespace avc

@@ -46,6 +46,21 @@ __device__ __forceinline__ void load_tri(const float *__restrict__ verts, const 
     }
 }
 
+// A sliver can win a pixel through the 1/256-pixel snap of its corners while its UNSNAPPED area is ~0 or of the other sign: the barycentric
+// weights e_k / (e0 + e1 + e2) then leave [0, 1] by far, or are inf / NaN, and would extrapolate the attribute (normals that feed the fusion).
+// Such weights -- any outside [-0.5, 1.5], or not finite -- are clamped to [0, 1] and renormalised (equal thirds if nothing is left); every
+// other triangle, including the ordinary near-edge pixel whose weights overshoot by a sub-pixel's worth, is left exactly as it was.
+__device__ __forceinline__ void bary_guard(double *e0, double *e1, double *e2)
+{
+    const double ar = (*e0 + *e1) + *e2;
+    const double l0 = *e0 / ar, l1 = *e1 / ar, l2 = *e2 / ar;
+    if (l0 >= -0.5 && l0 <= 1.5 && l1 >= -0.5 && l1 <= 1.5 && l2 >= -0.5 && l2 <= 1.5) return;
+    double c0 = l0 > 0.0 ? (l0 < 1.0 ? l0 : 1.0) : 0.0, c1 = l1 > 0.0 ? (l1 < 1.0 ? l1 : 1.0) : 0.0, c2 = l2 > 0.0 ? (l2 < 1.0 ? l2 : 1.0) : 0.0;
+    double sum = (c0 + c1) + c2;
+    if (!(sum > 0.0)) { c0 = c1 = c2 = 1.0; sum = 3.0; }
+    *e0 = c0 / sum; *e1 = c1 / sum; *e2 = c2 / sum;
+}
+
 __global__ __launch_bounds__(256) void raster_depth_kernel(const float *__restrict__ verts, const int32_t *__restrict__ faces, long long nf,
                                                            float cx, float cy, float cz, int size, unsigned long long *__restrict__ keys)
 {
@@ -116,8 +131,10 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const float *__rest
     const double e0 = (wx[2] - wx[1]) * (qy - wy[1]) - (wy[2] - wy[1]) * (qx - wx[1]);
     const double e1 = (wx[0] - wx[2]) * (qy - wy[2]) - (wy[0] - wy[2]) * (qx - wx[2]);
     const double e2 = (wx[1] - wx[0]) * (qy - wy[0]) - (wy[1] - wy[0]) * (qx - wx[0]);
-    const double ar = (e0 + e1) + e2;
-    const double l0 = e0 / ar, l1 = e1 / ar, l2 = e2 / ar;
+    double g0 = e0, g1 = e1, g2 = e2;
+    bary_guard(&g0, &g1, &g2);                          // slivers only (oracle/raster_oracle.c)
+    const double ar = (g0 + g1) + g2;
+    const double l0 = g0 / ar, l1 = g1 / ar, l2 = g2 / ar;
     const float *A = attrs + 3 * (long long)faces[3 * t + 0], *B = attrs + 3 * (long long)faces[3 * t + 1], *C = attrs + 3 * (long long)faces[3 * t + 2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) out[k] = (float)((l0 * (double)A[k] + l1 * (double)B[k]) + l2 * (double)C[k]);
@@ -214,7 +231,9 @@ __global__ __launch_bounds__(256) void raster_mvp_resolve_kernel(const float *__
     const double e0 = (wx[2] - wx[1]) * (qy - wy[1]) - (wy[2] - wy[1]) * (qx - wx[1]);
     const double e1 = (wx[0] - wx[2]) * (qy - wy[2]) - (wy[0] - wy[2]) * (qx - wx[2]);
     const double e2 = (wx[1] - wx[0]) * (qy - wy[0]) - (wy[1] - wy[0]) * (qx - wx[0]);
-    const double u0 = e0 * iw[0], u1 = e1 * iw[1], u2 = e2 * iw[2];
+    double g0 = e0, g1 = e1, g2 = e2;
+    bary_guard(&g0, &g1, &g2);
+    const double u0 = g0 * iw[0], u1 = g1 * iw[1], u2 = g2 * iw[2];
     const double den = (u0 + u1) + u2;
     const float *A = attrs + 3 * (long long)faces[3 * t + 0], *B = attrs + 3 * (long long)faces[3 * t + 1], *C = attrs + 3 * (long long)faces[3 * t + 2];
     float r[3];

@@ -41,6 +41,40 @@ class ReconNetwork(nn.Module):
         _lib.apply_range_check(ctx)
         return ctx
 
+    def infer_grid(self, items, axes, res, index=None):
+        """`infer` for items['cano_pts'] that ARE the points of the canonical grid (`axes` = grid.volume_axes(bounds, res), order of
+        generate_volume_points) or the subset of it given by the flat indices `index` (int32, device; the valid band in the order of
+        dataset.infer_pts): the coordinates are generated in the kernel; a dense grid whose last axis is a multiple of 128 points is column-folded
+        (include/avcap.h avc_recon_query_grid: ~1e-6 from `infer` on the same points), everything else is bit-identical to `infer`.  -> (1,N)"""
+        with torch.no_grad():
+            imgs = torch.cat([items['front_normal'], items['back_normal']], dim=1)
+            img_feat_map = self.get_feat_maps(imgs)[-1].contiguous()
+            return self.decode_grid(axes, res, img_feat_map, items['cano_smpl_center'], index)
+
+    def decode_grid(self, axes, res, img_feat_map, center, index=None):
+        import ctypes as C
+        res = [int(r) for r in res]
+        dev = axes[0].device
+        if img_feat_map.shape[0] != 1:
+            raise ValueError('decode_grid: one frame at a time (B == 1)')
+        N = res[0] * res[1] * res[2] if index is None else int(index.numel())
+        for a, r in zip(axes, res):
+            if a.numel() != r:
+                raise ValueError(f'decode_grid: axis table of {a.numel()} entries for a resolution of {r}')
+        ctx = self._ctx(dev)
+        out = torch.empty((1, N), dtype=torch.float32, device=dev)
+        m = img_feat_map[0]
+        _lib.check(_lib.lib().avc_set_img_feat_map(ctx, _lib.dev_ptr(m, name='img_feat_map'), m.shape[0], m.shape[1], m.shape[2], _lib.stream_ptr(dev)))
+        ax = (_lib.dev_ptr(axes[0], name='axis_x'), _lib.dev_ptr(axes[1], name='axis_y'), _lib.dev_ptr(axes[2], name='axis_z'))
+        if index is None:
+            _lib.check(_lib.lib().avc_recon_query_grid(ctx, *ax, (C.c_int32 * 3)(*res), _lib.f3(center[0]), out.data_ptr(), _lib.stream_ptr(dev)))
+        else:
+            if index.dtype != torch.int32 or not index.is_contiguous() or index.device != dev:
+                raise TypeError('decode_grid: index must be a contiguous int32 tensor on the device of the axis tables')
+            _lib.check(_lib.lib().avc_recon_query_grid_subset(ctx, *ax, (C.c_int32 * 3)(*res), index.data_ptr(), N, _lib.f3(center[0]),
+                                                              out.data_ptr(), _lib.stream_ptr(dev)))
+        return out
+
     def infer(self, items):
         """items['cano_pts'] (1,N,3), ['cano_smpl_center'] (1,3), ['front_normal'], ['back_normal'] (1,3,512,512)
         -> (1,N) occupancy in [0,1]   (arch_recon.py:45-76)."""

@@ -100,3 +100,82 @@ def all_gather_meshes(meshes: list[dict], n_frames: int, group=None, force: bool
             out[f] = {'v': vn[:, :3], 'vn': vn[:, 3:], 'f': all_f[r][fo:fo + 3 * Fn].reshape(Fn, 3)}
             vo += 6 * V; fo += 3 * Fn
     return out
+
+
+# ---- the sharded frame loop of `-m test` and the process plumbing around it -------------------------------------------------------------
+def free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def self_launch(script: str, argv: list[str], n_ranks: int) -> int:
+    """`python <script> --gpus N ...` with N > 1 and no launcher around it: start N ranks of the script, one per GPU, under
+    torch.distributed.run on 127.0.0.1 and return its exit status (rank 0's stdout passes through)."""
+    import os
+    import subprocess
+    import sys
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_ranks}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(script)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
+def init_process_group(backend: str, rank: int, world: int, device=None, timeout_s: float = 120.0):
+    """torch.distributed.init_process_group with a BOUNDED rendezvous and bounded collectives: a rank that never shows up (a GPU that failed to
+    come up, a wrong WORLD_SIZE) ends the job with a message and a non-zero status after `timeout_s` instead of hanging it."""
+    import datetime
+    import os
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    kw = {'device_id': device} if (backend == 'nccl' and device is not None) else {}
+    try:
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+    except Exception as e:      # noqa: BLE001 -- DistNetworkError / DistStoreError / RuntimeError depending on where the rendezvous gave up
+        raise SystemExit(f'rank {rank}: rendezvous of {world} ranks at {os.environ["MASTER_ADDR"]}:{os.environ["MASTER_PORT"]} failed within '
+                         f'{timeout_s:.0f} s ({type(e).__name__}: {e})')
+    got = dist.get_world_size()
+    if got != world:
+        raise SystemExit(f'rank {rank}: the process group has {got} ranks, {world} were asked for')
+
+
+def barrier_or_die(what: str, rank: int, timeout_s: float = 120.0, group=None):
+    """dist.barrier() that turns a peer's absence into an error message: under nccl the watchdog aborts the process after the group's timeout;
+    under gloo the call raises.  Either way the job ends non-zero instead of hanging."""
+    try:
+        dist.barrier(group=group)
+    except Exception as e:      # noqa: BLE001
+        raise SystemExit(f'rank {rank}: barrier "{what}" failed ({type(e).__name__}: {e}) -- a peer rank is gone or stuck')
+
+
+def run_sharded(frames: list, process, rank: int = 0, world: int = 1, log=print) -> dict:
+    """The frame loop of main.py:348, sharded (SURVEY.md 8(e)): this rank runs frames[rank::world] in order.  `process(k, frame, next_frame)` does one
+    frame (next_frame: the one this rank runs after it, or None -- FramePipeline's look-ahead).  A frame that raises is logged and SKIPPED: the
+    loop carries no state between frames (main.py:348), so one bad frame -- a missing .exr, an empty surface -- does not take the others down.
+    Returns {'done': [frames], 'failed': [(frame, 'Type: message')], 'results': {frame: what process returned}}."""
+    import traceback
+    mine = [frames[i] for i in shard_frames(len(frames), rank, world)]
+    done, failed, results = [], [], {}
+    for k, fr in enumerate(mine):
+        nxt = mine[k + 1] if k + 1 < len(mine) else None
+        try:
+            results[fr] = process(k, fr, nxt)
+            done.append(fr)
+        except Exception as e:      # noqa: BLE001 -- per-frame containment is the point
+            failed.append((fr, f'{type(e).__name__}: {e}'))
+            log(f'# rank {rank}: frame {fr} FAILED and is skipped -- {type(e).__name__}: {e}')
+            log(''.join(traceback.format_exception(type(e), e, e.__traceback__)).rstrip())
+    return {'done': done, 'failed': failed, 'results': results}
+
+
+def gather_summaries(summary: dict, group=None) -> list[dict]:
+    """Every rank's {'done', 'failed'} lists on every rank (one all_gather_object; host data, a few hundred bytes)."""
+    small = {'done': summary['done'], 'failed': summary['failed']}
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [small]
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, small, group=group)
+    return out

@@ -14,6 +14,28 @@ from .utils import recon_util
 from .utils.smpl_util import smpl_util
 
 
+class _stage:
+    """roctx range around one stage of a frame (tracing): `rocprofv3 --marker-trace` / rocprof-sys show the six stages -- U-Net,
+    avatar query, marching cubes, LBS, HGFilter, recon query -- plus normal maps / fusion / colours as named spans.  torch.cuda.nvtx IS roctx on
+    ROCm; where the extension is missing the range is a no-op."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        try:
+            torch.cuda.nvtx.range_push(self.name)
+            self.on = True
+        except Exception:       # noqa: BLE001
+            self.on = False
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
 def fill_volume(values: torch.Tensor, valid_u8: torch.Tensor, invalid_ov: torch.Tensor, out: torch.Tensor | None = None):
     """occ_volume[valid] = values; occ_volume[~valid] = invalid_pts_ov   (main.py:362-363)."""
     N = valid_u8.numel()
@@ -40,6 +62,19 @@ class FramePipeline:
         smpl_util.set_smpl_skinning_weights(dataset.body['skin_weights'])
         smpl_util.set_cano_smpl_vertices(dataset.cano_smpl_v)                 # main.py:335
 
+    def _grid_items(self, items: dict):
+        """'dense' / 'band' when items['cano_pts'] IS the dataset's own point tensor (one frame, every grid point / the valid band in the order of
+        dataset.infer_pts) -- the grid entry points then generate the same coordinates from the index --, else None (any other points: point queries)."""
+        pts = items['cano_pts']
+        ds = self.ds
+        if pts.shape[0] != 1 or getattr(ds, 'infer_pts', None) is None or pts.data_ptr() != ds.infer_pts.data_ptr() or getattr(ds, 'grid_axes', None) is None:
+            return None
+        if getattr(ds, 'valid_mode', None) == 'dense' and pts.shape[1] == ds.valid_u8.numel():
+            return 'dense'
+        if getattr(ds, 'valid_idx', None) is not None and pts.shape[1] == ds.valid_idx.numel():
+            return 'band'
+        return None
+
     @torch.no_grad()
     def avatar_frame(self, items: dict, skin=True, next_items: dict | None = None):
         """1. geometric avatar in canonical space (main.py:357-367) + skinning to live space (:383-389).
@@ -53,30 +88,38 @@ class FramePipeline:
         if pre is not None and pre[0] is items['smpl_pos_map']:
             wf.pose_feat_map, wf._map_on_device = pre[1], None
         else:
-            wf.precompute_conv(items)                                        # :359
-        if getattr(self.ds, 'valid_mode', None) == 'dense' and items['cano_pts'].shape[1] == self.ds.valid_u8.numel():
+            with _stage('avc/unet7ds'):
+                wf.precompute_conv(items)                                    # :359
+        with _stage('avc/avatar_query'):
+            out = self._avatar_query(items)
+        if next_items is not None:
+            with _stage('avc/unet7ds (next frame)'):
+                self._next_map = (next_items['smpl_pos_map'], wf.unet(next_items['smpl_pos_map']).contiguous())
+        with _stage('avc/marching_cubes'):
+            vol = fill_volume(out['cano_pts_ov'][0, :, 0], self.ds.valid_u8, self.ds.invalid_pts_ov)   # :362-364
+            v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds, iso_value=config.iso_value)   # :367
+        res = {'cano_v': v, 'cano_vn': n, 'f': f, 'occ_volume': vol}
+        if skin and v.shape[0] > 0:
+            with _stage('avc/lbs'):
+                lbs = smpl_util.calculate_lbs(v[None])                       # :385
+                live_v, mats = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'], True)     # :386
+                live_n = smpl_util.skinning_normal(n[None], lbs, items['cano2live_jnt_mats'])          # :389 (einsum with vert_mats[:, :3, :3])
+            res.update({'live_v': live_v[0], 'live_vn': live_n[0], 'vert_mats': mats[0]})
+        return res
+
+    def _avatar_query(self, items: dict):
+        if self._grid_items(items) == 'dense':
             # every grid point is queried: the kernel generates the points from the grid index (no 12 B/point read), the offsets,
             # which :360-364 never read, are not written, and -- when the last axis holds a multiple of 128 points -- the 64 pose-feature
             # columns of conv1 / conv5 enter as one fp32 vector per (x, y) column (fused_mlp.hip: column folding; ~1e-6 from the
             # point-by-point query, bit-identical to it otherwise: tests/test_gpu_query.py)
             out = self.occ_net.query_grid(items, self.ds.grid_axes, self.vol_res)
-        elif (getattr(self.ds, 'valid_idx', None) is not None and items['cano_pts'].shape[0] == 1 and items['cano_pts'].shape[1] == self.ds.valid_idx.numel()
-              and items['cano_pts'].data_ptr() == self.ds.infer_pts.data_ptr()):
+        elif self._grid_items(items) == 'band':
             # the dataset's valid band (items['cano_pts'] IS dataset.infer_pts): the same points by their grid indices -- no coordinates read, column-folded
             out = self.occ_net.query_grid(items, self.ds.grid_axes, self.vol_res, index=self.ds.valid_idx)
         else:
             out = self.occ_net.query(items)                                  # :360
-        if next_items is not None:
-            self._next_map = (next_items['smpl_pos_map'], wf.unet(next_items['smpl_pos_map']).contiguous())
-        vol = fill_volume(out['cano_pts_ov'][0, :, 0], self.ds.valid_u8, self.ds.invalid_pts_ov)   # :362-364
-        v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds, iso_value=config.iso_value)   # :367
-        res = {'cano_v': v, 'cano_vn': n, 'f': f, 'occ_volume': vol}
-        if skin and v.shape[0] > 0:
-            lbs = smpl_util.calculate_lbs(v[None])                           # :385
-            live_v, mats = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'], True)     # :386
-            live_n = smpl_util.skinning_normal(n[None], lbs, items['cano2live_jnt_mats'])          # :389 (einsum with vert_mats[:, :3, :3])
-            res.update({'live_v': live_v[0], 'live_vn': live_n[0], 'vert_mats': mats[0]})
-        return res
+        return out
 
     @torch.no_grad()
     def avatar_frame_sharded(self, items: dict, group=None, skin=True):
@@ -110,15 +153,42 @@ class FramePipeline:
     @torch.no_grad()
     def recon_frame(self, items: dict):
         """3. reconstruction network (main.py:438-453); items must hold front_normal / back_normal."""
-        out = self.recon_net.infer(items)                                    # :440
-        vol = fill_volume(out[0], self.ds.valid_u8, self.ds.invalid_pts_ov)                        # :442-443 (output[0])
-        v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds)             # :444 (iso 0.5)
+        kind = self._grid_items(items)
+        rn = self.recon_net
+        with _stage('avc/hgfilter'):
+            imgs = torch.cat([items['front_normal'], items['back_normal']], dim=1)                 # arch_recon.py:51-53
+            img_feat_map = rn.get_feat_maps(imgs)[-1].contiguous()
+        with _stage('avc/recon_query'):
+            if kind == 'dense':
+                out = rn.decode_grid(self.ds.grid_axes, self.vol_res, img_feat_map, items['cano_smpl_center'])                      # :440, on the grid (column-folded)
+            elif kind == 'band':
+                out = rn.decode_grid(self.ds.grid_axes, self.vol_res, img_feat_map, items['cano_smpl_center'], index=self.ds.valid_idx)
+            else:
+                out = rn.decode(items['cano_pts'].contiguous(), img_feat_map, items['cano_smpl_center'])                             # :440
+        with _stage('avc/marching_cubes'):
+            vol = fill_volume(out[0], self.ds.valid_u8, self.ds.invalid_pts_ov)                    # :442-443 (output[0])
+            v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds)         # :444 (iso 0.5)
         res = {'cano_v': v, 'cano_vn': n, 'f': f, 'occ_volume': vol}
         if v.shape[0] > 0:
-            lbs = smpl_util.calculate_lbs(v[None])                           # :451
-            res['live_v'] = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'])[0]       # :452
-            res['live_vn'] = smpl_util.skinning_normal(n[None], lbs, items['cano2live_jnt_mats'])[0]   # :453
+            with _stage('avc/lbs'):
+                lbs = smpl_util.calculate_lbs(v[None])                       # :451
+                res['live_v'] = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'])[0]       # :452
+                res['live_vn'] = smpl_util.skinning_normal(n[None], lbs, items['cano2live_jnt_mats'])[0]   # :453
         return res
+
+    @torch.no_grad()
+    def avatarcap_frame(self, items: dict, observed_normal: torch.Tensor, w2c_RT, cam: dict, integrate_manner: str = 'merge', iter_num: int = 100,
+                        next_items: dict | None = None):
+        """Steps 1-3 of the reference's loop body for one frame (main.py:357-453; BASELINE configs[2], "AvatarCap full"): avatar geometry + skinning,
+        canonical normal fusion with the image-observed normal map, HGFilter + reconstruction query + marching cubes + skinning."""
+        a = self.avatar_frame(items, next_items=next_items)
+        items = dict(items)
+        if a['cano_v'].shape[0] > 0:
+            with _stage('avc/normal_fusion'):
+                items['front_normal'], items['back_normal'], _ = self.fuse_normals(a, observed_normal, w2c_RT, cam, integrate_manner, iter_num)
+        else:
+            items['front_normal'], items['back_normal'] = self.cano_normal_maps(a['cano_v'], a['cano_vn'], a['f'])
+        return a, self.recon_frame(items)
 
 
     @torch.no_grad()
@@ -183,6 +253,7 @@ class FramePipeline:
         items['near'] = items['depth'] - 0.05
         items['far'] = items['depth'] + 0.05
         items['occupancy'] = items['depth'].clone()
-        self.network.warping_field.precompute_conv(items)                                           # :474
-        out = renderer.render(items, pts_space='cano', near_dist=0.02, far_dist=0.05)               # :475
+        renderer.net.warping_field.precompute_conv(items)                                           # :474 (nerf_renderer.net: the finetuned copy when one is loaded)
+        with _stage('avc/colour_vertices'):
+            out = renderer.render(items, pts_space='cano', near_dist=0.02, far_dist=0.05)           # :475
         return out['rgb_map'][0][:, [2, 1, 0]]                                                      # :476

@@ -10,16 +10,22 @@ import numpy as np
 
 
 def rodrigues(rvec) -> np.ndarray:
-    """Axis-angle (3,) or (3,1) -> 3x3 rotation, float64: R = cos(t) I + (1 - cos(t)) r r^T + sin(t) [r]_x with t = |rvec|, r = rvec / t;
-    the identity when t < DBL_EPSILON (OpenCV calib3d, cv::Rodrigues)."""
-    v = np.asarray(rvec, np.float64).reshape(3)
+    """Axis-angle (3,) or (3,1) -> 3x3 rotation: R = cos(t) I + (1 - cos(t)) r r^T + sin(t) [r]_x with t = |rvec|, r = rvec / t; the identity when
+    t < DBL_EPSILON (OpenCV calib3d, cv::Rodrigues).  Like cv::Rodrigues the arithmetic is double whatever the input, and the OUTPUT HAS THE INPUT'S
+    DEPTH: a float32 vector -- the reference's pose vectors are (`np.loadtxt(...).astype(np.float32)`, avatarcap_dataset.py:194) -- returns R rounded
+    to float32, which is what then enters `(I - R) J` and the kinematic chain (dataset/smpl.py:81-90).  Pinned against
+    scipy.spatial.transform.Rotation.from_rotvec (tests/test_host.py); OpenCV itself is absent from this image."""
+    a = np.asarray(rvec)
+    v = a.astype(np.float64).reshape(3)
     t = float(np.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]))
     if t < np.finfo(np.float64).eps:
-        return np.identity(3)
-    r = v / t
-    c, s = np.cos(t), np.sin(t)
-    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
-    return c * np.identity(3) + (1 - c) * np.outer(r, r) + s * K
+        R = np.identity(3)
+    else:
+        r = v / t
+        c, s = np.cos(t), np.sin(t)
+        K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+        R = c * np.identity(3) + (1 - c) * np.outer(r, r) + s * K
+    return R.astype(np.float32) if a.dtype == np.float32 else R
 
 
 def resize_nearest(img: np.ndarray, dsize) -> np.ndarray:

@@ -28,6 +28,9 @@ The JSON line also carries:
                   under its power-managed clock, profiles/r01_ubench_mfma_clock.md -- information, not `peak`).
   cpu_baseline -- the CPU restatements of oracle/ (the query on stock PyTorch CPU ops with identical weights on all host
                   cores, C marching cubes, NumPy LBS) timed on a bounded sample and scaled to one 256^3 frame.
+  configs      -- BASELINE configs[2] (AvatarCap full: avatar + canonical normal fusion, 100 iterations + HGFilter + reconstruction query, the
+                  reference's valid band at 256^3) and configs[3] (512^3 dense + colour head + marching cubes), a few frames each after the headline
+                  measurement, with their stage split (N = 1 only; never `value`).
   masked       -- the same frame with the reference's own valid-band masking (only points within 0.1 m
                   of the body are evaluated, dataset/avatarcap_dataset.py:114-118), for information.
 """
@@ -149,22 +152,15 @@ def cpu_baseline(pipe, sd, frame_out, res, budget_s=24.0):
 
 
 def _free_port():
-    import socket
-    with socket.socket() as so:
-        so.bind(('127.0.0.1', 0))
-        return so.getsockname()[1]
+    from avatarcap_amd.parallel import free_port
+    return free_port()
 
 
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this script, one per GPU, under
     torch.distributed.run on 127.0.0.1 and pass rank 0's JSON line through.  (Round 1 silently measured ONE GPU in this case.)"""
-    import subprocess
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
-    env.setdefault('OMP_NUM_THREADS', '8')
-    return subprocess.call(cmd, env=env)
+    from avatarcap_amd.parallel import self_launch as launch
+    return launch(__file__, sys.argv[1:], args.gpus)
 
 
 def dry_run(args, world, rank):
@@ -173,9 +169,9 @@ def dry_run(args, world, rank):
     import torch.distributed as dist
     from avatarcap_amd.parallel import all_gather_meshes, shard_frames
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        from avatarcap_amd.parallel import init_process_group
         with _stdout_to_stderr():                        # gloo announces its peers on stdout
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+            init_process_group('gloo', rank, world, timeout_s=args.dist_timeout)
     K = args.frames // world if args.frames else args.steps
     n_frames = world * K
     g = torch.Generator().manual_seed(1234)
@@ -208,6 +204,8 @@ def main():
     ap.add_argument('--dry-run', action='store_true', help='no GPU: launcher + gloo all-gather of stand-in meshes')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-masked', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the BASELINE configs[2] / configs[3] legs of the line')
+    ap.add_argument('--dist-timeout', type=float, default=180.0, help='seconds after which a rendezvous / collective that does not complete ends the job')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -229,13 +227,15 @@ def main():
     device = torch.device('cuda', local_rank)
     import torch.distributed as dist
     force_dist = os.environ.get('AVC_FORCE_DIST') == '1'    # exercise the RCCL all-gather with a single rank (tests/test_gpu_pipeline.py)
+    from avatarcap_amd.parallel import init_process_group, barrier_or_die
     if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', str(_free_port()))
         with _stdout_to_stderr():
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+            init_process_group('nccl', rank, world, device, timeout_s=args.dist_timeout)       # bounded: a missing rank ends the job with a message
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 0
-    assert rccl_ranks in (0, world)
+    if world > 1 and rccl_ranks != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the RCCL process group has {rccl_ranks} ranks')
 
     from avatarcap_amd import _lib
     from avatarcap_amd.dataset import to_cuda
@@ -247,10 +247,10 @@ def main():
     # inputs of this rank's frames, resident in HBM before timing
     my = [to_cuda(pipe.ds[(s * world) + rank], add_batch=True) for s in range(K + W)]
 
-    def barrier():
+    def barrier(what='timed region'):
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            barrier_or_die(what, rank)
         torch.cuda.synchronize()
 
     # inside a batch the pipeline is told the next frame, so that its U-Net launches are queued behind the running query (pipeline.py);
@@ -262,27 +262,37 @@ def main():
         with _stdout_to_stderr():
             all_gather_meshes([{'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']}], world, force=force_dist)
             torch.cuda.synchronize()
-    barrier()
+    barrier('start of the timed region')
     _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
     t0 = time.perf_counter()
     meshes = []
     for s in range(W, W + K):
         out = pipe.avatar_frame(my[s], next_items=my[s + 1] if s + 1 < W + K else None)
         meshes.append({'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']})
+    torch.cuda.synchronize()
+    t_frames = time.perf_counter() - t0            # this rank's K frames, before the exchange
+    t_gather = 0.0
     if world > 1 or force_dist:
+        tg = time.perf_counter()
         gathered = all_gather_meshes(meshes, world * K, force=force_dist)
+        torch.cuda.synchronize()
+        t_gather = time.perf_counter() - tg        # includes waiting for the slowest rank's frames
         assert len(gathered) == world * K
-    barrier()
+    barrier('end of the timed region')
     dt = time.perf_counter() - t0
     _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
+    per_rank = [[dt, t_frames, t_gather]]
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine_t = torch.tensor([dt, t_frames, t_gather], dtype=torch.float64, device=device)
+        all_t = torch.empty(world * 3, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(all_t, mine_t)
+        per_rank = all_t.reshape(world, 3).cpu().tolist()
+        dt = max(r[0] for r in per_rank)           # MAX over ranks
 
     import ctypes as C
-    avg_ms, launches = C.c_double(), C.c_int64()
+    avg_ms, launches, avg_cyc, ncyc = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
     _lib.check(_lib.lib().avc_timing_read(ctx, 0, C.byref(avg_ms), C.byref(launches), 1))
+    _lib.check(_lib.lib().avc_timing_read_cycles(ctx, 0, C.byref(avg_cyc), C.byref(ncyc)))     # s_memtime of the same launches -> the clock the chip held
     N = res ** 3
     achieved = N * FLOP_PER_POINT / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
 
@@ -290,7 +300,9 @@ def main():
         line = {
             'metric': 'reconstructed-mesh frames/sec at 256^3 grid (avatar occupancy-only, dense query + marching cubes + LBS)',
             'value': world * K / dt, 'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': K, 'warmup': W,
-            'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': dt / K * 1e3,
+            'ms_per_step_per_rank': [r[1] / K * 1e3 for r in per_rank], 'all_gather_ms_per_rank': [r[2] * 1e3 for r in per_rank],
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (products as 3 split-fp16 MFMA passes, fp32 accumulate)', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: AvatarNet occupancy-only, {res}^3 grid dense ({N} points/frame), random SMPL pose, '
                                    f'UNet7DS + fused query + marching cubes + normals + KNN-4 LBS per frame',
@@ -301,7 +313,9 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_TFLOPS,
                          'traffic': HBM_TRAFFIC_BYTES_256 if res == 256 else None, 'traffic_source': 'profiles/r02_pmc_avatar.md (FETCH_SIZE x2 + WRITE_SIZE)',
-                         'kernel': 'avc::avatar_kernel<true,false,true> (+ its column_terms_kernel pass, timed together)', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
+                         'kernel': 'avc::avatar_kernel<true,false,1> (+ its column_terms_kernel pass, timed together)', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
+                         'shader_cycles_per_launch': avg_cyc.value, 'clock_mhz': (avg_cyc.value / (avg_ms.value * 1e3)) if avg_ms.value > 0 else 0.0,
+                         'cycles_per_mfma': avg_cyc.value / (4728 * (N / 128 / min(N // 128, torch.cuda.get_device_properties(device).multi_processor_count))) if avg_cyc.value > 0 else 0.0,
                          'algorithmic_flop_per_launch': N * FLOP_PER_POINT,
                          'mfma_issued_tflops': N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0,
                          'mfma_util': (N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 / PEAK_F16_TFLOPS) if avg_ms.value > 0 else 0.0,
@@ -316,9 +330,93 @@ def main():
                 line['masked'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(pipe, sd, out, res)
+        if world == 1 and not args.no_configs:
+            del pipe, my, meshes
+            torch.cuda.empty_cache()
+            try:
+                line['configs'] = other_configs(device)
+            except Exception as e:       # informational legs only
+                line['configs'] = {'error': repr(e)}
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
+
+
+def other_configs(device, frames=3):
+    """BASELINE configs[2] and configs[3] on the driver-timed line (VERDICT round 2, next #5), N = 1, a few frames each; never `value`."""
+    from avatarcap_amd import config, synthetic as syn, _lib
+    from avatarcap_amd.dataset import SyntheticTestDataset, to_cuda, synthetic_camera, synthetic_observed_normals
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar
+    from avatarcap_amd.network.arch_recon import ReconNetwork
+    from avatarcap_amd.pipeline import FramePipeline
+    import contextlib
+    import ctypes as C
+    out = {}
+    ctx = _lib.ctx(device)
+
+    def stage_ms(fn, reps):
+        fn(); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps * 1e3, r
+
+    with contextlib.redirect_stdout(sys.stderr):
+        net = GeoTexAvatar(base_weight_volume=np.zeros((2, 2, 2, 24), np.float32)).to(device).eval(); syn.load_synth(net, syn.SEED)
+        rn = ReconNetwork().to(device).eval(); syn.load_synth(rn, syn.SEED)
+    # ---- configs[2]: AvatarCap full, 256^3, the reference's valid band
+    config.cfg['testing']['vol_res'] = [256] * 3
+    ds = SyntheticTestDataset([256] * 3, valid='band', n_frames=frames + 1, device=device)
+    pipe = FramePipeline(net, ds, rn)
+    items = [to_cuda(ds[i], add_batch=True) for i in range(frames + 1)]
+    w2c, cam = synthetic_camera()
+    a = pipe.avatar_frame(items[0])
+    obs = synthetic_observed_normals(a['live_v'], a['live_vn'], a['f'], w2c, cam, seed=0)       # the image-observed normal map of step 2, synthesised once
+    pipe.avatarcap_frame(items[0], obs, w2c, cam); torch.cuda.synchronize()
+    _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
+    t = time.perf_counter()
+    for i in range(1, frames + 1):
+        a, r = pipe.avatarcap_frame(items[i], obs, w2c, cam, next_items=items[i + 1] if i < frames else None)
+    torch.cuda.synchronize()
+    full_ms = (time.perf_counter() - t) / frames * 1e3
+    q = [(C.c_double(), C.c_int64()) for _ in range(2)]
+    for w in range(2):
+        _lib.check(_lib.lib().avc_timing_read(ctx, w, C.byref(q[w][0]), C.byref(q[w][1]), 1))
+    _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
+    it = dict(items[1])
+    t_av, a = stage_ms(lambda: pipe.avatar_frame(items[1]), 3)
+    t_fu, fm = stage_ms(lambda: pipe.fuse_normals(a, obs, w2c, cam), 3)
+    it['front_normal'], it['back_normal'] = fm[0], fm[1]
+    t_re, r = stage_ms(lambda: pipe.recon_frame(it), 3)
+    imgs = torch.cat([it['front_normal'], it['back_normal']], dim=1)
+    t_hg, _ = stage_ms(lambda: rn.get_feat_maps(imgs)[-1], 3)
+    out['configs[2]'] = {'workload': 'AvatarCap full (main.py:357-453): avatar query + marching cubes + LBS, canonical normal fusion (100 iterations), HGFilter, '
+                                     'reconstruction query + marching cubes + LBS; 256^3 grid, the reference\'s valid band', 'frames': frames,
+                         'valid_points': int(ds.infer_pts.shape[0]), 'ms_per_frame': full_ms, 'frames_per_s': 1e3 / full_ms,
+                         'stage_ms': {'avatar_frame (unet + band query + mc + lbs)': t_av, 'normal maps + fusion': t_fu,
+                                      'recon_frame (hgfilter + band query + mc + lbs)': t_re, 'of which hgfilter': t_hg},
+                         'kernel_ms': {'avatar query (band, column-folded)': q[0][0].value, 'recon query (band, column-folded)': q[1][0].value},
+                         'avatar_vertices': int(a['cano_v'].shape[0]), 'recon_vertices': int(r['cano_v'].shape[0])}
+    del ds, pipe, items, a, r, obs, fm, it, imgs
+    torch.cuda.empty_cache()
+    # ---- configs[3]: 512^3 dense + marching cubes + colour head on the vertices (HBM-bound stress)
+    config.cfg['testing']['vol_res'] = [512] * 3
+    ds = SyntheticTestDataset([512] * 3, valid='dense', n_frames=2, device=device)
+    pipe = FramePipeline(net, ds, rn)
+    items = [to_cuda(ds[i], add_batch=True) for i in range(2)]
+    _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
+    t5, a5 = stage_ms(lambda: pipe.avatar_frame(items[1]), 2)
+    qa, ql = C.c_double(), C.c_int64()
+    _lib.check(_lib.lib().avc_timing_read(ctx, 0, C.byref(qa), C.byref(ql), 1))
+    _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
+    nv = min(200_000, int(a5['cano_v'].shape[0]))
+    v, n = a5['cano_v'][:nv].contiguous(), a5['cano_vn'][:nv].contiguous()
+    tc, rgb = stage_ms(lambda: pipe.colour_vertices(items[1], v, n), 2)
+    out['configs[3]'] = {'workload': '512^3 dense grid (134,217,728 points) + marching cubes + normals + LBS, colour head on 200 k vertices (64 samples per ray)',
+                         'avatar_frame_ms': t5, 'frames_per_s': 1e3 / t5, 'query_kernel_ms': qa.value, 'vertices': int(a5['cano_v'].shape[0]),
+                         'faces': int(a5['f'].shape[0]), 'colour_vertices': nv, 'colour_ms': tc, 'rgb_finite': bool(torch.isfinite(rgb).all())}
+    return out
 
 
 def masked_run(res, device, K, W):

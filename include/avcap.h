@@ -136,6 +136,20 @@ int avc_template_query(avc_ctx *ctx, const float *pts_dev, int64_t n, int occupa
 int avc_recon_query(avc_ctx *ctx, const float *pts_dev, int64_t n, const float center[3],
                     float *out_dev, avc_stream stream);
 
+/* The same decoder on the dense canonical grid / on a subset of it given by flat grid indices, without the (N,3) point array -- axis tables, point
+ * order and `index_dev` exactly as for avc_avatar_query_grid / avc_avatar_query_grid_subset (ReconNetwork.infer is called with the same
+ * items['cano_pts'] as the avatar query: main.py:440, arch_recon.py:48).  The decoder's input is [img_feat(32) sampled at (x, y) | z]
+ * (arch_recon.py:63-70) and feeds fc0, fc1 and fc2 (res_layers).  A DENSE grid whose R_z is a multiple of 128 is column-folded: what the three layers do
+ * with the 32 feature channels is one fp32 vector of 896 values per (x, y) column (3.5 KB per column of scratch in the context), which enters the
+ * accumulators through free K slots of the z k-step; only the z column stays a per-point product: 14 % fewer MFMAs, no per-point gather, 13.2 instead of
+ * 17.6 ms at 256^3.  Same algebra as avc_recon_query, other rounding: ~1e-6 from it.  Every other launch -- another R_z, a subset, or
+ * avc_set_option "column_fold" 0 -- runs the point-by-point kernel on the generated points: bit-identical to avc_recon_query. */
+int avc_recon_query_grid(avc_ctx *ctx, const float *axis_x_dev, const float *axis_y_dev, const float *axis_z_dev,
+                         const int32_t res[3], const float center[3], float *out_dev, avc_stream stream);
+int avc_recon_query_grid_subset(avc_ctx *ctx, const float *axis_x_dev, const float *axis_y_dev, const float *axis_z_dev,
+                                const int32_t res[3], const int32_t *index_dev, int64_t n, const float center[3],
+                                float *out_dev, avc_stream stream);
+
 /* occ_volume[valid] = values; occ_volume[~valid] = fill  (main.py:362-363, 442-443).
  * valid_dev (N) uint8/bool; values_dev (n_valid) in flat order; fill_dev (N - n_valid). */
 int avc_scatter_volume(avc_ctx *ctx, const uint8_t *valid_dev, int64_t N, const float *values_dev,
@@ -241,7 +255,8 @@ int avc_timing_read_cycles(avc_ctx *ctx, int which, double *avg_cycles_out, int6
 /* ---- switches of a context --------------------------------------------------------------------
  * No entry point reads the environment: avc_ctx_create reads the defaults ONCE (AVC_NO_FOLD, AVC_MLP_BLOCKS, AVC_KNN_BRUTE / AVC_KNN_PATH,
  * AVC_FUSION_NO_GRAPH), this call changes them afterwards.  Test / A-B switches; none changes what a caller may rely on:
- *   "column_fold"  1 (default) | 0   avc_avatar_query_grid[_subset] without column folding: bit-identical to avc_avatar_query instead of ~1e-6 from it
+ *   "column_fold"  1 (default) | 0   avc_avatar_query_grid[_subset] / avc_recon_query_grid[_subset] without column folding: bit-identical to the
+ *                                    point queries instead of ~1e-6 from them
  *   "mlp_blocks"   0 (default: one persistent workgroup per CU) | n
  *   "knn_search"   0 (default: per wave) | 1 per-lane grid search | 2 cooperative grid search | 3 exhaustive scan -- all four return the same bits
  *   "fusion_graph" 1 (default: the fusion iterations replay a hipGraph) | 0 plain launches */

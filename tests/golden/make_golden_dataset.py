@@ -68,12 +68,17 @@ def install(td, pos_maps):
     cv.IMREAD_UNCHANGED, cv.INTER_NEAREST = -1, 0
 
     def Rodrigues(r):
+        # cv::Rodrigues computes in double and returns a matrix of the INPUT's depth (CV_32F in -> CV_32F out): the reference's float32 pose vectors
+        # (avatarcap_dataset.py:194) get R rounded to float32
+        depth = np.asarray(r).dtype
         v = np.asarray(r, np.float64).reshape(3); t = np.linalg.norm(v)
         if t < 2.220446049250313e-16:
-            return np.eye(3), None
-        k = v / t
-        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
-        return np.cos(t) * np.eye(3) + (1 - np.cos(t)) * np.outer(k, k) + np.sin(t) * K, None
+            R = np.eye(3)
+        else:
+            k = v / t
+            K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+            R = np.cos(t) * np.eye(3) + (1 - np.cos(t)) * np.outer(k, k) + np.sin(t) * K
+        return (R.astype(np.float32) if depth == np.float32 else R), None
 
     def resize(img, dsize, interpolation=None):
         assert interpolation == cv.INTER_NEAREST

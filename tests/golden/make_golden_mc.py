@@ -54,6 +54,16 @@ def main():
     import skimage
     from skimage import measure
     store = {'skimage_version': np.array(skimage.__version__)}
+    # which binary made these vectors: sha256 of the Lewiner extension and of its look-up tables, as installed (the reference pins 0.17.2,
+    # requirements.txt:8; only 0.18.3 exists in this image and nothing offline can prove the two releases' extensions identical -- DESIGN.md section 4)
+    import glob
+    import hashlib
+    mdir = os.path.dirname(measure.__file__)
+    for key, pat in (('sha256_lewiner_cy_so', '_marching_cubes_lewiner_cy*.so'), ('sha256_lewiner_luts_py', '_marching_cubes_lewiner_luts.py'),
+                     ('sha256_lewiner_py', '_marching_cubes_lewiner.py')):
+        f = sorted(glob.glob(os.path.join(mdir, pat)))[0]
+        store[key] = np.array(os.path.basename(f) + ' ' + hashlib.sha256(open(f, 'rb').read()).hexdigest())
+        print(key, store[key])
     names = []
     for k, (name, vol, iso, sp) in enumerate(cases()):
         sp = np.asarray(sp, np.float32)

@@ -217,6 +217,32 @@ def test_vertex_colours_match_oracle(pipe64):
     assert err < 1e-4 + 2 * slack
 
 
+def test_vertex_colours_from_a_finetuned_network(pipe64):
+    """main.py:307-314,474-475: with testing.net_ckpt_finetuned set, the texture comes from a SECOND GeoTexAvatar -- `nerf_renderer.net` -- whose
+    pose feature map is computed on ITS warping field (`nerf_renderer.net.warping_field.precompute_conv(items)`), not on the geometry network's.
+    colour_vertices(..., renderer) must therefore give what a pipeline built on the second network gives for the same vertices."""
+    from avatarcap_amd.dataset import to_cuda
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar, NerfRenderer
+    from avatarcap_amd.pipeline import FramePipeline
+    from avatarcap_amd.utils.smpl_util import smpl_util
+    from common import geotex_sd_with_density
+    ds = pipe64.ds
+    items = to_cuda(ds[0], add_batch=True)
+    out = pipe64.avatar_frame(items)
+    d2, _ = smpl_util.knn_points(out['cano_v'][None], smpl_util.cano_smpl_vertices[None], K=1)
+    near = torch.nonzero(d2[0, :, 0] < 0.03 ** 2)[:, 0]
+    idx = near[torch.linspace(0, near.numel() - 1, 200, device='cuda').long()]
+    v, n = out['cano_v'][idx].contiguous(), out['cano_vn'][idx].contiguous()
+    fine = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume()).to('cuda').eval()
+    fine.load_state_dict({k: torch.from_numpy(a) for k, a in geotex_sd_with_density(seed=gi.SEED_NET + 5).items()})
+    assert fine.warping_field.pose_feat_map is None                                # nothing has run on it yet: a stale / missing map would show
+    rgb = pipe64.colour_vertices(items, v, n, NerfRenderer(fine))
+    own = FramePipeline(fine, ds).colour_vertices(items, v, n)
+    assert rgb.shape == (200, 3) and float(rgb.max()) > 0.2
+    assert torch.equal(rgb, own)
+    assert not torch.equal(rgb, pipe64.colour_vertices(items, v, n))               # and it is not the geometry network's texture
+
+
 def test_full_frame_chain(pipe64):
     """avatar -> canonical normal maps -> reconstruction network, all on the device (main.py:357-453 minus
     the image-normal fusion).  The maps must equal the oracle rasteriser's on the avatar mesh and the

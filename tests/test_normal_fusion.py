@@ -129,6 +129,24 @@ def test_merge_runs_and_blends():
     assert np.array_equal(cov[m], tar[m]) and np.array_equal(cov[~m], src[~m])
 
 
+
+def _within_measured_slack(d, slacks, what, factor=4.0, floors=(2e-6, 2e-4, 2e-3)):
+    """Bounds from MEASURED slack instead of hand-set numbers (as tests/test_gpu_512.py does for colours).  `slacks` = one or more arrays
+    |some fp32 evaluation - fp64 oracle| on the very same inputs: the fp32 run of the oracle itself and, where the goldens hold it, the REFERENCE's own
+    fp32 run (torch autograd + torch.optim.Adam).  They say what the iterations lose in fp32: Adam's normalised step amplifies rounding wherever a
+    gradient is near zero, so a handful of pixels drift by 1e-4 .. 1e-2 while the bulk agrees to 1e-7; the oracle's fp32 run shares the fp64 run's
+    operation order and loses least, the reference's autograd run ~50x more.  Another fp32 evaluation with yet another summation order (the HIP
+    kernels) may differ from fp64 by a small multiple of the largest measured slack, quantile by quantile: mean, 99.9 % and worst pixel."""
+    slacks = slacks if isinstance(slacks, (list, tuple)) else [slacks]
+    rows = []
+    for (name, q), floor in zip((('mean', None), ('99.9 %', 0.999), ('max', 1.0)), floors):
+        dv = float(d.mean() if q is None else np.quantile(d, q))
+        sv = max(float(sl.mean() if q is None else np.quantile(sl, q)) for sl in slacks)
+        rows.append((name, dv, sv, factor * sv + floor))
+    print(what + ': ' + '; '.join('%s %.2e (measured fp32 slack %.2e, bound %.2e)' % r for r in rows))
+    for name, dv, sv, bound in rows:
+        assert dv <= bound, (what, name, dv, sv, bound)
+
 # ---------------------------------------------------------------- the oracle against the reference's own code
 @pytest.fixture(scope='module')
 def fusion_golden():
@@ -143,10 +161,13 @@ def test_oracle_merge_matches_reference_run(fusion_golden):
     src, tar = src.astype(np.float32), tar.astype(np.float32)
     for tag, iters, neck in (('b', 10, (300, 200)), ('a', 100, (-256, 150))):
         out = nfo.merge_normal_images(src, tar, iters, neck, np.float32)
-        d = np.abs(out[::3, ::3] - fusion_golden[f'G15_{tag}_lattice'])
-        # both are fp32 runs of the same 100-step Adam recursion with different summation orders (autograd vs hand-written):
-        # the bulk agrees to ~1e-6, a handful of pixels with near-zero gradients drift further (cf. fp32 vs fp64 oracle)
-        assert d.mean() < 2e-5 and np.quantile(d, 0.999) < 1e-3 and d.max() < 2e-2, (tag, d.mean(), d.max())
+        ref64 = nfo.merge_normal_images(src, tar, iters, neck, np.float64)
+        # both are fp32 runs of the same Adam recursion with different summation orders (autograd vs hand-written): each is held to the fp64 oracle
+        # within the measured fp32 slack, and so is their difference (twice: two fp32 runs)
+        slack = np.abs(out - ref64)[::3, ::3]
+        _within_measured_slack(np.abs(fusion_golden[f'G15_{tag}_lattice'] - ref64[::3, ::3]), slack, f'reference run {tag} vs fp64 oracle')
+        ref_slack = np.abs(fusion_golden[f'G15_{tag}_lattice'] - ref64[::3, ::3])
+        _within_measured_slack(np.abs(out[::3, ::3] - fusion_golden[f'G15_{tag}_lattice']), [slack, ref_slack], f'fp32 oracle vs reference run {tag}', factor=2.0)
         assert abs(out.astype(np.float64).sum() - fusion_golden[f'G15_{tag}_checksum'][0]) < 2e-3 * fusion_golden[f'G15_{tag}_checksum'][1] ** 0.5 + 1
     assert np.array_equal(nfo.merge_normal_images_cover(src, tar)[::3, ::3], fusion_golden['G15_cover_lattice'])
 
@@ -239,13 +260,12 @@ def test_hip_merge_normal_images_matches_oracle(size, iters, neck, fusion_golden
     ref = nfo.merge_normal_images(src, tar, iters, neck, np.float64)
     out = merge_normal_images(src, tar, iters, neck)
     assert out.dtype == np.float32 and out.shape == src.shape
-    d = np.abs(out - ref)
-    # 100 Adam steps amplify fp32 rounding at the few pixels whose gradient is near zero (the fp32 oracle differs from the
-    # fp64 one by as much): bound the bulk tightly and the worst pixel loosely
-    assert d.mean() < 2e-5 and np.quantile(d, 0.999) < 1e-3 and d.max() < 2e-2, (d.max(), d.mean())
+    slack = np.abs(nfo.merge_normal_images(src, tar, iters, neck, np.float32) - ref)  # what fp32 itself loses over these iterations
+    _within_measured_slack(np.abs(out - ref), slack, f'HIP vs fp64 oracle ({size}^2, {iters} iterations)')
     if size == 512:                                                                   # the reference's own run of these very inputs
-        g = np.abs(out[::3, ::3] - fusion_golden['G15_a_lattice'])
-        assert g.mean() < 2e-5 and np.quantile(g, 0.999) < 1e-3 and g.max() < 2e-2, (g.max(), g.mean())
+        ref_slack = np.abs(fusion_golden['G15_a_lattice'] - ref[::3, ::3])
+        _within_measured_slack(np.abs(out - ref)[::3, ::3], [slack[::3, ::3], ref_slack], 'HIP vs fp64 oracle, against the reference run\'s own slack')
+        _within_measured_slack(np.abs(out[::3, ::3] - fusion_golden['G15_a_lattice']), [slack[::3, ::3], ref_slack], 'HIP vs the reference run', factor=8.0)
     obs = nfo.erode3x3(np.linalg.norm(tar, axis=-1) > 0, 3) > 0
     assert np.array_equal(out[~obs], src[~obs])                                       # erosion / distance transform agree exactly
     assert np.array_equal(merge_normal_images(src, tar, iters, neck), out)            # deterministic
@@ -265,12 +285,11 @@ def test_hip_merge_non_square_ragged_image():
     assert src.shape == (93, 75, 3)
     ref = nfo.merge_normal_images(src, tar, 12, (30, 70), np.float64)
     out = merge_normal_images(src, tar, 12, (30, 70))
-    d = np.abs(out - ref)
-    assert d.mean() < 2e-5 and d.max() < 2e-2, (d.max(), d.mean())
+    _within_measured_slack(np.abs(out - ref), np.abs(nfo.merge_normal_images(src, tar, 12, (30, 70), np.float32) - ref), 'HIP vs fp64 oracle (93 x 75)')
     obs = nfo.erode3x3(np.linalg.norm(tar, axis=-1) > 0, 3) > 0
     assert np.array_equal(out[~obs], src[~obs])
     # no observed pixel at all / every pixel observed: the distance transform's two saturated ends
     assert np.array_equal(merge_normal_images(src, np.zeros_like(tar), 3, (30, 70)), src)
     full = np.ascontiguousarray(np.where(np.linalg.norm(tar, axis=-1, keepdims=True) > 0, tar, np.float32([0, 0, 1])), np.float32)
     o2, r2 = merge_normal_images(src, full, 3, (30, 70)), nfo.merge_normal_images(src, full, 3, (30, 70), np.float64)
-    assert np.abs(o2 - r2).max() < 2e-2 and np.abs(o2 - r2).mean() < 2e-5
+    _within_measured_slack(np.abs(o2 - r2), np.abs(nfo.merge_normal_images(src, full, 3, (30, 70), np.float32) - r2), 'HIP vs fp64 oracle (every pixel observed)')

@@ -141,3 +141,58 @@ def test_all_gather_meshes_validates_its_shard():
         assert all_gather_meshes([], 0, force=True) == []                   # a rank / batch without frames
     finally:
         dist.destroy_process_group()
+
+
+def test_main_shards_frames_and_contains_a_failing_frame(tmp_path):
+    """`python main.py -m test --gpus N`: the product entry point shards main.py:348's frame loop itself -- frame k of the
+    list on rank k mod N, every rank writing its own files --, skips a frame that raises (logged, exit status 1 at the end, the others done) and, with
+    --gather-meshes, all-gathers the batch's meshes to rank 0.  --dry-run swaps FramePipeline for stand-in meshes on gloo; the loop, the launcher,
+    the rendezvous and the gather are the product's."""
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    env = dict(os.environ); env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    ok = tmp_path / 'ok'
+    r = subprocess.run([sys.executable, os.path.join(root, 'main.py'), '-m', 'test', '--dry-run', '--frames', '7', '--gpus', '2', '--gather-meshes',
+                        '--output-dir', str(ok)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert sorted(p.name for p in ok.glob('*_mesh.npz')) == ['%04d_mesh.npz' % f for f in range(7)]
+    lines = r.stdout.splitlines()
+    assert sum('rank 0: frame' in l for l in lines) == 4 and sum('rank 1: frame' in l for l in lines) == 3       # 0,2,4,6 | 1,3,5
+    assert any('7 of 7 frames done on 2 rank(s)' in l for l in lines)
+    allm = np.load(ok / 'all_avatar_meshes.npz')
+    assert allm['frames'].tolist() == list(range(7))
+    for f in range(7):
+        assert allm['v_%04d' % f].shape == (5 + f % 7, 3) and float(allm['v_%04d' % f][0, 0]) == f + 0.5 and int(allm['f_%04d' % f][0, 0]) == f
+    bad = tmp_path / 'bad'
+    r = subprocess.run([sys.executable, os.path.join(root, 'main.py'), '-m', 'test', '--dry-run', '--frames', '6', '--gpus', '2', '--gather-meshes',
+                        '--dry-fail', '3', '--output-dir', str(bad)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert sorted(p.name for p in bad.glob('*_mesh.npz')) == ['%04d_mesh.npz' % f for f in (0, 1, 2, 4, 5)]       # frame 3 skipped, 5 (same rank, after it) done
+    assert 'frame 3 FAILED and is skipped' in r.stdout and '5 of 6 frames done on 2 rank(s); FAILED: 3 (RuntimeError' in r.stdout
+    allm = np.load(bad / 'all_avatar_meshes.npz')
+    assert allm['v_0003'].shape == (0, 3) and allm['v_0005'].shape == (10, 3)                                     # the failed frame travels as an empty mesh
+
+
+def test_run_sharded_and_bounded_rendezvous():
+    """run_sharded: order, look-ahead argument, containment; init_process_group: a rendezvous that cannot complete ends with a message, not a hang."""
+    import subprocess
+    import sys
+    from avatarcap_amd.parallel import run_sharded
+    seen = []
+
+    def process(k, fr, nxt):
+        seen.append((k, fr, nxt))
+        if fr == 'c':
+            raise ValueError('boom')
+        return fr.upper()
+    s = run_sharded(list('abcdefg'), process, rank=0, world=2, log=lambda m: None)
+    assert seen == [(0, 'a', 'c'), (1, 'c', 'e'), (2, 'e', 'g'), (3, 'g', None)]
+    assert s['done'] == ['a', 'e', 'g'] and s['failed'] == [('c', 'ValueError: boom')] and s['results'] == {'a': 'A', 'e': 'E', 'g': 'G'}
+    assert run_sharded([], process, 0, 1)['done'] == []
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    code = ("import sys; sys.path.insert(0, %r); from avatarcap_amd import parallel; import os; os.environ['MASTER_PORT'] = str(parallel.free_port());"
+            "parallel.init_process_group('gloo', 0, 2, timeout_s=3.0)" % root)                # rank 1 never comes
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'rendezvous of 2 ranks' in r.stderr and 'failed within 3 s' in r.stderr

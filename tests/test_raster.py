@@ -69,6 +69,70 @@ def test_hip_rasteriser_matches_oracle(size):
     assert float(e.abs().max()) == 0.0
 
 
+def _sliver_scene(n=6000, size=64, seed=3):
+    """Needles and slivers: nearly collinear corner triples whose corners sit within a sub-pixel step of pixel-centre rows / columns -- the 1/256-pixel
+    snap of the coverage test and the unsnapped positions of the attribute planes then disagree about the triangle's area, down to its sign."""
+    rs = np.random.RandomState(seed)
+    px = 2.0 / size
+    a = rs.uniform(-0.9, 0.9, (n, 2))
+    d = rs.uniform(-1, 1, (n, 2)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    L = rs.uniform(0.5, 12, (n, 1)) * px
+    axis_aligned = rs.rand(n) < 0.6
+    d[axis_aligned] = np.where(rs.rand(axis_aligned.sum(), 1) < 0.5, [[1.0, 0.0]], [[0.0, 1.0]])
+    a[axis_aligned] = (np.floor(a[axis_aligned] / px) + 0.5) * px                  # ... through pixel centres
+    nrm = np.stack([-d[:, 1], d[:, 0]], 1)
+    eps = rs.uniform(-1.5, 1.5, (n, 3, 1)) * px / 256                                # corner offsets across the needle: a sub-pixel step or so
+    t = np.stack([np.zeros((n, 1)), 0.5 * L * rs.uniform(0.8, 1.2, (n, 1)), L], 1)  # along it
+    xy = a[:, None, :] + t * d[:, None, :] + eps * nrm[:, None, :]
+    z = rs.uniform(-0.3, 0.3, (n, 3, 1))
+    v = np.concatenate([xy, z], 2).reshape(-1, 3).astype(np.float32)
+    f = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    attr = rs.uniform(-1, 1, (3 * n, 3)).astype(np.float32)
+    return v, f, attr
+
+
+def test_oracle_slivers_interpolate_inside_their_corners():
+    """attributes are interpolated with the barycentrics of the UNSNAPPED corners while coverage comes from the snapped ones; a sliver
+    that wins a pixel with a near-zero / opposite-sign unsnapped area must not extrapolate (or emit inf / NaN): every covered pixel's value lies
+    within its triangle's corner values (weights clamped to [0, 1] and renormalised for such triangles, raster_oracle.c: bary_guard)."""
+    v, f, attr = _sliver_scene()
+    hit = 0
+    for view_img in raster.render_cano_mesh(v, attr, f, np.zeros(3, np.float32), 64):
+        assert np.isfinite(view_img).all()
+        hit += int((np.abs(view_img).sum(-1) > 0).sum())
+    assert hit > 200                                                                 # the scene does cover pixels
+    # every triangle on its own (no depth competition): the pixel values against the corner range
+    worst = 0.0
+    for t in range(0, f.shape[0], 7):
+        fr, bk = raster.render_cano_mesh(v, attr, f[t:t + 1], np.zeros(3, np.float32), 64)
+        lo, hi = attr[f[t]].min(0), attr[f[t]].max(0)
+        for img in (fr, bk):
+            m = np.abs(img).sum(-1) > 0
+            if m.any():
+                worst = max(worst, float(np.maximum(lo - img[m], img[m] - hi).max()))
+    span = 2.0
+    assert worst < 0.51 * span, worst            # ordinary near-edge overshoot is allowed up to the guard's threshold (weights in [-0.5, 1.5]) ...
+    M, _ = _pinhole(64, 64, 80.0, 2.0)
+    im = raster.render_mesh(v, attr, f, M, 64, 64)
+    assert np.isfinite(im).all() and float(np.abs(im[..., :3]).max()) <= 1.0 + 0.51 * span
+
+
+@pytest.mark.gpu
+def test_hip_rasterisers_match_oracle_on_slivers():
+    import torch
+    from avatarcap_amd.utils.visualize_util import render_cano_mesh_device
+    from avatarcap_amd.utils.renderer import render_mesh_device
+    v, f, attr = _sliver_scene()
+    c = np.zeros(3, np.float32)
+    ofr, obk = raster.render_cano_mesh(v, attr, f, c, 64)
+    fr, bk = render_cano_mesh_device(torch.from_numpy(v).cuda(), torch.from_numpy(attr).cuda(), torch.from_numpy(f).cuda(), c, 64)
+    assert np.array_equal(fr.cpu().numpy(), ofr) and np.array_equal(bk.cpu().numpy(), obk)
+    M, _ = _pinhole(64, 64, 80.0, 2.0)
+    om = raster.render_mesh(v, attr, f, M, 64, 64)
+    gm = render_mesh_device(torch.from_numpy(v).cuda(), torch.from_numpy(attr).cuda(), torch.from_numpy(f).cuda(), M, 64, 64)
+    assert np.array_equal(gm.cpu().numpy(), om)
+
+
 def _pinhole(W, H, f, tz):
     from avatarcap_amd.utils.renderer import gl_perspective_projection_matrix
     mv = np.eye(4, dtype=np.float32); mv[2, 3] = tz

@@ -41,6 +41,35 @@ layer('geo.0 o shared.6', RL, 2, 16)
 SEQ.append(('geo.1 head (+ output store)', 'one-tile heads', 24))
 
 
+RSEQ = [('fc0 rows 0..255 (z k-step, 8 tiles) + flush pair 0', 'fc0 wide chunks', 24)]
+RSEQ += [(f'fc1 over x[{64 * c}..{64 * c + 63}]', 'fc1 chunks (4 k-steps x 8 tiles)', 96) for c in range(4)]
+RSEQ += [('[fc0 rows 256..511 | fc1 z] + flush pair 0', 'fc0 wide chunks', 48)]
+RSEQ += [(f'fc1 over x[{256 + 64 * c}..{256 + 64 * c + 63}]', 'fc1 chunks (4 k-steps x 8 tiles)', 96) for c in range(4)]
+RSEQ += [('fc2 pair 0 first half (+ fc1 pairs 1..3 epilogue)', 'fc2', 54), ('fc2 pair 0 second half', 'fc2', 48), ('fc2 pair 1 first half', 'fc2', 54),
+         ('fc2 pair 1 second half', 'fc2', 48), ('fc3 head (+ sigmoid, store, next tile\'s column loads)', 'fc3 head', 24)]
+
+
+def recon_main():
+    global SEQ
+    SEQ = RSEQ
+    sys.path.insert(0, 'tests')
+    import golden_inputs as gi
+    from common import recon_sd
+    from avatarcap_amd.network.arch_recon import ReconNetwork
+    rn = ReconNetwork().to('cuda').eval()
+    rn.load_state_dict({k: torch.from_numpy(v) for k, v in recon_sd().items()})
+    imap = torch.from_numpy(gi.img_feat_map()[None]).cuda()
+    center = torch.from_numpy(gi.center()[None]).cuda()
+    axes = volume_axes(syn.CANO_BOUNDS, (RES,) * 3, 'cuda')
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for _ in range(2):
+        ev[0].record()
+        y = rn.decode_grid(axes, (RES,) * 3, imap, center)
+        ev[1].record()
+    torch.cuda.synchronize()
+    report(y.view(-1).view(torch.int64), ev[0].elapsed_time(ev[1]), 'recon_fold_kernel<1>` (dense 256^3 grid, column-folded; with its column pass')
+
+
 def main():
     net = GeoTexAvatar(base_weight_volume=np.zeros((2, 2, 2, 24), np.float32)).to('cuda').eval()
     sd = syn.synth_state_dict(syn.module_shapes(net), syn.SEED)
@@ -54,8 +83,10 @@ def main():
         o = OccupancyNet(net).query_grid(batch, axes, (RES,) * 3, want_offset=True)
         ev[1].record()
     torch.cuda.synchronize()
-    ms = ev[0].elapsed_time(ev[1])
-    raw = o['nonrigid_offset'].view(-1).view(torch.int64)
+    report(o['nonrigid_offset'].view(-1).view(torch.int64), ev[0].elapsed_time(ev[1]), 'avatar_kernel<true,false,1>` (dense 256^3, column-folded')
+
+
+def report(raw, ms, what):
     nw = 1024
     summ = raw[:4 * nw].cpu().numpy().reshape(nw, 4).astype(np.float64)
     st = raw[8192:8192 + nw * 256].cpu().numpy().reshape(nw, 256)
@@ -64,7 +95,7 @@ def main():
     tot = summ[:, 0].mean()
     lines = []
     P = lines.append
-    P(f'# Time split of `avatar_kernel<true,false,1>` (dense 256^3, column-folded), s_memtime stamps of an `AVC_DBG_TIMING=2` build -- round 3')
+    P(f'# Time split of `{what}), s_memtime stamps of an `AVC_DBG_TIMING=2` build -- round 3')
     P('')
     P(f'`tools/timing_probe.py`: launch {ms:.2f} ms (instrumented build), {tot:.4e} shader cycles per wave = {tot / ms / 1e3:.0f} MHz, '
       f'{tot / (mfma_tile * tiles_per_wave):.2f} cycles per MFMA ({mfma_tile} MFMAs x {tiles_per_wave} tiles per wave); wave-to-wave spread of the total '
@@ -117,9 +148,10 @@ def main():
     P(f'| **tile** | {len(SEQ)} | {mfma_tile} | {drain.sum() + bar.sum():.0f} | {body.sum():.0f} | {body.sum() / mfma_tile:.1f} | 100 % | {tile_total - 32 * mfma_tile:.0f} |')
     text = '\n'.join(lines) + '\n'
     print(text)
-    if len(sys.argv) > 1:
-        open(sys.argv[1], 'w').write(text)
+    out = [a for a in sys.argv[1:] if a != '--recon']
+    if out:
+        open(out[0], 'w').write(text)
 
 
 if __name__ == '__main__':
-    main()
+    recon_main() if '--recon' in sys.argv else main()
