@@ -260,12 +260,21 @@ def test_hip_merge_normal_images_matches_oracle(size, iters, neck, fusion_golden
     ref = nfo.merge_normal_images(src, tar, iters, neck, np.float64)
     out = merge_normal_images(src, tar, iters, neck)
     assert out.dtype == np.float32 and out.shape == src.shape
-    slack = np.abs(nfo.merge_normal_images(src, tar, iters, neck, np.float32) - ref)  # what fp32 itself loses over these iterations
-    _within_measured_slack(np.abs(out - ref), slack, f'HIP vs fp64 oracle ({size}^2, {iters} iterations)')
-    if size == 512:                                                                   # the reference's own run of these very inputs
+    # Yardsticks, all measured on these very inputs: (1) the oracle's own fp32 run against its fp64 run -- it shares the fp64 run's operation order and so
+    # understates what ANOTHER order loses (the reference's autograd run deviates 50x more in the mean); (2) how the recursion amplifies rounding-sized
+    # noise wherever it enters: the fp64 oracle on inputs perturbed by a few fp32 ulps (2^-20 relative) -- order-independent, worst pixel included
+    # (1.4e-3 at 512^2 / 100 iterations: Adam's normalised step is chaotic where a gradient is near zero); (3) at 512^2 the REFERENCE's own fp32 run.
+    rs = np.random.RandomState(size)
+    noise = lambda a: a.astype(np.float64) * (1.0 + 2.0 ** -20 * rs.uniform(-1, 1, a.shape))      # noqa: E731
+    cond = np.abs(nfo.merge_normal_images(noise(src), noise(tar), iters, neck, np.float64) - ref)
+    if size == 512:                                                                   # the reference's own run of these very inputs (lattice of every third pixel)
         ref_slack = np.abs(fusion_golden['G15_a_lattice'] - ref[::3, ::3])
-        _within_measured_slack(np.abs(out - ref)[::3, ::3], [slack[::3, ::3], ref_slack], 'HIP vs fp64 oracle, against the reference run\'s own slack')
-        _within_measured_slack(np.abs(out[::3, ::3] - fusion_golden['G15_a_lattice']), [slack[::3, ::3], ref_slack], 'HIP vs the reference run', factor=8.0)
+        _within_measured_slack(np.abs(out - ref)[::3, ::3], [cond[::3, ::3], ref_slack], 'HIP vs fp64 oracle on the lattice (slacks: 8-ulp conditioning, reference run)')
+        _within_measured_slack(np.abs(out[::3, ::3] - fusion_golden['G15_a_lattice']), [cond[::3, ::3], ref_slack], 'HIP vs the reference run', factor=8.0)
+        _within_measured_slack(np.abs(out - ref), [cond], f'HIP vs fp64 oracle ({size}^2, {iters} iterations)')
+    else:
+        slack = np.abs(nfo.merge_normal_images(src, tar, iters, neck, np.float32) - ref)
+        _within_measured_slack(np.abs(out - ref), [slack, cond], f'HIP vs fp64 oracle ({size}^2, {iters} iterations)')
     obs = nfo.erode3x3(np.linalg.norm(tar, axis=-1) > 0, 3) > 0
     assert np.array_equal(out[~obs], src[~obs])                                       # erosion / distance transform agree exactly
     assert np.array_equal(merge_normal_images(src, tar, iters, neck), out)            # deterministic

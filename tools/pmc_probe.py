@@ -18,6 +18,20 @@ axes = volume_axes(syn.CANO_BOUNDS, (res, res, res), 'cuda')
 mode = sys.argv[3] if len(sys.argv) > 3 else 'grid'       # 'grid' = what bench.py launches (points from the index, no offsets); 'pts' = the (N,3) array
 if mode == 'pts':
     batch['cano_pts'] = generate_volume_points(syn.CANO_BOUNDS, (res, res, res), 'cuda')[None]
+if mode == 'recon':                        # the folded recon query on the dense grid (avc_recon_query_grid)
+    sys.path.insert(0, 'tests')
+    import golden_inputs as gi
+    from common import recon_sd
+    from avatarcap_amd.network.arch_recon import ReconNetwork
+    rn = ReconNetwork().to('cuda').eval()
+    rn.load_state_dict({k: torch.from_numpy(v) for k, v in recon_sd().items()})
+    imap = torch.from_numpy(gi.img_feat_map()[None]).cuda()
+    center = torch.from_numpy(gi.center()[None]).cuda()
+    for _ in range(reps + 1):
+        rn.decode_grid(axes, (res, res, res), imap, center)
+    torch.cuda.synchronize()
+    print('done')
+    sys.exit(0)
 for _ in range(reps + 1):
     if mode == 'pts':
         OccupancyNet(net).query(batch)

@@ -1,6 +1,7 @@
 #!/bin/bash
-# usage: tools/run_pmc.sh <tag> [res]   -- separate rocprofv3 --pmc passes (never combined with sys/hip traces)
-TAG=$1; RES=${2:-256}
+# usage: tools/run_pmc.sh <tag> [res] [mode]   -- separate rocprofv3 --pmc passes (never combined with sys/hip traces); mode: grid (avatar query) | recon
+TAG=$1; RES=${2:-256}; MODE=${3:-grid}
+if [ "$MODE" = recon ]; then KRE='recon_fold_kernel|recon_column_terms_kernel'; else KRE='avatar_kernel|column_terms_kernel'; fi
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
@@ -11,7 +12,7 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "FETCH_SIZE TCC_REQ" \
          "WRITE_SIZE TCC_HIT TCC_MISS" ; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv --kernel-include-regex 'avatar_kernel|column_terms_kernel' -d $OUT/p$i -o p$i -- python tools/pmc_probe.py $RES 1 > $OUT/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv --kernel-include-regex "$KRE" -d $OUT/p$i -o p$i -- python tools/pmc_probe.py $RES 1 $MODE > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections
@@ -19,7 +20,7 @@ agg = collections.OrderedDict()
 for f in sorted(glob.glob('$OUT/p*/*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name']
-        if 'avatar_kernel' not in name and 'column_terms_kernel' not in name: continue
+        if 'avatar_kernel' not in name and 'column_terms_kernel' not in name and 'recon_fold_kernel' not in name: continue
         k = ('col:' if 'column_terms_kernel' in name else '') + r['Counter_Name']; agg.setdefault(k, []).append(float(r['Counter_Value']))
 with open('$OUT/summary.txt', 'w') as out:
     for k, v in agg.items():
