@@ -1,26 +1,32 @@
 // Fused per-point MLP queries for gfx950 (MI355X):
-//   avatar_kernel : OccupancyNet.query  = WarpingField.query + DoubleTNet.forward
-//                   (reference network/arch_avatar.py:356-381, :113-140, :65-83)
-//   recon_kernel  : ReconNetwork.infer's decoder loop (network/arch_recon.py:55-73)
+//   avatar_kernel     : OccupancyNet.query  = WarpingField.query + DoubleTNet.forward
+//                       (reference network/arch_avatar.py:356-381, :113-140, :65-83)
+//   recon_kernel      : ReconNetwork.infer's decoder loop (network/arch_recon.py:55-73), point by point
+//   recon_fold_kernel : the same decoder on a dense grid, the image-feature columns folded per (x, y) column
 //
 // Design:
-//   * one workgroup = 4 waves (one per SIMD, ~450 VGPRs each), persistent over 128-point tiles;
+//   * one workgroup = 4 waves (one per SIMD, ~400 of the 512 VGPR+AGPR each), persistent over 128-point tiles;
 //     a wave owns 32 points and ALL hidden channels of them, so the whole 17-layer chain runs
 //     out of registers: the D tile of one layer is, register for register, the B operand of the
 //     next (mlp_layout.h).  No activation ever touches LDS or HBM.
 //   * arithmetic: every fp32 product a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with
 //     (hi, lo) fp16 pairs on v_mfma_f32_32x32x16_f16, fp32 accumulation (22+ significant bits,
 //     ~1e-6 relative; the parity bar is 1e-4 absolute).  3 MFMA passes at 16x the fp32-MFMA rate.
-//   * weights (3.6 MB, pre-split and pre-permuted by pack.cpp) stream L2 -> VGPR -> LDS with
-//     global_load_dwordx4 + ds_write_b128 into a 2 x 64 KiB ring, one chunk ahead of the MFMAs that read it
-//     (ds_read_b128, lane-linear => conflict-free); one barrier per chunk.
+//   * weights (3.4 MB, pre-split and pre-permuted by pack.cpp) stream L2 -> LDS by LDS-DMA in its buffer form
+//     (`buffer_load_dwordx4 ... offen lds`: no staging VGPRs, no ds_write) into a 2 x 64 KiB ring, one chunk ahead of
+//     the MFMAs that read it (ds_read_b128, lane-linear => conflict-free); one barrier per chunk.
 //   * everything is a compile-time unrolled sequence of CHUNK STEPS.  Inside a chunk every k-step
 //     issues, in the shadow of its 3*TPC MFMAs: the LDS reads of the next k-step's A fragments, a
-//     slice of the next chunk's global->LDS prefetch, and a slice of the PREVIOUS tile pair's
-//     epilogue (bias is the accumulator init; scale, activation, fp16 re-split), so VALU / LDS /
-//     VMEM work hides behind the matrix pipe instead of serialising with it.
-//   * fused prologue: bilinear gather of the channel-last feature map, positional encoding
-//     (accurate sincosf), the p + offset hand-off in fp32.
+//     slice of the next chunk's LDS-DMA, and a slice of the PREVIOUS tile pair's epilogue (bias or column term is
+//     the accumulator init; activation, fp16 re-split), each pinned behind one MFMA, so VALU / LDS / VMEM work hides
+//     behind the matrix pipe instead of serialising with it.  Layers with a short K (conv1 of a folded launch,
+//     shared.0) are ONE wide chunk of all eight tiles; layers with a second input segment (conv5, shared.4) walk a
+//     tile pair's k-steps as two chunks of equal size.
+//   * fused prologue: bilinear gather of the channel-last feature map (point-by-point launches; dense grids take the
+//     feature part of conv1 / conv5 as one fp32 vector per (x, y) column), positional encoding (accurate sincos),
+//     the p + offset hand-off in fp32.
+//   * at the board's power cap the launch time is set by energy, not cycles (profiles/r03_power_wall.md): the kernel
+//     issues 92 - 94 % of the split-fp16 MFMA rate the part sustains with nothing else in the instruction stream.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <stdint.h>

@@ -23,9 +23,10 @@ The JSON line also carries:
                   product -- 4,728 MFMAs per 32 points once the 64 pose-feature columns of conv1 / conv5 are folded per
                   grid column, DESIGN.md 2.5 -- so `mfma_util` = 2.73 x frac is the matrix-pipe utilisation; the launch
                   time includes the column pass that feeds the folded kernel; `traffic` is the
-                  HBM byte count of the committed rocprofv3 --pmc pass, profiles/r02_pmc_avatar.md;
-                  `sustained_mfma_tflops_measured` is the rate a pure MFMA + LDS-read loop holds on this part
-                  under its power-managed clock, profiles/r01_ubench_mfma_clock.md -- information, not `peak`).
+                  HBM byte count of the committed rocprofv3 --pmc pass, profiles/r03_pmc_avatar.md;
+                  `clock_mhz` = s_memtime cycles of the timed launches / their device time = the clock the chip held in THIS run;
+                  `sustained_mfma_tflops_measured` is the rate a pure MFMA + LDS-read loop of full-entropy operands holds on this
+                  part at its power cap, profiles/r03_power_wall.md -- information, not `peak`).
   cpu_baseline -- the CPU restatements of oracle/ (the query on stock PyTorch CPU ops with identical weights on all host
                   cores, C marching cubes, NumPy LBS) timed on a bounded sample and scaled to one 256^3 frame.
   configs      -- BASELINE configs[2] (AvatarCap full: avatar + canonical normal fusion, 100 iterations + HGFilter + reconstruction query, the
@@ -52,9 +53,10 @@ FLOP_PER_POINT = 1_773_568          # warp 428,288 + shared 425,472 + geo 33,024
 MFMA_ISSUED_PER_POINT = 4728 * 32 * 32 * 16 * 2 / 32   # 4728 v_mfma_f32_32x32x16_f16 per 32 points (3 split passes, tile padding, shared.6 folded
                                                         # into geo.0, the 64 feature columns of conv1 / conv5 folded per grid column: DESIGN.md section 2)
 PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
-SUSTAINED_F16_TFLOPS = 1673.0      # what this part sustains on split-fp16 MFMAs fed from LDS once its clock manager has
-                                    # settled (1.6 GHz, pipe 99 % busy): profiles/r01_ubench_mfma_clock.md -- information only
-HBM_TRAFFIC_BYTES_256 = 0.512e9     # per dense 256^3 launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc (profiles/r02_pmc_avatar.md):
+SUSTAINED_F16_TFLOPS = 1505.0      # what this part sustains at its power cap on split-fp16 MFMAs of FULL-ENTROPY operands fed from LDS, nothing else in
+                                    # the instruction stream (1.47 GHz): tools/ubench/mfma_order.hip, profiles/r03_power_wall.md -- information only
+                                    # (round 1's 1673 was measured on low-entropy operands)
+HBM_TRAFFIC_BYTES_256 = 0.510e9     # per dense 256^3 launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc (profiles/r03_pmc_avatar.md: 356 + 154 MB):
                                     # 67.1 MB of occupancy written (exact), the feature map per XCD, what share of the weight stream left L2, and the
                                     # per-column table of the column-folded launch (131 MB written by the column pass, read back 2 KB per tile);
                                     # round 1's 1.98e9 also read 201 MB of points and wrote 201 MB of offsets nobody reads
@@ -312,7 +314,7 @@ def main():
                        'dense_points': 'generated from the grid index (avc_avatar_query_grid), offsets not written'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_TFLOPS,
-                         'traffic': HBM_TRAFFIC_BYTES_256 if res == 256 else None, 'traffic_source': 'profiles/r02_pmc_avatar.md (FETCH_SIZE x2 + WRITE_SIZE)',
+                         'traffic': HBM_TRAFFIC_BYTES_256 if res == 256 else None, 'traffic_source': 'profiles/r03_pmc_avatar.md (FETCH_SIZE x2 + WRITE_SIZE; collected by rocprofv3 --pmc, not in this run)',
                          'kernel': 'avc::avatar_kernel<true,false,1> (+ its column_terms_kernel pass, timed together)', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
                          'shader_cycles_per_launch': avg_cyc.value, 'clock_mhz': (avg_cyc.value / (avg_ms.value * 1e3)) if avg_ms.value > 0 else 0.0,
                          'cycles_per_mfma': avg_cyc.value / (4728 * (N / 128 / min(N // 128, torch.cuda.get_device_properties(device).multi_processor_count))) if avg_cyc.value > 0 else 0.0,

@@ -105,7 +105,7 @@ int avc_avatar_query(avc_ctx *ctx, const float *pts_dev, int64_t n, const float 
  * bit-identical to the reference's.  Outputs as above; offset_out_dev may be NULL (main.py:360-364 never reads it).
  * When R_z is a multiple of 128 the launch is column-folded: the 64 pose-feature columns of the warping field's conv1 / conv5 enter as one fp32
  * vector per (x, y) column instead of per point (same algebra, other rounding: a few 1e-6 from avc_avatar_query on the same points, which an
- * unfolded launch -- any other R_z, or AVC_NO_FOLD=1 in the environment -- reproduces bit for bit).  Scratch: 2 KB per column in the context. */
+ * unfolded launch -- any other R_z, or avc_set_option "column_fold" 0 -- reproduces bit for bit).  Scratch: 2 KB per column in the context. */
 int avc_avatar_query_grid(avc_ctx *ctx, const float *axis_x_dev, const float *axis_y_dev, const float *axis_z_dev,
                           const int32_t res[3], const float center[3], int occupancy_sigmoid,
                           float *occ_out_dev, float *offset_out_dev, avc_stream stream);
@@ -113,7 +113,7 @@ int avc_avatar_query_grid(avc_ctx *ctx, const float *axis_x_dev, const float *ax
 /* The query on a SUBSET of that grid -- the valid band of the reference's test loop (avatarcap_dataset.py:114-116: infer_pts = vol_pts[infer_pts_flag],
  * queried at main.py:360) -- given as `n` flat grid indices (index_dev[k] = x*Ry*Rz + y*Rz + z, int32, any order): output k belongs to grid point
  * index_dev[k], coordinates as in avc_avatar_query_grid.  The launch is column-folded like a dense one (each point takes its column's vector), so it agrees
- * with avc_avatar_query on the same points to a few 1e-6 (bit for bit with AVC_NO_FOLD=1), and the 12 bytes per point of coordinates are never read. */
+ * with avc_avatar_query on the same points to a few 1e-6 (bit for bit with "column_fold" 0), and the 12 bytes per point of coordinates are never read. */
 int avc_avatar_query_grid_subset(avc_ctx *ctx, const float *axis_x_dev, const float *axis_y_dev, const float *axis_z_dev,
                                  const int32_t res[3], const int32_t *index_dev, int64_t n, const float center[3],
                                  int occupancy_sigmoid, float *occ_out_dev, float *offset_out_dev, avc_stream stream);
