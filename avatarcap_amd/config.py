@@ -30,6 +30,10 @@ cfg = dict()           # configurations from the yaml file (config.py:25)
 # 'numeric range'); a query then synchronises and raises AvcapError (AVC_ERR_RANGE) instead of returning silently wrong values
 check_range = False
 
+# not in the reference: ReconNetwork.get_feat_maps replays the HGFilter encoder as a hipGraph (one launch per frame instead of ~200; same kernels, same
+# bits); False keeps the eager launches
+hg_graph = True
+
 
 def load_config(path):
     import yaml

@@ -25,10 +25,49 @@ class ReconNetwork(nn.Module):
         self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, '_packed_version', None))
 
     def get_feat_maps(self, image):
+        """`self.image_encoder(image)[0]` (arch_recon.py:52-53).  On the HIP device the encoder's ~200 launches per frame (MIOpen convolutions, the fused
+        GroupNorm op, bicubic up-sampling, adds / cats: ~5 ms of kernels that the host needs ~8 ms to enqueue) are recorded ONCE per input shape and set
+        of weights as a hipGraph (torch.cuda.CUDAGraph) and replayed with one launch per frame: the same kernels on the same arguments -- results are bit
+        for bit those of the eager call (tests/test_gpu_producers.py).  `config.hg_graph = False` keeps the eager launches."""
         from .unets import deterministic_convs
+        from .. import config
+        if image.is_cuda and getattr(config, 'hg_graph', True) and not torch.is_grad_enabled():
+            out = self._graph_feat_maps(image)
+            if out is not None:
+                return out
         with deterministic_convs():              # bit-identical feature maps from call to call (see unets.deterministic_convs)
             feat_maps, _ = self.image_encoder(image)
         return feat_maps
+
+    def _graph_feat_maps(self, image):
+        from .unets import deterministic_convs
+        key = (tuple(image.shape), image.dtype, image.device, tuple(p._version for p in self.image_encoder.parameters()),
+               tuple(p.data_ptr() for p in self.image_encoder.parameters()))
+        g = getattr(self, '_hg_graph', None)
+        if g is None or g['key'] != key:
+            if getattr(self, '_hg_graph_failed', None) == key:
+                return None
+            try:
+                static_in = image.detach().clone()
+                side = torch.cuda.Stream(device=image.device)
+                side.wait_stream(torch.cuda.current_stream(image.device))
+                with torch.cuda.stream(side), deterministic_convs():
+                    for _ in range(2):          # MIOpen's solution search, workspace and the GroupNorm op's scratch: all settled before the capture
+                        self.image_encoder(static_in)
+                torch.cuda.current_stream(image.device).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with deterministic_convs(), torch.cuda.graph(graph):
+                    feat_maps, _ = self.image_encoder(static_in)
+                g = self._hg_graph = {'key': key, 'graph': graph, 'in': static_in, 'out': feat_maps}
+            except Exception as e:              # noqa: BLE001 -- a capture the runtime refuses falls back to the eager launches of the same kernels, once, loudly
+                import warnings
+                warnings.warn(f'HGFilter: hipGraph capture failed ({type(e).__name__}: {e}); launching eagerly')
+                self._hg_graph_failed = key
+                self._hg_graph = None
+                return None
+        g['in'].copy_(image)
+        g['graph'].replay()
+        return [t.clone() for t in g['out']]       # the graph's output buffers are rewritten by the next replay
 
     def _ctx(self, device):
         ctx = _lib.ctx(device)

@@ -77,3 +77,33 @@ def test_recon_infer_end_to_end_at_512(golden):
         e = maxabs(y.cpu().numpy(), gold)
         print(f'ReconNetwork.infer ({res}^2 maps) vs reference (CPU): {e:.3e}')
         assert e < 1e-4
+
+
+def test_hgfilter_graph_replay_equals_eager_launches():
+    """ReconNetwork.get_feat_maps replays the encoder as a hipGraph (config.hg_graph): the same kernels on the same arguments -- the feature map is bit
+    for bit the eager call's, for a second input through the same graph, after new weights (re-capture), and the replay really is taken."""
+    from avatarcap_amd import config
+    from avatarcap_amd.network.arch_recon import ReconNetwork
+    rn = ReconNetwork().to('cuda').eval()
+    syn.load_synth(rn, gi.SEED_NET)
+    a, b = _t(gi.normal_maps(512, seed=78)[None]), _t(gi.normal_maps(512, seed=79)[None])
+    with torch.no_grad():
+        config.hg_graph = False
+        try:
+            ea, eb = rn.get_feat_maps(a)[-1].clone(), rn.get_feat_maps(b)[-1].clone()
+        finally:
+            config.hg_graph = True
+        ga = rn.get_feat_maps(a)[-1]
+        assert rn._hg_graph is not None and getattr(rn, '_hg_graph_failed', None) is None          # captured, not fallen back
+        gb = rn.get_feat_maps(b)[-1]
+        assert torch.equal(ga, ea) and torch.equal(gb, eb)
+        assert torch.equal(rn.get_feat_maps(a)[-1], ea) and ga.data_ptr() != rn.get_feat_maps(a)[-1].data_ptr()   # fresh tensors, not the graph's buffers
+        key = rn._hg_graph['key']
+        syn.load_synth(rn, gi.SEED_NET + 3)                                                          # new weights: the graph is recorded again
+        gc = rn.get_feat_maps(a)[-1]
+        assert rn._hg_graph['key'] != key and not torch.equal(gc, ea)
+        config.hg_graph = False
+        try:
+            assert torch.equal(rn.get_feat_maps(a)[-1], gc)
+        finally:
+            config.hg_graph = True
