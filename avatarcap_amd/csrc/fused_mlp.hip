@@ -447,7 +447,7 @@ struct BiasDirect {
     __device__ __forceinline__ void rewind(const float *, unsigned = 0) {}
 };
 // The queue's loads are BUFFER loads: resource built from the (wave-uniform) block pointer, one per-lane byte offset register that never changes
-// (16 h, plus the lane's column row in BiasQueueLane) and immediates.  The flat form `global_load_dwordx4 v, v_off, s[base:base+1]` of round 2 had its
+// (16 h) and immediates.  The flat form `global_load_dwordx4 v, v_off, s[base:base+1]` of round 2 had its
 // address registers parked in AGPRs by the allocator and read back in front of every load: two v_accvgpr_read per load, ~900 per point tile.
 // (declared as the LLVM intrinsic itself: hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128 selects a ONE-dword load for the 128-bit result)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -492,31 +492,6 @@ struct BiasQueue {
     __device__ __forceinline__ f32x16 tile_at(int t) const { return bias_tile_buf(bias_rsrc(next), hoff, 128 * t); }
     __device__ __forceinline__ void skip(int nfloats) { next += nfloats; }
 };
-// The same queue when a block may come from a table indexed PER LANE (column-folded launches over a subset of the grid: the 32 points of a wave
-// lie in whatever columns the valid band gives them): `lane` is added to every address of the current block, 0 for the layer table.
-struct BiasQueueLane {
-    const float *next;
-    unsigned hoff;
-    unsigned lane;           // byte offset of this lane's row of the per-column table (0: the layer table)
-    f32x16 nb[2];
-    __device__ __forceinline__ void fetch(int)
-    {
-        const i32x4 rs = bias_rsrc(next);
-        const unsigned v = hoff + lane;
-        nb[0] = bias_tile_buf(rs, v, 0); nb[1] = bias_tile_buf(rs, v, 128);
-    }
-    __device__ __forceinline__ void take(f32x16 *acc, int ntiles, int)
-    {
-        acc[0] = nb[0];
-        if (ntiles > 1) acc[1] = nb[1];
-        next += 32 * ntiles;
-    }
-    __device__ __forceinline__ void after_barrier(int h) { fetch(h); }
-    __device__ __forceinline__ void rewind(const float *head, unsigned lane_off = 0) { next = head; lane = lane_off; }
-    __device__ __forceinline__ f32x16 tile_at(int t) const { return bias_tile_buf(bias_rsrc(next), hoff + lane, 128 * t); }
-    __device__ __forceinline__ void skip(int nfloats) { next += nfloats; }
-};
-
 // max(x, 0) as a signed-integer max on the bit pattern (negative floats are negative integers; -0 and negative NaNs -> +0): one v_max_i32 with an
 // inline constant.  fmaxf() would put a canonicalising v_max_f32 in front, and an inline-asm v_max_f32 (round 2) is opaque to the hazard recogniser,
 // which then pads every use of a transcendental result behind it with an s_nop.
@@ -967,8 +942,113 @@ __global__ __launch_bounds__(256) void column_terms_kernel(const float *__restri
     }
 }
 
-// FOLD: 0 = point by point; 1 = column-folded dense grid (every tile in one column: wave-uniform column blocks); 2 = column-folded SUBSET of the
-// grid (p.gidx, the valid band: the 32 points of a wave lie in whatever columns they lie, their column blocks are gathered per lane)
+
+// ---- column terms of a SUBSET launch (FOLD == 2): several columns in a wave ------------------------------------------------------------------
+// The 32 points of a wave lie in whatever (x, y) columns the valid band gives them; a band's runs along z keep a wave inside one or two.  The wave's
+// points are cut into RUNS of equal adjacent columns (a column met twice is two runs: no ordering is assumed).  conv1's and conv5's accumulators are
+// INITIALISED by one MFMA per tile: run r owns a pair of K slots; the A fragment holds, at that pair, its column's term of the tile's row split into
+// fp16 halves (c_hi, c_lo), the B fragment 1.0 at the pair for exactly the lanes whose point belongs to the run -- D = c_hi + c_lo, an exact fp32 sum,
+// for those points and 0 for the others, whatever pair the run got: a point's value does not depend on which points share its launch.  Six pairs per
+// pass (slots 4..7 of the lanes h == 0, 8..15 of the lanes h == 1); a wave with more than six runs repeats the MFMA with the next six.  A lane fetches
+// four floats per tile (256-byte wave-instructions).  Round 2 gathered a per-lane accumulator init instead: four `dwordx4` of 64 distinct addresses per
+// tile through the texture path -- 3.9 ns per point against the dense launch's 3.4.
+constexpr int SEG_PER_PASS = 6;
+struct ColSegs {
+    unsigned long long first;    // lanes 0..31: first point of a run
+    unsigned nseg;               // runs in the wave (1..32)
+    unsigned seg;                // the run of this lane's point
+    unsigned col;                // this lane's column
+};
+__device__ __forceinline__ ColSegs col_segments(unsigned col, int j, int h)
+{
+    ColSegs c;
+    c.col = col;
+    const unsigned prev = (unsigned)__shfl_up((int)col, 1, 32);
+    const bool first = (j == 0) || (prev != col);
+    c.first = __builtin_amdgcn_ballot_w64(first && h == 0) & 0xffffffffull;
+    c.nseg = (unsigned)__builtin_popcountll(c.first);
+    c.seg = (unsigned)__builtin_popcountll(c.first & ((2ull << j) - 1ull)) - 1u;
+    return c;
+}
+// what pass `pass` needs: the B-side ones of this lane (dword d of the fragment: 0x3C003C00 where the lane's run owns pair d of its half) and, per
+// dword, the byte offset of the owning run's column in the table (512 floats per column; runs beyond the last: run 0's column, with no ones)
+struct SegPass { u32x4 ones; unsigned colbyte[4]; };
+__device__ __forceinline__ SegPass seg_pass(const ColSegs &c, unsigned pass, int h)
+{
+    unsigned long long rest = c.first;
+    for (unsigned n = 0; n < pass * SEG_PER_PASS; ++n) rest &= rest - 1ull;
+    unsigned colr[SEG_PER_PASS];
+#pragma unroll
+    for (int i = 0; i < SEG_PER_PASS; ++i) {
+        const int pos = rest ? __builtin_ctzll(rest) : 0;
+        colr[i] = (unsigned)__builtin_amdgcn_readlane((int)c.col, pos);
+        rest &= rest - 1ull;
+    }
+    SegPass sp;
+    const unsigned mine = c.seg - pass * SEG_PER_PASS;        // this lane's run as a pair of this pass (>= 6, incl. wrapped: none)
+    // pair i -> (half, dword): 0, 1 -> h == 0 dwords 2, 3 (slots 4..7); 2..5 -> h == 1 dwords 0..3 (slots 8..15)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const unsigned pair = h ? (unsigned)(d + 2) : (d >= 2 ? (unsigned)(d - 2) : 99u);
+        sp.ones[d] = (mine == pair) ? 0x3C003C00u : 0u;
+        sp.colbyte[d] = (h ? colr[d + 2] : colr[d >= 2 ? d - 2 : 0]) * 2048u;
+    }
+    return sp;
+}
+__device__ __forceinline__ unsigned seg_patch_word(float c)     // (c_hi | c_lo << 16)
+{
+    const _Float16 hi = (_Float16)c, lo = (_Float16)(c - (float)hi);
+    const half2_t hv = {hi, lo};
+    return __builtin_bit_cast(unsigned, hv);
+}
+// the four floats a lane needs for tile `t` of a pass: rows row0 + 32 t + j of the columns owning its dwords
+__device__ __forceinline__ void seg_fetch(const SegPass &sp, const i32x4 &rs, int j, int row, float *c4)
+{
+#pragma unroll
+    for (int d = 0; d < 4; ++d) c4[d] = raw_buffer_load_f32(rs, (int)(sp.colbyte[d] + 4u * (unsigned)(row + j)), 0, 0);
+}
+__device__ __forceinline__ f32x16 seg_mfma(const float *c4, const SegPass &sp, int h, f32x16 acc)
+{
+    const u32x4 a = {h ? seg_patch_word(c4[0]) : 0u, h ? seg_patch_word(c4[1]) : 0u, seg_patch_word(c4[2]), seg_patch_word(c4[3])};
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, sp.ones), acc, 0, 0, 0);
+}
+// accumulator init of NT tiles starting at table row `row0` (floats; the layer's offset included): pass 0 from floats requested ahead (`c0`), the
+// passes of a wave with more than six runs fetched here
+template <int NT>
+__device__ __forceinline__ void seg_init(const ColSegs &c, const SegPass &sp0, const float (*c0)[4], const i32x4 &rs, int j, int h, int row0, f32x16 *acc)
+{
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+        acc[t] = seg_mfma(c0[t], sp0, h, z);
+    }
+    const unsigned npass = (c.nseg + SEG_PER_PASS - 1) / SEG_PER_PASS;
+    for (unsigned pass = 1; pass < npass; ++pass) {
+        const SegPass sp = seg_pass(c, pass, h);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float c4[4];
+            seg_fetch(sp, rs, j, row0 + 32 * t, c4);
+            acc[t] = seg_mfma(c4, sp, h, acc[t]);
+        }
+    }
+}
+// the Bias interface of dense() for a layer initialised this way
+struct BiasSegs {
+    const ColSegs *c; const SegPass *sp0; const float (*c0)[4]; i32x4 rs; int j, h, row;      // c0: pass-0 floats of the layer's tiles, row: next tile's table row
+    __device__ __forceinline__ void take(f32x16 *acc, int ntiles, int)
+    {
+        seg_init<2>(*c, *sp0, c0, rs, j, h, row, acc);          // (dense() takes tile pairs)
+        c0 += ntiles; row += 32 * ntiles;
+    }
+    __device__ __forceinline__ void after_barrier(int) {}
+    __device__ __forceinline__ void rewind(const float *, unsigned = 0) {}
+};
+
+// FOLD: 0 = point by point; 1 = column-folded dense grid (every tile in one column: wave-uniform column blocks as accumulator init); 2 = column-folded
+// SUBSET of the grid (p.gidx, the valid band: the 32 points of a wave lie in whatever columns they lie; accumulator init by runs of columns, ColSegs)
 template <bool WARP, bool COLOUR, int FOLD = 0>
 __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
 {
@@ -980,16 +1060,16 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
 
     const long long tk0 = clock64();
     Stream s = stream_init(p, wave, lane, B_FIRST);
-    using BiasQ = std::conditional_t<FOLD == 2, BiasQueueLane, BiasQueue>;
+    using BiasQ = BiasQueue;
     BiasQ bias;
     bias.hoff = 16u * h;
     const unsigned tiles_per_col = FOLD == 1 ? p.grz / TILE_PTS : 1u;
-    float pt_next[3];                    // FOLD == 2: the next tile's point is loaded a tile ahead (its column decides where the bias queue continues)
+    float pt_next[3];                    // FOLD == 2: the next tile's point is loaded a tile ahead
     unsigned col_next = 0;
     if constexpr (FOLD == 2) {
         const int64_t i0 = (int64_t)blockIdx.x * TILE_PTS + wave * 32 + j;
         col_next = load_point(p, i0 < p.n ? i0 : p.n - 1, pt_next);
-        bias.rewind(p.colterms, col_next * 2048u);
+        bias.rewind(p.bias + 256);           // conv1's column terms ride its k-step: the queue starts at conv2's block
     } else {
         bias.rewind(FOLD == 1 ? p.colterms + (size_t)(blockIdx.x / tiles_per_col) * 512 : p.bias);
     }
@@ -1024,7 +1104,7 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         asm volatile("" : "+v"(park));   // opaque per tile: otherwise every park address is hoisted out of the loop as its own VGPR
         f32x16 pa[2], pb[2];             // deferred accumulators of a layer's last tile pair (ping/pong)
         f32x16 w8[8];                    // the eight accumulators of a wide layer (conv1 of a folded launch, shared.0)
-        if constexpr (WARP && FOLD != 0) wide_bias_early(bias, w8);      // conv1's column blocks, tiles 2 .. 7: in flight during the prologue
+        if constexpr (WARP && FOLD == 1) wide_bias_early(bias, w8);      // conv1's column blocks, tiles 2 .. 7: in flight during the prologue
         const float *bias_head = p.bias;
         asm volatile("" : "+s"(bias_head));   // opaque per tile: keeps bias addresses from being hoisted out of the loop
         unsigned head_lane = 0;              // FOLD == 2: the next tile's per-lane row of the column table
@@ -1044,6 +1124,17 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
                 if (h == 0) { z[0] = pt[0]; z[1] = pt[1]; z[2] = pt[2]; }
                 split8(z, S4.hi, S4.lo, s.range);
             }
+            // FOLD == 2: the wave's runs of columns; conv1's column terms of the first six runs requested
+            ColSegs segs{};
+            SegPass sp0{};
+            float c1[8][4], c5[8][4];
+            const i32x4 crs = bias_rsrc(p.colterms);
+            if constexpr (FOLD == 2) {
+                segs = col_segments(col, j, h);
+                sp0 = seg_pass(segs, 0, h);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) seg_fetch(sp0, crs, j, 32 * t, c1[t]);
+            }
             const ParkIn S{park, &S4};
             const RegIn RX{X}, RY{Y}, R4{&S4};
 #if AVC_DBG_TIMING
@@ -1059,12 +1150,16 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
                     col5 = p.colterms + (size_t)(tile / tiles_per_col) * 512 + 256;
                     const int64_t nt = tile + gridDim.x < p.ntiles ? tile + gridDim.x : p.ntiles - 1;
                     bias_head = p.colterms + (size_t)(nt / tiles_per_col) * 512;                                           // where the next tile starts
+                    asm volatile("" : "+s"(after1), "+s"(col5), "+s"(after5), "+s"(bias_head));
+                    wide8<1, B_MAIN>(s, R4, w8, bias, h, after1);                                                                   // conv1+bn1 on xyz (+ column term)
                 } else {
-                    col5 = p.colterms + 256; lane5 = col * 2048u;
-                    bias_head = p.colterms; head_lane = col_next * 2048u;
+                    // column terms in the k-step (ColSegs): accumulators start at zero, the bias queue never sees conv1 / conv5
+                    col5 = after5;                   // conv4's last pair sends the queue to conv6's block
+                    bias_head = after1;              // ... and the last head to conv2's: where the next tile starts
+                    asm volatile("" : "+s"(after1), "+s"(col5), "+s"(after5), "+s"(bias_head));
+                    seg_init<8>(segs, sp0, c1, crs, j, h, 0, w8);
+                    chunk<1, 8, B_MAIN>(s, R4, w8, NoSide{});                 // (the queue already holds conv2's first block: nothing to request here)
                 }
-                asm volatile("" : "+s"(after1), "+s"(col5), "+s"(after5), "+s"(bias_head));
-                wide8<1, B_MAIN>(s, R4, w8, bias, h, after1);                                                                       // conv1+bn1 on xyz (+ column term)
                 flush<ACT_SOFTPLUS>(w8, X, s.range);
                 dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, PendWide<ACT_SOFTPLUS>{w8, X, &s.range}, pb);         // conv2 (+ conv1's pairs 1 .. 3)
             } else {
@@ -1072,7 +1167,14 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
                 dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                    // conv2
             }
             dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RY, RY, X, bias, h, SP{pb, Y + 12, &s.range}, pa);                        // conv3
-            if constexpr (FOLD != 0) {
+            if constexpr (FOLD == 2) {
+                // conv5's column terms of the first six runs: requested here, in flight during conv4
+#pragma unroll
+                for (int t = 0; t < 8; ++t) seg_fetch(sp0, crs, j, 256 + 32 * t, c5[t]);
+                dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5F>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5, 0);         // conv4
+                BiasSegs b5{&segs, &sp0, c5, crs, j, h, 256};
+                dense<8, 16, 1, ACT_SOFTPLUS, B_MAIN>(s, RY, R4, X, b5, h, SP{pb, Y + 12, &s.range}, pa);                      // conv5 on [xyz | x4]
+            } else if constexpr (FOLD == 1) {
                 dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5F>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5, lane5);     // conv4
                 dense<8, 16, 1, ACT_SOFTPLUS, B_MAIN>(s, RY, R4, X, bias, h, SP{pb, Y + 12, &s.range}, pa, after5);            // conv5 on [xyz | x4] (+ column term)
             } else {

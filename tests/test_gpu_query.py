@@ -133,6 +133,34 @@ def test_avatar_query_large_preactivations(net):
     assert maxabs(out['cano_pts_ov'][0].cpu().numpy(), occ) < 1e-4
 
 
+@pytest.mark.parametrize('per_col', [5, 6, 11, 32, 45])
+def test_grid_subset_query_runs_per_wave(net, per_col):
+    """The band's column terms ride the xyz k-step, six RUNS of equal adjacent columns per pass (fused_mlp.hip: ColSegs): `per_col` points of every column
+    in grid order put 32 / per_col runs into a wave -- 7 (one more than a pass holds), 6, 3 - 4, 1 - 2 (a band), 1 --, a column met again later is a second
+    run, and a ragged tail.  Folded vs point-by-point vs the oracle."""
+    from avatarcap_amd.network.arch_avatar import OccupancyNet
+    from avatarcap_amd.grid import generate_volume_points_np, volume_axes
+    from oracle import avatarcap_oracle as orc
+    config.if_type = 'sdf'
+    res = (6, 7, 48)
+    fmap = gi.pose_feat_map()
+    net.warping_field.pose_feat_map = _t(fmap[None])
+    allp = generate_volume_points_np(syn.CANO_BOUNDS, res)
+    base = (np.arange(res[0] * res[1])[:, None] * res[2] + np.arange(per_col)[None, :] + 1).reshape(-1)
+    idx = np.concatenate([base, base[:77] + 1 if per_col < 45 else base[:77]]).astype(np.int32)[:-3]      # some columns come back as later runs; ragged count
+    pts = allp[idx]
+    index = torch.from_numpy(idx).cuda()
+    ax = volume_axes(syn.CANO_BOUNDS, res, 'cuda')
+    a = OccupancyNet(net).query(_batch(pts))
+    g = OccupancyNet(net).query_grid(_batch(pts), ax, res, want_offset=True, index=index)
+    d_occ, d_off = maxabs(g['cano_pts_ov'].cpu().numpy(), a['cano_pts_ov'].cpu().numpy()), maxabs(g['nonrigid_offset'].cpu().numpy(), a['nonrigid_offset'].cpu().numpy())
+    print(f'{per_col} points per column: folded subset vs point-by-point: occupancy {d_occ:.2e}, offsets {d_off:.2e}')
+    assert 0 < d_occ < 2e-5 and d_off < 2e-5
+    ref = orc.occupancy_query(pts, fmap, gi.center(), geotex_sd())
+    assert maxabs(g['cano_pts_ov'][0].cpu().numpy(), ref['cano_pts_ov']) < TOL and maxabs(g['nonrigid_offset'][0].cpu().numpy(), ref['nonrigid_offset']) < TOL
+    assert torch.equal(OccupancyNet(net).query_grid(_batch(pts), ax, res, index=index)['cano_pts_ov'], g['cano_pts_ov'])       # deterministic
+
+
 @pytest.mark.parametrize('res', [(4, 6, 128), (3, 5, 256), (5, 4, 50)])
 def test_recon_grid_query(res):
     """avc_recon_query_grid: the decoder on the dense grid without the point array.  A last axis of a multiple of 128 points is column-folded (the 32
