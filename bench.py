@@ -398,7 +398,7 @@ def other_configs(device, frames=3):
                          'valid_points': int(ds.infer_pts.shape[0]), 'ms_per_frame': full_ms, 'frames_per_s': 1e3 / full_ms,
                          'stage_ms': {'avatar_frame (unet + band query + mc + lbs)': t_av, 'normal maps + fusion': t_fu,
                                       'recon_frame (hgfilter + band query + mc + lbs)': t_re, 'of which hgfilter': t_hg},
-                         'kernel_ms': {'avatar query (band, column-folded)': q[0][0].value, 'recon query (band, column-folded)': q[1][0].value},
+                         'kernel_ms': {'avatar query (band, column-folded)': q[0][0].value, 'recon query (band, point by point on generated coordinates)': q[1][0].value},
                          'avatar_vertices': int(a['cano_v'].shape[0]), 'recon_vertices': int(r['cano_v'].shape[0])}
     del ds, pipe, items, a, r, obs, fm, it, imgs
     torch.cuda.empty_cache()

@@ -455,3 +455,40 @@ def test_two_networks_on_one_device_keep_their_own_weights():
     assert not torch.equal(ys[0], ys[1])
     for rn, ref in zip(rns, ys):
         assert torch.equal(rn.decode(_t(pts[None]), imap, _t(gi.center()[None])), ref)
+
+
+def test_context_options_and_launch_clock(net):
+    """avc_set_option: unknown names and out-of-range values are AVC_ERR_ARG (nothing is read from the environment after avc_ctx_create);
+    avc_timing_read_cycles: the shader cycles of the timed launches divided by their device time is a plausible gfx950 shader clock."""
+    import ctypes as C
+    from avatarcap_amd.network.arch_avatar import OccupancyNet
+    from avatarcap_amd.grid import volume_axes
+    ctx = _lib.ctx(torch.device('cuda', 0))
+    for name, value in (('no_such_option', 1), ('column_fold', 2), ('knn_search', 4), ('mlp_blocks', -1), ('fusion_graph', 7)):
+        with pytest.raises(_lib.AvcapError) as e:
+            _lib.set_option(name, value)
+        assert e.value.status == -1
+    for name, value in (('column_fold', 1), ('knn_search', 0), ('mlp_blocks', 0), ('fusion_graph', 1)):
+        _lib.set_option(name, value)
+    res = (8, 8, 128)
+    net.warping_field.pose_feat_map = _t(gi.pose_feat_map()[None])
+    batch = {'cano_smpl_center': _t(gi.center()[None])}
+    ax = volume_axes(syn.CANO_BOUNDS, res, 'cuda')
+    q = OccupancyNet(net)
+    q.query_grid(batch, ax, res); torch.cuda.synchronize()
+    _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
+    for _ in range(3):
+        full = q.query_grid(batch, ax, res)
+    _lib.set_option('mlp_blocks', 16)                       # fewer persistent workgroups: same bits
+    few = q.query_grid(batch, ax, res)
+    _lib.set_option('mlp_blocks', 0)
+    torch.cuda.synchronize()
+    ms, nl, cyc, nc = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
+    _lib.check(_lib.lib().avc_timing_read(ctx, 0, C.byref(ms), C.byref(nl), 1))
+    _lib.check(_lib.lib().avc_timing_read_cycles(ctx, 0, C.byref(cyc), C.byref(nc)))
+    _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
+    assert nl.value == 4 and nc.value == 4 and ms.value > 0
+    mhz = cyc.value / (ms.value * 1e3)
+    print(f'launch clock: {cyc.value:.3e} cycles / {ms.value:.3f} ms = {mhz:.0f} MHz')
+    assert 500 < mhz < 3000                                 # (the column pass is inside the event pair, not inside the cycle count: a lower bound of the clock)
+    assert torch.equal(full['cano_pts_ov'], few['cano_pts_ov'])
