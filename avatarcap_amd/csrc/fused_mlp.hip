@@ -91,7 +91,6 @@ constexpr int TILE_PTS = 32 * WAVES;
 constexpr int PARK_BASE = 2 * layout::SLOT_BYTES;     // per-wave 8 KiB: 4 input k-steps parked in LDS (see ParkIn)
 constexpr int PARK_PER_WAVE = 4 * layout::UNIT_BYTES;
 constexpr int LDS_BYTES = PARK_BASE + WAVES * PARK_PER_WAVE;   // 128 KiB weight ring + 32 KiB = the whole 160 KiB
-constexpr int PIECE = WAVES * 1024;          // chunk sizes are multiples of this
 
 constexpr int chunk_bytes(int ks, int tpc) { return ks * tpc * layout::UNIT_BYTES; }
 
@@ -444,7 +443,7 @@ struct BiasDirect {
         p += 32 * ntiles;
     }
     __device__ __forceinline__ void after_barrier(int) {}
-    __device__ __forceinline__ void rewind(const float *, unsigned = 0) {}
+    __device__ __forceinline__ void rewind(const float *) {}
 };
 // The queue's loads are BUFFER loads: resource built from the (wave-uniform) block pointer, one per-lane byte offset register that never changes
 // (16 h) and immediates.  The flat form `global_load_dwordx4 v, v_off, s[base:base+1]` of round 2 had its
@@ -487,7 +486,7 @@ struct BiasQueue {
         next += 32 * ntiles;
     }
     __device__ __forceinline__ void after_barrier(int h) { fetch(h); }
-    __device__ __forceinline__ void rewind(const float *head, unsigned = 0) { next = head; }
+    __device__ __forceinline__ void rewind(const float *head) { next = head; }
     // tile `t` of the current block's layer, loaded directly (wide layers: tiles 2..7 are requested early, tiles 0 / 1 come through the queue)
     __device__ __forceinline__ f32x16 tile_at(int t) const { return bias_tile_buf(bias_rsrc(next), hoff, 128 * t); }
     __device__ __forceinline__ void skip(int nfloats) { next += nfloats; }
@@ -623,7 +622,7 @@ struct NoPairPatch { template <class P, class T> __device__ __forceinline__ half
 template <int NT, int KS0, int KS1, int ACT, int NEXT_BYTES, class In0, class In1, class Bias, class Pre, class PP = NoPairPatch>
 __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
                                       Frag *__restrict__ out, Bias &bias, int h,
-                                      Pre &&pre, f32x16 *__restrict__ pend, const float *jump = nullptr, unsigned jump_lane = 0, PP &&ppatch = PP{})
+                                      Pre &&pre, f32x16 *__restrict__ pend, const float *jump = nullptr, PP &&ppatch = PP{})
 {
     // `ppatch(pair, tile, a_hi)`: A-fragment patch of the FIRST k-step of the second segment (see chunk())
     // `jump`: where the bias blocks continue after this layer's last pair, when not at the following block of the table (column-folded
@@ -639,7 +638,7 @@ __device__ __forceinline__ void dense(Stream &s, const In0 &in0, const In1 &in1,
         constexpr int p = decltype(pc)::value;
         f32x16 acc[2];
         bias.take(acc, 2, h);
-        if constexpr (p == NPAIR - 1) { if (jump) bias.rewind(jump, jump_lane); }
+        if constexpr (p == NPAIR - 1) { if (jump) bias.rewind(jump); }
         constexpr int afterA = KB > 0 ? BB : (p + 1 < NPAIR ? BA : NEXT_BYTES);
         chunk<KA, 2, afterA>(s, in0, acc, [&](auto kc, auto rc) {
             if constexpr (decltype(kc)::value == 0 && decltype(rc)::value == 5) bias.after_barrier(h);
@@ -688,11 +687,11 @@ __device__ __forceinline__ void wide_bias_early(const Bias &bias, f32x16 *acc8)
     for (int t = 2; t < 8; ++t) acc8[t] = bias.tile_at(t);
 }
 template <int KS, int NEXT_BYTES, class In, class Bias>
-__device__ __forceinline__ void wide8(Stream &s, const In &in, f32x16 *__restrict__ acc8, Bias &bias, int h, const float *jump = nullptr, unsigned jump_lane = 0)
+__device__ __forceinline__ void wide8(Stream &s, const In &in, f32x16 *__restrict__ acc8, Bias &bias, int h, const float *jump = nullptr)
 {
     bias.take(acc8, 2, h);
     bias.skip(192);
-    if (jump) bias.rewind(jump, jump_lane);
+    if (jump) bias.rewind(jump);
     chunk<KS, 8, NEXT_BYTES>(s, in, acc8, [&](auto qc, auto rc) {
         if constexpr (decltype(qc)::value == 0 && decltype(rc)::value == 5) bias.after_barrier(h);
     });
@@ -709,12 +708,12 @@ __device__ __forceinline__ void flush(const f32x16 *__restrict__ pend, Frag *__r
 // one-tile linear head (rows 0..31 of which only the first few are real): the three products of a
 // k-step go to three accumulators, so no MFMA depends on its predecessor.  Same slot structure as chunk().
 template <int KS, int NEXT_BYTES, bool LAST, class Bias, class Pre>
-__device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, Bias &bias, const float *bias_head, int h, Pre &&pre, unsigned head_lane = 0)
+__device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, Bias &bias, const float *bias_head, int h, Pre &&pre)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x16 a0, a1, a2;
     bias.take(&a0, 1, h);
-    if constexpr (LAST) bias.rewind(bias_head, head_lane);      // the next block is the first one of the next point tile
+    if constexpr (LAST) bias.rewind(bias_head);      // the next block is the first one of the next point tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a1[r] = 0.f; a2[r] = 0.f; }
 #if AVC_DBG_TIMING
@@ -900,7 +899,7 @@ constexpr int B_CONV5 = first_chunk_bytes(16, layout::IN67_KS), B_CONV5F = first
 // K shrinks from 5 k-steps to the xyz k-step: 192 of the 4,920 MFMAs of a tile, and the per-tile gather, split and parking of the 64
 // channels, are gone.  Same algebra as the reference, different rounding (fp32 dot products instead of three fp16 products): a folded
 // launch agrees with the point-by-point query to ~1e-6, not bit for bit (tests/test_gpu_query.py).
-constexpr int COLW = 2 * 256 * 64;               // floats of PackedNet::colw: [conv1 | conv5][out channel][feature channel]
+// (PackedNet::colw: [conv1 | conv5][out channel][feature channel], 2 x 256 x 64 floats)
 __global__ __launch_bounds__(256) void column_terms_kernel(const float *__restrict__ feat, int H, int W, const float *__restrict__ gx,
                                                            const float *__restrict__ gy, int nx, int ny, float cx, float cy,
                                                            const float *__restrict__ colw, const float *__restrict__ bias1,
@@ -1044,7 +1043,7 @@ struct BiasSegs {
         c0 += ntiles; row += 32 * ntiles;
     }
     __device__ __forceinline__ void after_barrier(int) {}
-    __device__ __forceinline__ void rewind(const float *, unsigned = 0) {}
+    __device__ __forceinline__ void rewind(const float *) {}
 };
 
 // FOLD: 0 = point by point; 1 = column-folded dense grid (every tile in one column: wave-uniform column blocks as accumulator init); 2 = column-folded
@@ -1107,7 +1106,6 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         if constexpr (WARP && FOLD == 1) wide_bias_early(bias, w8);      // conv1's column blocks, tiles 2 .. 7: in flight during the prologue
         const float *bias_head = p.bias;
         asm volatile("" : "+s"(bias_head));   // opaque per tile: keeps bias addresses from being hoisted out of the loop
-        unsigned head_lane = 0;              // FOLD == 2: the next tile's per-lane row of the column table
         float q[3] = {pt[0], pt[1], pt[2]};
         float off[3] = {0.f, 0.f, 0.f};
 
@@ -1143,7 +1141,6 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             using SP = Pending<ACT_SOFTPLUS, 8>;
             // column-folded launch: conv1's and conv5's blocks come from the column table, everything else from the layer table
             const float *after1 = nullptr, *col5 = nullptr, *after5 = nullptr;
-            unsigned lane5 = 0;
             if constexpr (FOLD != 0) {
                 after1 = bias_head + 256; after5 = bias_head + 5 * 256;
                 if constexpr (FOLD == 1) {
@@ -1171,11 +1168,11 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
                 // conv5's column terms of the first six runs: requested here, in flight during conv4
 #pragma unroll
                 for (int t = 0; t < 8; ++t) seg_fetch(sp0, crs, j, 256 + 32 * t, c5[t]);
-                dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5F>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5, 0);         // conv4
+                dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5F>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5);            // conv4
                 BiasSegs b5{&segs, &sp0, c5, crs, j, h, 256};
                 dense<8, 16, 1, ACT_SOFTPLUS, B_MAIN>(s, RY, R4, X, b5, h, SP{pb, Y + 12, &s.range}, pa);                      // conv5 on [xyz | x4]
             } else if constexpr (FOLD == 1) {
-                dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5F>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5, lane5);     // conv4
+                dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5F>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5);            // conv4
                 dense<8, 16, 1, ACT_SOFTPLUS, B_MAIN>(s, RY, R4, X, bias, h, SP{pb, Y + 12, &s.range}, pa, after5);            // conv5 on [xyz | x4] (+ column term)
             } else {
                 dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                   // conv4
@@ -1222,7 +1219,7 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         } else {
             // geometry only: pack.cpp folded shared.6 (linear) into geo.0 -- one 256->128 layer instead of two
             dense<4, 16, 0, ACT_LEAKY, B_HEAD8>(s, TY, TY, X, bias, h, RP{pb, Y + 12, &s.range}, pa);                              // geo 0 o shared 6
-            g = head<8, B_FIRST, true>(s, X, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pa, X + 4, &s.range}, head_lane);           // geo 1
+            g = head<8, B_FIRST, true>(s, X, bias, bias_head, h, Pending<ACT_LEAKY, 4>{pa, X + 4, &s.range});                      // geo 1
         }
 
         const bool writer = (h == 0) && (pidx_raw < p.n);
@@ -1289,7 +1286,7 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
             split8(z, I[2].hi, I[2].lo, s.range);
         }
         Frag X[16], Y[16];
-        const RegIn RI{I}, RX{X}, RY{Y};
+        const RegIn RI{I}, RY{Y};
         f32x16 pend[2];
         BiasDirect bias{p.bias};
         asm volatile("" : "+s"(bias.p));   // see avatar_kernel
@@ -1389,7 +1386,7 @@ struct BiasRegs {
         cur += ntiles;
     }
     __device__ __forceinline__ void after_barrier(int) {}
-    __device__ __forceinline__ void rewind(const float *, unsigned = 0) {}
+    __device__ __forceinline__ void rewind(const float *) {}
 };
 
 template <class F>
@@ -1398,7 +1395,7 @@ struct BiasRegsThen {                // BiasRegs whose after-the-barrier slot ru
     F then;
     __device__ __forceinline__ void take(f32x16 *acc, int ntiles, int) { acc[0] = cur[0]; if (ntiles > 1) acc[1] = cur[1]; cur += ntiles; }
     __device__ __forceinline__ void after_barrier(int) { then(); }
-    __device__ __forceinline__ void rewind(const float *, unsigned = 0) {}
+    __device__ __forceinline__ void rewind(const float *) {}
 };
 
 constexpr int B_Z8 = chunk_bytes(1, 8), B_ZZ8 = chunk_bytes(2, 8), B_FC2F = first_chunk_bytes(16, 1);
@@ -1523,7 +1520,7 @@ __global__ __launch_bounds__(256, 1) void recon_fold_kernel(const QueryParams p)
             for (int r = 0; r < 16; ++r) zero2[t][r] = 0.0f;
         BiasRegs bias{zero2};
         f32x16 pend[2];
-        dense<4, 16, 1, ACT_LEAKY, B_HEAD8>(s, RegIn{Y}, RZ, X, bias, h, PendWide<ACT_LEAKY>{acc16 + 8, Y, &s.range}, pend, nullptr, 0,
+        dense<4, 16, 1, ACT_LEAKY, B_HEAD8>(s, RegIn{Y}, RZ, X, bias, h, PendWide<ACT_LEAKY>{acc16 + 8, Y, &s.range}, pend, nullptr,
                                             [&](auto pc, auto tc, half8 a) { return patched(a, pd2[2 * decltype(pc)::value + decltype(tc)::value]); });      // fc2 on [x(256) | z]
         // the next tile's first column terms: requested right after the head's barrier, in flight during the fc3 head, the output store and the loop's turn-around
         auto prefetch_next = [&]() { fetch8(cn, col_rsrc(tile_n), col_voff(col_next), 0, 8); };
