@@ -302,6 +302,16 @@ def test_normal_fusion_step_in_the_frame_loop(pipe64):
     items['front_normal'], items['back_normal'] = front, back
     r = pipe64.recon_frame(items)
     assert r['cano_v'].shape[0] > 0
+    # FramePipeline.avatarcap_frame = exactly this chain (BASELINE configs[2], what bench.py's `configs` leg times): same bits
+    a2, r2 = pipe64.avatarcap_frame(to_cuda(pipe64.ds[0], add_batch=True), obs, w2c, cam, 'merge', iter_num=20)
+    for k in ('cano_v', 'f', 'live_v', 'occ_volume'):
+        assert torch.equal(a2[k], a[k]) and torch.equal(r2[k], r[k]), k
+    # and the reconstruction query on the band goes through the grid entry point: the dataset's own point tensor is recognised, any other tensor is not
+    assert pipe64._grid_items(items) == 'band'
+    other = dict(items); other['cano_pts'] = items['cano_pts'].clone()
+    assert pipe64._grid_items(other) is None
+    r3 = pipe64.recon_frame({**other, 'front_normal': front, 'back_normal': back})
+    assert torch.equal(r3['occ_volume'], r['occ_volume'])                     # (a band launch of the recon query is bit-identical to the point query)
 
 
 def test_latency_mode_single_rank_equals_throughput_mode(pipe64):
