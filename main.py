@@ -67,7 +67,7 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
     cfg = config.cfg
     out_dir = cfg['testing']['output_dir']
     os.makedirs(out_dir, exist_ok=True)
-    log = lambda msg: print(msg, flush=True)                                     # noqa: E731
+    log = lambda msg: (sys.stdout.write(str(msg) + '\n'), sys.stdout.flush())   # one write per line: ranks share the launcher's stdout    # noqa: E731
 
     nerf_net = None
     if dry_run:
