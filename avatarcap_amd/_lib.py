@@ -26,6 +26,24 @@ class avc_bn(C.Structure):
     _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('mean', C.c_void_p), ('var', C.c_void_p), ('eps', C.c_float)]
 
 
+class avc_conv2d(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('b', C.c_void_p), ('cout', C.c_int32), ('cin', C.c_int32), ('kh', C.c_int32), ('kw', C.c_int32)]
+
+
+class avc_groupnorm(C.Structure):
+    _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('channels', C.c_int32), ('groups', C.c_int32), ('eps', C.c_float)]
+
+
+class avc_convblock(C.Structure):
+    _fields_ = [('conv', avc_conv2d * 3), ('downsample', avc_conv2d), ('bn', avc_groupnorm * 4)]
+
+
+class avc_hgfilter(C.Structure):
+    _fields_ = [('conv1', avc_conv2d), ('bn1', avc_groupnorm), ('conv2', avc_convblock), ('conv3', avc_convblock), ('conv4', avc_convblock),
+                ('depth', C.c_int32), ('hourglass', C.POINTER(avc_convblock)), ('top_m', avc_convblock),
+                ('conv_last', avc_conv2d), ('bn_end', avc_groupnorm), ('l', avc_conv2d)]
+
+
 _SIGNATURES = {
     'avc_last_error': (C.c_char_p, []),
     'avc_version': (C.c_int, []),
@@ -47,6 +65,10 @@ _SIGNATURES = {
     'avc_recon_query_grid': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
     'avc_recon_query_grid_subset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_int64,
                                               C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
+    'avc_hgfilter_pack': (C.c_int, [C.c_void_p, C.POINTER(avc_hgfilter)]),
+    'avc_hgfilter_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'avc_hgfilter_debug_tensor': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                            C.c_void_p]),
     'avc_group_norm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                  C.c_int, C.c_void_p, C.c_void_p]),
     'avc_scatter_volume': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -199,3 +221,53 @@ class BnList:
             arr[i].gamma, arr[i].beta, arr[i].mean, arr[i].var = (h.ctypes.data for h in hs)
             arr[i].eps = float(e['eps'])
         self.arr = arr
+
+
+class HGFilterWeights:
+    """avc_hgfilter for a module tree shaped like the reference's HGFilter (network/HGFilters.py:124-175); keeps the host arrays alive."""
+
+    def __init__(self, m):
+        self.keep = []
+        h = avc_hgfilter()
+        self._conv(h.conv1, m.conv1)
+        self._norm(h.bn1, m.bn1)
+        for name in ('conv2', 'conv3', 'conv4'):
+            self._block(getattr(h, name), getattr(m, name))
+        hg = m.m0
+        d = hg.depth
+        names = [f'b{k}_{lvl}' for lvl in range(d, 0, -1) for k in (1, 2)] + ['b2_plus_1'] + [f'b3_{lvl}' for lvl in range(1, d + 1)]
+        self.blocks = (avc_convblock * len(names))()
+        for i, n in enumerate(names):
+            self._block(self.blocks[i], hg._modules[n])
+        h.depth = d
+        h.hourglass = C.cast(self.blocks, C.POINTER(avc_convblock))
+        self._block(h.top_m, m.top_m_0)
+        self._conv(h.conv_last, m.conv_last0)
+        self._norm(h.bn_end, m.bn_end0)
+        self._conv(h.l, m.l0)
+        self.struct = h
+
+    def _arr(self, t):
+        a = _host(t)
+        self.keep.append(a)
+        return a.ctypes.data
+
+    def _conv(self, dst, conv):
+        w = conv.weight
+        dst.w = self._arr(w)
+        dst.b = self._arr(conv.bias) if conv.bias is not None else None
+        dst.cout, dst.cin, dst.kh, dst.kw = (int(v) for v in w.shape)
+
+    def _norm(self, dst, gn):
+        if not isinstance(gn, torch.nn.GroupNorm) or gn.weight is None:
+            raise NotImplementedError("the HIP encoder implements norm='group' with affine parameters (what ReconNetwork builds)")
+        dst.gamma, dst.beta = self._arr(gn.weight), self._arr(gn.bias)
+        dst.channels, dst.groups, dst.eps = int(gn.num_channels), int(gn.num_groups), float(gn.eps)
+
+    def _block(self, dst, blk):
+        for i, (cv, bn) in enumerate(((blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3))):
+            self._conv(dst.conv[i], cv)
+            self._norm(dst.bn[i], bn)
+        if blk.downsample is not None:
+            self._conv(dst.downsample, blk.downsample[2])
+            self._norm(dst.bn[3], blk.bn4)

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libavcap_hip.so')
-SOURCES = ['fused_mlp.hip', 'misc.hip', 'mesh.hip', 'raster.hip', 'fusion.hip', 'knn_lbs.hip', 'pack.cpp', 'capi.cpp']
+SOURCES = ['fused_mlp.hip', 'conv_enc.hip', 'misc.hip', 'mesh.hip', 'raster.hip', 'fusion.hip', 'knn_lbs.hip', 'pack.cpp', 'capi.cpp']
 HEADERS = ['avcap_internal.h', 'mlp_layout.h', 'mc_tables.h', os.path.join('..', '..', 'include', 'avcap.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']

@@ -30,8 +30,8 @@ cfg = dict()           # configurations from the yaml file (config.py:25)
 # 'numeric range'); a query then synchronises and raises AvcapError (AVC_ERR_RANGE) instead of returning silently wrong values
 check_range = False
 
-# not in the reference: ReconNetwork.get_feat_maps replays the HGFilter encoder as a hipGraph (one launch per frame instead of ~200; same kernels, same
-# bits); False keeps the eager launches
+# not in the reference: the HGFilter encoder (csrc/conv_enc.hip) replays its ~70 launches as one hipGraph per frame (avc_set_option "enc_graph");
+# False launches the same kernels one by one -- same bits
 hg_graph = True
 
 

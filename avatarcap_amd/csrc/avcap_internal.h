@@ -56,6 +56,8 @@ struct Options {
     int mlp_blocks = 0;       // persistent workgroups of the fused queries; 0 = one per CU (AVC_MLP_BLOCKS)
     int knn_search = 0;       // 0 automatic, 1 per-lane grid search, 2 cooperative grid search, 3 exhaustive scan (AVC_KNN_PATH=lane|wave, AVC_KNN_BRUTE=1)
     int fusion_graph = 1;     // normal-fusion iterations replayed as a hipGraph (AVC_FUSION_NO_GRAPH=1 -> 0)
+    int enc_graph = 1;        // the image encoder's launches replayed as a hipGraph
+    int enc_lastwg = 1;       // GroupNorm statistics folded by the last workgroup of the producing launch (0: by a launch of their own)
 };
 
 }  // namespace avc
@@ -84,6 +86,7 @@ struct avc_ctx {
     void *fusion_scratch = nullptr; size_t fusion_scratch_bytes = 0;   // normal-fusion work buffers
     void *fusion_graph = nullptr, *fusion_graph_exec = nullptr;        // hipGraph_t / hipGraphExec_t of the fusion iterations
     int fusion_graph_H = 0, fusion_graph_W = 0, fusion_graph_iters = 0;
+    void *encoder = nullptr;                                       // enc::Encoder: packed HGFilter weights + the launch plan of the last input size (conv_enc.hip)
     void *gn_scratch = nullptr; size_t gn_scratch_bytes = 0;       // GroupNorm slice sums
     void *scatter_scratch = nullptr; size_t scatter_scratch_bytes = 0;   // block counts of avc_scatter_volume
     void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
@@ -132,6 +135,13 @@ int canonicalize_normals(const float *live_v, const float *vert_mats, int64_t nv
 int merge_normal_images(avc_ctx *ctx, const float *src, const float *tar, int H, int W, int iter_num, int neck_x, int neck_y, float *out, hipStream_t s);
 int merge_normal_images_cover(const float *src, const float *tar, int64_t npix, float *out, hipStream_t s);
 void release_fusion_graph(avc_ctx *ctx);
+// conv_enc.hip
+namespace enc {
+int pack_encoder(avc_ctx *ctx, const avc_hgfilter *net);
+int encoder_forward(avc_ctx *ctx, const float *image, int H, int W, float *feat_out, float *normx_out, int bind, hipStream_t s);
+int encoder_debug_tensor(avc_ctx *ctx, int launch, int which, float *out, int *C, int *H, int *W, hipStream_t s);
+void release_encoder(avc_ctx *ctx);
+}
 // knn_lbs.hip
 int knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, hipStream_t s);
 int calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s);

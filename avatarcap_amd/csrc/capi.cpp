@@ -58,6 +58,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->col_scratch) hipFree(ctx->col_scratch);
     if (ctx->rcol_scratch) hipFree(ctx->rcol_scratch);
     if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
+    enc::release_encoder(ctx);
     release_fusion_graph(ctx);
     if (ctx->fusion_scratch) hipFree(ctx->fusion_scratch);
     for (int w = 0; w < 2; ++w) {
@@ -348,6 +349,27 @@ int avc_skinning(avc_ctx *ctx, const float *pts, const float *nrm, int64_t n, co
     return skinning(pts, nrm, n, lbs, jm, po, no, mo, (hipStream_t)stream);
 }
 
+int avc_hgfilter_pack(avc_ctx *ctx, const avc_hgfilter *net)
+{
+    AVC_REQUIRE(ctx && net, AVC_ERR_ARG, "avc_hgfilter_pack: NULL argument");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return enc::pack_encoder(ctx, net);
+}
+
+int avc_hgfilter_forward(avc_ctx *ctx, const float *image, int H, int W, float *feat_out, float *normx_out, int bind_img_feat_map, avc_stream stream)
+{
+    AVC_REQUIRE(ctx, AVC_ERR_ARG, "avc_hgfilter_forward: NULL ctx");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return enc::encoder_forward(ctx, image, H, W, feat_out, normx_out, bind_img_feat_map, (hipStream_t)stream);
+}
+
+int avc_hgfilter_debug_tensor(avc_ctx *ctx, int launch, int which, float *out_nchw_dev, int32_t *C, int32_t *H, int32_t *W, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && C && H && W, AVC_ERR_ARG, "avc_hgfilter_debug_tensor: NULL argument");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return enc::encoder_debug_tensor(ctx, launch, which, out_nchw_dev, C, H, W, (hipStream_t)stream);
+}
+
 int avc_set_option(avc_ctx *ctx, const char *name, int value)
 {
     AVC_REQUIRE(ctx && name, AVC_ERR_ARG, "avc_set_option: NULL argument");
@@ -355,6 +377,8 @@ int avc_set_option(avc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "mlp_blocks")) { AVC_REQUIRE(value >= 0, AVC_ERR_ARG, "avc_set_option: mlp_blocks >= 0 (0: one workgroup per CU)"); ctx->opt.mlp_blocks = value; }
     else if (!strcmp(name, "knn_search")) { AVC_REQUIRE(value >= 0 && value <= 3, AVC_ERR_ARG, "avc_set_option: knn_search is 0 (auto), 1 (lane), 2 (wave) or 3 (exhaustive)"); ctx->opt.knn_search = value; }
     else if (!strcmp(name, "fusion_graph")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: fusion_graph is 0 or 1"); ctx->opt.fusion_graph = value; }
+    else if (!strcmp(name, "enc_graph")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: enc_graph is 0 or 1"); ctx->opt.enc_graph = value; }
+    else if (!strcmp(name, "enc_lastwg")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: enc_lastwg is 0 or 1"); ctx->opt.enc_lastwg = value; }
     else AVC_REQUIRE(false, AVC_ERR_ARG, "avc_set_option: unknown option '%s'", name);
     return AVC_OK;
 }

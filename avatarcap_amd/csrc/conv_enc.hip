@@ -1,0 +1,1152 @@
+// The image encoder of ReconNetwork on gfx950 (MI355X): PIFu's stacked hourglass as the reference configures it,
+//   HGFilter(stack 1, depth 4, in 6, out 32, GroupNorm(32), 'no_down', no tanh)      network/HGFilters.py:124-219
+//   ConvBlock (three pre-activated 3x3 convs c/2, c/4, c/4, concatenated, + residual)  network/HGFilters.py:33-75
+//   HourGlass (avg_pool2d down, bicubic align_corners=True up)                          network/HGFilters.py:77-121
+// 232.3 GFLOP per 512^2 frame.  Rounds 1-3 ran it on MIOpen (~200 launches, 5.3 ms of kernels, 1-2 % of the MFMA peak).
+//
+// Design:
+//   * activations live in HBM channel-last (H, W, C) fp32, RAW (pre-normalisation): a GroupNorm needs the statistics of the whole
+//     tensor, so it cannot be applied by the producer; the CONSUMER applies y = relu(a_c x + b_c) while it stages its input tile,
+//     with (a_c, b_c) from the group statistics the producer left behind.
+//   * every convolution is an implicit GEMM  D[pixel][co] = sum_{tap, ci} X[pixel + tap][ci] W[co][ci][tap]  on
+//     v_mfma_f32_32x32x16_f16, A = activations (rows = 32 pixels of one image row), B = weights (columns = 32 output channels),
+//     fp32 products as three fp16 passes (hi*hi + hi*lo + lo*hi, fp32 accumulation -- the arithmetic of fused_mlp.hip).
+//     One workgroup = 4 waves = (4 PT * 32 / TWC) image rows x TWC columns x (32 CT) output channels, K walked as
+//     (32-channel chunk) x (tap) steps of two k-steps each:
+//       - the chunk's halo tile goes HBM -> registers -> GroupNorm + ReLU + fp16 split -> LDS ([pixel][32 hi | 32 lo | pad], 144 B per
+//         pixel: a lane's 8 consecutive channels are one ds_read_b128 and 32 lanes on consecutive pixels hit all banks once),
+//         double-buffered one chunk ahead;
+//       - the step's weights (pre-split, pre-ordered fragments: pack_conv) travel L2 -> LDS by buffer LDS-DMA into a 3-slot ring two
+//         steps ahead; one barrier per step.
+//   * the epilogue writes the raw output and/or its slice of the block's concatenated output + residual, and accumulates the
+//     GroupNorm statistics of both: with D transposed (pixels in rows) a lane owns one channel and 16 PT pixels of it, so the pixel
+//     sum is in-lane; per-workgroup group partials go to HBM and the LAST workgroup to finish (ticket counter) folds them in a fixed
+//     order, in double, into (mean, rstd) per group: deterministic, no floating-point atomics, no extra launch.
+//   * avg_pool2d and bicubic-upsample + add are two small HBM-bound kernels that also leave statistics behind.
+//   * the whole encoder (~65 launches) is recorded once per input size as a hipGraph and replayed per frame.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdint.h>
+#include <type_traits>
+#include <utility>
+
+#include "avcap_internal.h"
+
+namespace avc {
+namespace enc {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ f32x4 raw_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// ---- LDS map of conv_mfma_kernel ---------------------------------------------------------------------------------------
+constexpr int PIXB = 144;                       // bytes per staged pixel: 32 channels x (hi, lo) halves + 16 pad (odd multiple of 16: conflict-free b128 reads)
+constexpr int ACT_BYTES = 49152;                // one staged chunk: up to 340 halo pixels
+constexpr int RING_SLOT = 16384, RING_SLOTS = 3;
+constexpr int LDS_ACT0 = 0, LDS_ACT1 = ACT_BYTES, LDS_RING = 2 * ACT_BYTES;
+constexpr int LDS_AB = LDS_RING + RING_SLOTS * RING_SLOT;       // (a, b) of the prologue's affine map per input channel (<= 256)
+constexpr int LDS_FLAG = LDS_AB + 2048;
+constexpr int LDS_TOTAL = LDS_FLAG + 64;
+constexpr int MAX_CIN = 256;
+
+// Group statistics a launch contributes to (torch.nn.GroupNorm: mean and biased variance over (C/G, H, W)).
+struct StatOut {
+    float *part;         // [groups][ntiles] (sum, sum of squares) per workgroup tile; null = no statistics of this kind
+    float *stats;        // [groups] (mean, rstd), the launch's first group first
+    int cpg;             // channels per group
+    int groups;          // groups this launch covers (all of its Cout)
+    float inv_n;         // 1 / (cpg * H * W)
+    float eps;
+};
+
+struct ConvArgs {
+    const float *x;              // input (H, W, Cin) channel-last
+    int H, W, Cin;
+    const float *in_stats;       // (mean, rstd) per group of x  (NORM launches)
+    const float *gamma, *beta;   // the consumer's GroupNorm affine
+    int in_cpg;
+    float in_scale;              // power of two folded into (a, b): keeps small activations' lo halves normal
+    const char *wstream;         // packed weights: slices of 32 CT output channels, each [chunk][tap][k-step][tile][hi 1 KiB | lo 1 KiB]
+    unsigned wbytes, slice_bytes;
+    const float *bias;           // (Cout) or null
+    float out_scale;             // undoes the weight and activation scales
+    int Cout;
+    float *raw;                  // (H, W, Cout) or null
+    float *y;                    // (H, W, yC): channels [ycoff, ycoff + Cout) <- conv + res[same channels], or null
+    const float *res;            // (H, W, yC)
+    int yC, ycoff;
+    StatOut st_raw, st_y;
+    unsigned *counter;           // ticket of the last-workgroup reduction (self-resetting); null = a finalise launch follows
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ float relu_bits(float x)
+{
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// (x0, x1) -> packed fp16 pair hi = RN(x), lo = RN(x - hi)   (fused_mlp.hip split2)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo)
+{
+    const half2_t hv = {(_Float16)x0, (_Float16)x1};
+    hi = __builtin_bit_cast(unsigned, hv);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo)
+        : "v"(hi), "v"(x0), "v"(x1));
+}
+
+// D-tile register r (0..15) of lane-half h -> row of the 32x32 tile (CDNA4 C/D map; mlp_layout.h d_row)
+__device__ __forceinline__ constexpr int d_row0(int r) { return (r & 3) + 8 * (r >> 2); }      // + 4 h
+
+// ---- statistics: fold the per-tile partials of `groups` groups into (mean, rstd); one workgroup, fixed order, double ------------
+__device__ __forceinline__ void finalize_stats(const StatOut &st, int ntiles, int tid)
+{
+    if (!st.part) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int g = wave; g < st.groups; g += 4) {
+        double s = 0.0, q = 0.0;
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(st.part) + (size_t)g * ntiles;
+        for (int t = lane; t < ntiles; t += 64) {
+            // device-scope load: the partials were written by workgroups on other XCDs (their L2s are not coherent with ours)
+            const unsigned long long v = __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s += (double)__builtin_bit_cast(float, (unsigned)v);
+            q += (double)__builtin_bit_cast(float, (unsigned)(v >> 32));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+        if (lane == 0) {
+            const double mean = s * (double)st.inv_n, var = fmax(q * (double)st.inv_n - mean * mean, 0.0);
+            st.stats[2 * g] = (float)mean;
+            st.stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)st.eps));
+        }
+    }
+}
+
+// the tail every statistics-producing kernel shares: publish this workgroup's partials, take a ticket, the last one folds
+__device__ __forceinline__ void stats_tail(const StatOut &a, const StatOut &b, unsigned *counter, int ntiles, unsigned total_wgs, int tid, char *smem_flag)
+{
+    if (!counter) return;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<volatile unsigned *>(smem_flag) = (t == total_wgs - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*reinterpret_cast<volatile unsigned *>(smem_flag)) {
+        __threadfence();
+        finalize_stats(a, ntiles, tid);
+        finalize_stats(b, ntiles, tid);
+        if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(256) void stats_finalize_kernel(StatOut a, StatOut b, int ntiles)
+{
+    finalize_stats(a, ntiles, threadIdx.x);
+    finalize_stats(b, ntiles, threadIdx.x);
+}
+
+// ---- the convolution ---------------------------------------------------------------------------------------------------
+// CT: 32-channel output tiles per workgroup (B operands), PT: 32-pixel tiles per wave (A operands), TAPS: 9 (3x3, pad 1) or 1,
+// TWC: image columns of a pixel tile (32: one image row; 16: two rows of 16 -- images narrower than 32),
+// NORM: the input goes through relu(GroupNorm(.)) while it is staged (else: raw).
+template <int CT, int PT, int TAPS, int TWC, bool NORM>
+__global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PTR = 32 / TWC;                          // image rows of one pixel tile
+    constexpr int ROWS = 4 * PT * PTR;                     // image rows of the workgroup's tile
+    constexpr int PAD = TAPS == 9 ? 1 : 0;
+    constexpr int RP = TAPS == 9 ? (TWC == 32 ? 34 : 32) : TWC;      // LDS row pitch in pixels (pitch 32 for the 16-wide tile: see the bank note in DESIGN.md)
+    constexpr int HR = ROWS + 2 * PAD, HC = TWC + 2 * PAD;
+    constexpr int NPIX = HR * RP;
+    static_assert(NPIX * PIXB <= ACT_BYTES, "staged tile does not fit its LDS buffer");
+    constexpr int NPIECE = (NPIX * 8 + 255) / 256;         // 16-byte pieces (4 channels of one pixel) per thread and chunk
+    constexpr int STEP_BYTES = 2 * CT * 2048;              // weights of one (chunk, tap): 2 k-steps x CT tiles x [hi | lo]
+    static_assert(STEP_BYTES <= RING_SLOT, "ring slot too small");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int slices = p.Cout / (32 * CT);
+    const int slice = blockIdx.x % slices, tile = blockIdx.x / slices;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const int y0 = ty * ROWS, x0 = tx * TWC;
+    const int nchunks = p.Cin >> 5, nsteps = nchunks * TAPS;
+
+    // ---- the prologue's affine map per input channel: relu(a x + b), a = gamma rstd, b = beta - mean a (both times in_scale)
+    if (tid < p.Cin) {
+        float a = p.in_scale, b = 0.0f;
+        if constexpr (NORM) {
+            const int g = tid / p.in_cpg;
+            const float mean = p.in_stats[2 * g], rstd = p.in_stats[2 * g + 1];
+            a = p.gamma[tid] * rstd;
+            b = (p.beta[tid] - mean * a) * p.in_scale;
+            a *= p.in_scale;
+        }
+        *reinterpret_cast<f32x2 *>(smem + LDS_AB + tid * 8) = f32x2{a, b};
+    }
+
+    // ---- staging geometry of this thread: piece i = 4 channels `sub` of staged pixel sp = tid / 8 + 32 i
+    const int sub = tid & 7;
+    int goff[NPIECE];                                      // byte offset of the piece in x for chunk 0; negative = outside the image (zero padding)
+    {
+        int sp = tid >> 3;
+        int hr = sp / RP, hc = sp - hr * RP;
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) {
+            const int iy = y0 - PAD + hr, ix = x0 - PAD + hc;
+            const bool ok = (i * 32 + (tid >> 3)) < NPIX && hc < HC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            goff[i] = ok ? ((iy * p.W + ix) * p.Cin + sub * 4) * 4 : (int)0x80000000;
+            hc += 32;                                      // next piece: 32 staged pixels on (RP is 32 or 34: at most one row wrap)
+            if (hc >= RP) { hc -= RP; ++hr; }
+            if (RP < 32 && hc >= RP) { hc -= RP; ++hr; }  // RP == 16 (1x1 on the narrow tile)
+        }
+    }
+    i32x4 xrs;
+    {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(p.x);
+        xrs[0] = (int)(unsigned)a; xrs[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+        xrs[2] = p.H * p.W * p.Cin * 4; xrs[3] = 0x00027000;
+    }
+    f32x4 stage[NPIECE];
+    auto load_acts = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) stage[i] = raw_buffer_load_f32x4(xrs, goff[i], c * 128, 0);
+    };
+    // pieces [i0, i1) of the staged chunk c: affine + ReLU + split -> LDS buffer `buf`
+    auto store_acts = [&](int c, unsigned buf, int i0, int i1) {
+        const f32x4 ab0 = *reinterpret_cast<const f32x4 *>(smem + LDS_AB + (c * 32 + sub * 4) * 8);
+        const f32x4 ab1 = *reinterpret_cast<const f32x4 *>(smem + LDS_AB + (c * 32 + sub * 4) * 8 + 16);
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) {
+            if (i < i0 || i >= i1) continue;
+            if ((i + 1) * 32 > NPIX && i * 32 + (tid >> 3) >= NPIX) continue;
+            float v0 = ab0[0] * stage[i][0] + ab0[1], v1 = ab0[2] * stage[i][1] + ab0[3];
+            float v2 = ab1[0] * stage[i][2] + ab1[1], v3 = ab1[2] * stage[i][3] + ab1[3];
+            if constexpr (NORM) { v0 = relu_bits(v0); v1 = relu_bits(v1); v2 = relu_bits(v2); v3 = relu_bits(v3); }
+            unsigned h01, l01, h23, l23;
+            split2(v0, v1, h01, l01);
+            split2(v2, v3, h23, l23);
+            if (goff[i] < 0) { h01 = l01 = h23 = l23 = 0u; }
+            const unsigned a = buf + ((tid >> 3) + 32 * i) * PIXB + sub * 8;
+            *reinterpret_cast<u32x2 *>(smem + a) = u32x2{h01, h23};
+            *reinterpret_cast<u32x2 *>(smem + a + 64) = u32x2{l01, l23};
+        }
+    };
+
+    // ---- weights: buffer LDS-DMA into the ring; wave w moves the w-th quarter of a step (CT pieces of 1 KiB)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p.wstream), 0, (int)p.wbytes, 0x00027000);
+    const unsigned wbase = slice * p.slice_bytes + wave * (CT * 1024);
+    const unsigned lane16 = lane * 16u;
+    auto dma_step = [&](int step) {
+        const unsigned so = wbase + (unsigned)step * STEP_BYTES;
+        const unsigned dst = LDS_RING + (unsigned)(step % RING_SLOTS) * RING_SLOT + wave * (CT * 1024);
+        static_for<CT>([&](auto ic) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void *)(smem + dst), 16, (int)lane16, (int)so, decltype(ic)::value * 1024, 0);
+        });
+    };
+
+    // ---- A-operand addresses: pixel tile n of this wave = tile row q = wave PT + n; lane (j, h) reads 8 channels of pixel j
+    unsigned abase[PT];
+#pragma unroll
+    for (int n = 0; n < PT; ++n) {
+        const int q = wave * PT + n, r = j / TWC, cc = j - r * TWC;
+        abase[n] = (unsigned)(((q * PTR + r) * RP + cc) * PIXB + h * 16);
+    }
+
+    load_acts(0);
+    dma_step(0);
+    if (nsteps > 1) dma_step(1);
+    __syncthreads();                                        // the (a, b) table
+    store_acts(0, LDS_ACT0, 0, NPIECE);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x16 acc[PT][CT];
+#pragma unroll
+    for (int n = 0; n < PT; ++n)
+#pragma unroll
+        for (int m = 0; m < CT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.0f;
+
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned abuf = (c & 1) ? LDS_ACT1 : LDS_ACT0, nbuf = (c & 1) ? LDS_ACT0 : LDS_ACT1;
+        const bool more = c + 1 < nchunks;
+        static_for<TAPS>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int step = c * TAPS + t;
+            if (t == 0 && more) load_acts(c + 1);
+            const bool dma = step + 2 < nsteps;
+            if (dma) dma_step(step + 2);
+            const unsigned wb = LDS_RING + (unsigned)(step % RING_SLOTS) * RING_SLOT + lane16;
+            constexpr int toff = TAPS == 9 ? ((t / 3) * RP + (t % 3)) * PIXB : 0;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                half8 bh[CT], bl[CT], ah[PT], al[PT];
+#pragma unroll
+                for (int m = 0; m < CT; ++m) {
+                    bh[m] = *reinterpret_cast<const half8 *>(smem + wb + (kk * CT + m) * 2048);
+                    bl[m] = *reinterpret_cast<const half8 *>(smem + wb + (kk * CT + m) * 2048 + 1024);
+                }
+#pragma unroll
+                for (int n = 0; n < PT; ++n) {
+                    ah[n] = *reinterpret_cast<const half8 *>(smem + abuf + abase[n] + toff + kk * 32);
+                    al[n] = *reinterpret_cast<const half8 *>(smem + abuf + abase[n] + toff + kk * 32 + 64);
+                }
+#pragma unroll
+                for (int n = 0; n < PT; ++n)
+#pragma unroll
+                    for (int m = 0; m < CT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bh[m], acc[n][m], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < PT; ++n)
+#pragma unroll
+                    for (int m = 0; m < CT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bl[m], acc[n][m], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < PT; ++n)
+#pragma unroll
+                    for (int m = 0; m < CT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[n], bh[m], acc[n][m], 0, 0, 0);
+            }
+            // the next chunk's tile: its pieces are spread over taps 1..8 (3x3) or all behind the one step (1x1)
+            if (more) {
+                if constexpr (TAPS == 9) {
+                    if constexpr (t >= 1) store_acts(c + 1, nbuf, ((t - 1) * NPIECE) / 8, (t * NPIECE) / 8);
+                } else {
+                    store_acts(c + 1, nbuf, 0, NPIECE);
+                }
+            }
+            // step + 1's weights have landed (only this step's own DMA may still fly), every LDS write is done
+            if (dma) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        });
+    }
+
+    // ---- epilogue: lane (j, h) owns channel co = 32 (slice CT + m) + j and, per pixel tile, the 16 pixels d_row0(r) + 4 h
+    const bool full = y0 + ROWS <= p.H && x0 + TWC <= p.W;
+    float sr[CT], qr[CT], sy[CT], qy[CT];
+#pragma unroll
+    for (int m = 0; m < CT; ++m) sr[m] = qr[m] = sy[m] = qy[m] = 0.0f;
+    auto emit = [&](auto masked) {
+        constexpr bool MASK = decltype(masked)::value;
+#pragma unroll
+        for (int m = 0; m < CT; ++m) {
+            const int co = (slice * CT + m) * 32 + j;
+            const float bias = p.bias ? p.bias[co] : 0.0f;
+#pragma unroll
+            for (int n = 0; n < PT; ++n) {
+                const int q = wave * PT + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pl = d_row0(r) + 4 * h;
+                    const int iy = y0 + q * PTR + (TWC == 32 ? 0 : (r >> 3)), ix = x0 + (TWC == 32 ? pl : (pl & 15));
+                    if (MASK && (iy >= p.H || ix >= p.W)) continue;
+                    const int pix = iy * p.W + ix;
+                    const float v = acc[n][m][r] * p.out_scale + bias;
+                    if (p.raw) p.raw[(size_t)pix * p.Cout + co] = v;
+                    sr[m] += v; qr[m] += v * v;
+                    if (p.y) {
+                        const size_t o = (size_t)pix * p.yC + p.ycoff + co;
+                        const float w = v + p.res[o];
+                        p.y[o] = w;
+                        sy[m] += w; qy[m] += w * w;
+                    }
+                }
+            }
+        }
+    };
+    if (full) emit(std::false_type{}); else emit(std::true_type{});
+
+    // ---- statistics: the two pixel halves, then the cpg adjacent channel lanes, then the four waves through LDS
+    if (p.st_raw.part || p.st_y.part) {
+        float *red = reinterpret_cast<float *>(smem + LDS_ACT0);          // [kind][wave][32 CT groups max](s, q); the staged tiles are dead
+        auto reduce = [&](const StatOut &st, float *s, float *q, int kind) {
+            if (!st.part) return;
+#pragma unroll
+            for (int m = 0; m < CT; ++m) {
+                s[m] += __shfl_xor(s[m], 32); q[m] += __shfl_xor(q[m], 32);
+                for (int o = 1; o < st.cpg; o <<= 1) { s[m] += __shfl_xor(s[m], o); q[m] += __shfl_xor(q[m], o); }
+                if (h == 0 && (j & (st.cpg - 1)) == 0) {
+                    const int g = (m * 32 + j) / st.cpg;
+                    *reinterpret_cast<f32x2 *>(red + ((kind * 4 + wave) * 32 * CT + g) * 2) = f32x2{s[m], q[m]};
+                }
+            }
+        };
+        reduce(p.st_raw, sr, qr, 0);
+        reduce(p.st_y, sy, qy, 1);
+        __syncthreads();
+        const int ntiles = p.tiles_x * p.tiles_y;
+        auto publish = [&](const StatOut &st, int kind) {
+            if (!st.part) return;
+            const int gps = 32 * CT / st.cpg;                              // groups of this workgroup's slice
+            if (tid < gps) {
+                float s = 0.0f, q = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const f32x2 v = *reinterpret_cast<const f32x2 *>(red + ((kind * 4 + w) * 32 * CT + tid) * 2);
+                    s += v[0]; q += v[1];
+                }
+                *reinterpret_cast<f32x2 *>(st.part + ((size_t)(slice * gps + tid) * ntiles + tile) * 2) = f32x2{s, q};
+            }
+        };
+        publish(p.st_raw, 0);
+        publish(p.st_y, 1);
+        stats_tail(p.st_raw, p.st_y, p.counter, ntiles, gridDim.x, tid, smem + LDS_FLAG);
+    }
+}
+
+
+// ---- conv1: 7x7, stride 2, pad 3, 6 -> 64 channels, bias (HGFilters.py:134) -------------------------------------------------
+// 2.5 of the encoder's 232 GFLOP: fp32 FMAs, no MFMA.  The input is the reference's NCHW image (6, Hin, Win); a workgroup
+// computes a 16 x 16 tile of output pixels x 64 channels out of LDS (37 x 37 x 6 input tile, all 18,816 weights as [tap][ci][co]);
+// a thread owns 4 horizontally adjacent pixels x 16 channels.  Output channel-last (H1, W1, 64) + GroupNorm partials of bn1.
+constexpr int C1_CO = 64, C1_CI = 6, C1_K = 7, C1_T = 16, C1_IN = 2 * C1_T + C1_K - 2;     // 37
+constexpr int C1_LDS_W = C1_K * C1_K * C1_CI * C1_CO * 4;                                   // 75,264 B
+constexpr int C1_LDS_IN = C1_CI * C1_IN * (C1_IN + 1) * 4;                                  // 33,744 B (row pitch 38)
+constexpr int C1_LDS = C1_LDS_W + C1_LDS_IN + 64;
+
+struct Conv1Args {
+    const float *img;            // (6, Hin, Win)
+    int Hin, Win, H, W;          // output H x W
+    const float *w;              // [49][6][64] (repacked by pack)
+    const float *bias;           // (64)
+    float *out;                  // (H, W, 64)
+    StatOut st;
+    unsigned *counter;
+    int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256, 1) void conv1_kernel(const Conv1Args p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *wl = reinterpret_cast<float *>(smem);
+    float *il = reinterpret_cast<float *>(smem + C1_LDS_W);
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const int oy0 = ty * C1_T, ox0 = tx * C1_T;
+    for (int i = tid; i < C1_K * C1_K * C1_CI * C1_CO / 4; i += 256)
+        reinterpret_cast<f32x4 *>(wl)[i] = reinterpret_cast<const f32x4 *>(p.w)[i];
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+    for (int i = tid; i < C1_CI * C1_IN * C1_IN; i += 256) {
+        const int ci = i / (C1_IN * C1_IN), r = i - ci * (C1_IN * C1_IN), yy = r / C1_IN, xx = r - yy * C1_IN;
+        const int iy = iy0 + yy, ix = ix0 + xx;
+        float v = 0.0f;
+        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) v = p.img[((size_t)ci * p.Hin + iy) * p.Win + ix];
+        il[(ci * C1_IN + yy) * (C1_IN + 1) + xx] = v;
+    }
+    __syncthreads();
+    const int cg = tid & 3, pg = tid >> 2;            // 16 channels cg*16.., pixel group: row pg / 4, columns 4 (pg % 4) ..
+    const int py = pg >> 2, px = (pg & 3) * 4;
+    float acc[4][16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[k][c] = 0.0f;
+    for (int ci = 0; ci < C1_CI; ++ci)
+        for (int dy = 0; dy < C1_K; ++dy) {
+            const float *row = il + (ci * C1_IN + 2 * py + dy) * (C1_IN + 1) + 2 * px;
+            float in[13];
+#pragma unroll
+            for (int k = 0; k < 13; ++k) in[k] = row[k];
+#pragma unroll
+            for (int dx = 0; dx < C1_K; ++dx) {
+                const float *wp = wl + ((dy * C1_K + dx) * C1_CI + ci) * C1_CO + cg * 16;
+                float w[16];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const f32x4 v = reinterpret_cast<const f32x4 *>(wp)[c4];
+                    w[4 * c4] = v[0]; w[4 * c4 + 1] = v[1]; w[4 * c4 + 2] = v[2]; w[4 * c4 + 3] = v[3];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) acc[k][c] = __builtin_fmaf(in[2 * k + dx], w[c], acc[k][c]);
+            }
+        }
+    // bias, store, per-channel sums over this thread's valid pixels
+    float s[16], q[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s[c] = q[c] = 0.0f;
+    const int oy = oy0 + py;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ox = ox0 + px + k;
+        if (oy < p.H && ox < p.W) {
+            float *dst = p.out + ((size_t)oy * p.W + ox) * C1_CO + cg * 16;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[k][4 * c4 + e] + p.bias[cg * 16 + 4 * c4 + e];
+                    v[e] = t; s[4 * c4 + e] += t; q[4 * c4 + e] += t * t;
+                }
+                reinterpret_cast<f32x4 *>(dst)[c4] = v;
+            }
+        }
+    }
+    if (!p.st.part) return;
+    __syncthreads();                                   // the input tile is dead: reuse it as [pixel group][64 channels](s, q)
+    float *red = il;                                   // 64 x 64 x 2 floats = 32 KiB
+#pragma unroll
+    for (int c = 0; c < 16; ++c) *reinterpret_cast<f32x2 *>(red + ((pg * 64) + cg * 16 + c) * 2) = f32x2{s[c], q[c]};
+    __syncthreads();
+    float *red2 = wl;                                  // per-channel totals (weights are dead too)
+    if (tid < 64) {
+        float ss = 0.0f, qq = 0.0f;
+        for (int g = 0; g < 64; ++g) { const f32x2 v = *reinterpret_cast<const f32x2 *>(red + (g * 64 + tid) * 2); ss += v[0]; qq += v[1]; }
+        red2[2 * tid] = ss; red2[2 * tid + 1] = qq;
+    }
+    __syncthreads();
+    const int ntiles = p.tiles_x * p.tiles_y;
+    if (tid < p.st.groups) {
+        float ss = 0.0f, qq = 0.0f;
+        for (int c = 0; c < p.st.cpg; ++c) { ss += red2[2 * (tid * p.st.cpg + c)]; qq += red2[2 * (tid * p.st.cpg + c) + 1]; }
+        *reinterpret_cast<f32x2 *>(p.st.part + ((size_t)tid * ntiles + tile) * 2) = f32x2{ss, qq};
+    }
+    StatOut none{};
+    stats_tail(p.st, none, p.counter, ntiles, gridDim.x, tid, smem + C1_LDS - 64);
+}
+
+// ---- avg_pool2d(2, stride 2) + statistics of the pooled tensor (HGFilters.py:103) ------------------------------------------------
+// x (H, W, C) -> out (H/2, W/2, C); thread = 4 channels, loops over pixels; a workgroup covers PPW output pixels.
+struct EltArgs {
+    const float *a, *b;          // pool: a = x.  upsample-add: a = up1 (H, W, C), b = low3 (H/2, W/2, C)
+    float *out;
+    int H, W, C;                 // OUTPUT size
+    StatOut st;
+    unsigned *counter;
+    int Hb, Wb;                  // size of the other tensor (pool: the input; upsample-add: low3)
+    const float *in_stats, *gamma, *beta; int in_cpg;     // norm-relu: GroupNorm of a
+    int ppw;                     // output pixels per workgroup
+    int ntiles;
+};
+
+template <class F>
+__device__ __forceinline__ void elt_body(const EltArgs &p, F &&value)
+{
+    __shared__ float red[256 * 8];
+    __shared__ unsigned flag[16];
+    const int tid = threadIdx.x, c4n = p.C >> 2;         // C in {32..256}: c4n in {8..64}
+    const int c4 = tid % c4n, sub = tid / c4n, nsub = 256 / c4n;
+    const int npix = p.H * p.W, pix0 = blockIdx.x * p.ppw, pix1 = min(npix, pix0 + p.ppw);
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (int pix = pix0 + sub; pix < pix1; pix += nsub) {
+        const int oy = pix / p.W, ox = pix - oy * p.W;
+        const f32x4 v = value(oy, ox, c4);
+        *reinterpret_cast<f32x4 *>(p.out + (size_t)pix * p.C + 4 * c4) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+    }
+    if (!p.st.part) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[tid * 8 + 2 * e] = s[e]; red[tid * 8 + 2 * e + 1] = q[e]; }
+    __syncthreads();
+    // group g = channels [g cpg, (g + 1) cpg): cpg in {1, 2, 4, 8}
+    if (tid < p.st.groups) {
+        float ss = 0.0f, qq = 0.0f;
+        for (int c = tid * p.st.cpg; c < (tid + 1) * p.st.cpg; ++c)
+            for (int k = 0; k < nsub; ++k) { const float *r = red + ((k * c4n + (c >> 2)) * 8 + 2 * (c & 3)); ss += r[0]; qq += r[1]; }
+        *reinterpret_cast<f32x2 *>(p.st.part + ((size_t)tid * p.ntiles + blockIdx.x) * 2) = f32x2{ss, qq};
+    }
+    StatOut none{};
+    stats_tail(p.st, none, p.counter, p.ntiles, gridDim.x, tid, reinterpret_cast<char *>(flag));
+}
+
+__global__ __launch_bounds__(256) void avgpool_kernel(const EltArgs p)
+{
+    elt_body(p, [&](int oy, int ox, int c4) {
+        // torch's order: ((x00 + x01) + x10) + x11, then / 4; rows / columns beyond 2 H, 2 W (odd inputs) are dropped
+        const float *r0 = p.a + ((size_t)(2 * oy) * p.Wb + 2 * ox) * p.C + 4 * c4;
+        const float *r1 = r0 + (size_t)p.Wb * p.C;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(r0), b = *reinterpret_cast<const f32x4 *>(r0 + p.C);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(r1), d = *reinterpret_cast<const f32x4 *>(r1 + p.C);
+        return (((a + b) + c) + d) * 0.25f;
+    });
+}
+
+// ---- up1 + interpolate(low3, scale_factor=2, mode='bicubic', align_corners=True) + statistics (HGFilters.py:113-116) ------------
+// torch's upsample_bicubic2d: source coordinate = dst * (in - 1) / (out - 1), taps floor - 1 .. floor + 2 clamped to the image,
+// cubic convolution coefficients with A = -0.75, rows first (along x), then along y.
+__device__ __forceinline__ void cubic_coeffs(float t, float c[4])
+{
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = x2 + 1.0f;
+    c[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    c[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+    c[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    c[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+__global__ __launch_bounds__(256) void upadd_kernel(const EltArgs p)
+{
+    const float sy = p.H > 1 ? (float)(p.Hb - 1) / (float)(p.H - 1) : 0.0f, sx = p.W > 1 ? (float)(p.Wb - 1) / (float)(p.W - 1) : 0.0f;
+    elt_body(p, [&](int oy, int ox, int c4) {
+        const float ry = sy * (float)oy, rx = sx * (float)ox;
+        const int iy = min((int)floorf(ry), p.Hb - 1), ix = min((int)floorf(rx), p.Wb - 1);
+        const float ty = fminf(fmaxf(ry - (float)iy, 0.0f), 1.0f), tx = fminf(fmaxf(rx - (float)ix, 0.0f), 1.0f);
+        float cy[4], cx[4];
+        cubic_coeffs(ty, cy);
+        cubic_coeffs(tx, cx);
+        int xs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xs[k] = min(max(ix - 1 + k, 0), p.Wb - 1);
+        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int yy = min(max(iy - 1 + m, 0), p.Hb - 1);
+            const float *row = p.b + (size_t)yy * p.Wb * p.C + 4 * c4;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(row + (size_t)xs[0] * p.C), v1 = *reinterpret_cast<const f32x4 *>(row + (size_t)xs[1] * p.C);
+            const f32x4 v2 = *reinterpret_cast<const f32x4 *>(row + (size_t)xs[2] * p.C), v3 = *reinterpret_cast<const f32x4 *>(row + (size_t)xs[3] * p.C);
+            const f32x4 r = v0 * cx[0] + v1 * cx[1] + v2 * cx[2] + v3 * cx[3];
+            acc = m == 0 ? r * cy[0] : acc + r * cy[m];
+        }
+        const f32x4 u = *reinterpret_cast<const f32x4 *>(p.a + ((size_t)oy * p.W + ox) * p.C + 4 * c4);
+        return u + acc;
+    });
+}
+
+// relu(GroupNorm(a)) materialised (HGFilters.py:178: the block that follows normalises THIS tensor again and needs its statistics)
+__global__ __launch_bounds__(256) void normrelu_kernel(const EltArgs p)
+{
+    const int c4 = threadIdx.x % (p.C >> 2);
+    float a[4], b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * c4 + e, g = c / p.in_cpg;
+        a[e] = p.gamma[c] * p.in_stats[2 * g + 1];
+        b[e] = p.beta[c] - p.in_stats[2 * g] * a[e];
+    }
+    elt_body(p, [&](int oy, int ox, int c4_) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(p.a + ((size_t)oy * p.W + ox) * p.C + 4 * c4_);
+        return f32x4{relu_bits(a[0] * v[0] + b[0]), relu_bits(a[1] * v[1] + b[1]), relu_bits(a[2] * v[2] + b[2]), relu_bits(a[3] * v[3] + b[3])};
+    });
+}
+
+// (H, W, C) channel-last -> the reference's (C, H, W)
+__global__ void hwc_to_nchw_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int HW)
+{
+    __shared__ float tile[64][65];
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int pp = p0 + r, c = c0 + tx;
+        tile[r][tx] = (c < C && pp < HW) ? src[(size_t)pp * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, pp = p0 + tx;
+        if (c < C && pp < HW) dst[(size_t)c * HW + pp] = tile[tx][r];
+    }
+}
+
+
+// =====================================================================================================================
+// host side: weight packing, the launch plan of one input size, the hipGraph
+// =====================================================================================================================
+struct DevConv {            // a packed convolution
+    char *wstream = nullptr; unsigned wbytes = 0;
+    float *bias = nullptr;  // device (cout) or null
+    float *w_direct = nullptr;   // conv1 only: [49][6][64] fp32
+    float wscale_inv = 1.0f;     // 2^-sw
+    int cout = 0, cin = 0, taps = 0;
+    unsigned off[3] = {0, 0, 0}; // byte offset of the stream packed for CT = 1, 2, 4
+};
+struct DevNorm { float *gamma = nullptr, *beta = nullptr; int C = 0, groups = 32; float eps = 1e-5f; };
+struct DevBlock { DevConv conv[3], ds; bool has_ds = false; DevNorm bn[4]; int cin = 0, cout = 0; };
+
+struct Tensor { float *data = nullptr; int H = 0, W = 0, C = 0; float *stats = nullptr; };   // stats: (mean, rstd) x 32 groups
+
+enum LaunchKind { L_CONV1, L_CONV, L_POOL, L_UPADD, L_NORMRELU, L_FINAL };
+struct Launch {
+    LaunchKind kind;
+    ConvArgs conv; int CT = 0, PT = 0, TAPS = 0, TWC = 0; bool norm = false;
+    Conv1Args c1;
+    EltArgs elt;
+    StatOut fa, fb; int fn = 0;      // L_FINAL
+    unsigned grid = 0;
+};
+
+struct Encoder {
+    bool packed = false;
+    DevConv conv1, conv_last, l;
+    DevNorm bn1, bn_end;
+    DevBlock conv2, conv3, conv4, top_m;
+    std::vector<DevBlock> hg;        // b1_d, b2_d, ..., b1_1, b2_1, b2_plus_1, b3_1 .. b3_d
+    int depth = 0;
+    std::vector<void *> weight_allocs;
+    // the plan of one input size
+    int Hin = 0, Win = 0, lastwg = -1;
+    std::vector<Launch> plan;
+    std::vector<void *> plan_allocs;
+    float *in_buf = nullptr;
+    Tensor out, normx;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    hipStream_t cap_stream = nullptr;
+};
+
+static void free_plan(Encoder *e)
+{
+    if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+    if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+    for (void *p : e->plan_allocs) hipFree(p);
+    e->plan_allocs.clear(); e->plan.clear(); e->Hin = e->Win = 0; e->in_buf = nullptr;
+}
+static void free_weights(Encoder *e)
+{
+    for (void *p : e->weight_allocs) hipFree(p);
+    e->weight_allocs.clear();
+    e->hg.clear();
+    e->packed = false;
+}
+void release_encoder(avc_ctx *ctx)
+{
+    Encoder *e = static_cast<Encoder *>(ctx->encoder);
+    if (!e) return;
+    free_plan(e);
+    free_weights(e);
+    if (e->cap_stream) hipStreamDestroy(e->cap_stream);
+    delete e;
+    ctx->encoder = nullptr;
+}
+
+template <class T>
+static int upload_vec(Encoder *e, const std::vector<T> &v, T **dst)
+{
+    void *d = nullptr;
+    AVC_HIP(hipMalloc(&d, v.size() * sizeof(T)));
+    e->weight_allocs.push_back(d);
+    AVC_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<T *>(d);
+    return AVC_OK;
+}
+
+constexpr int conv_ct(int cout) { return cout >= 128 ? 4 : (cout >= 64 ? 2 : 1); }
+
+// [slice][chunk][tap][k-step][tile][hi 1 KiB | lo 1 KiB]; element (lane, e) of a fragment: co = 32 (slice CT + tile) + (lane & 31),
+// ci = 32 chunk + 16 kstep + 8 (lane >> 5) + e.  Any CT that divides cout / 32 reads the same stream (a slice of CT tiles is CT
+// consecutive slices of one tile only when the tile index is the outermost axis -- it is not; so the stream is packed per CT).
+static int pack_conv(Encoder *e, const avc_conv2d &c, int taps_expected, DevConv &d, const char *name)
+{
+    AVC_REQUIRE(c.w, AVC_ERR_ARG, "avc_hgfilter_pack: %s: NULL weight", name);
+    AVC_REQUIRE(c.kh * c.kw == taps_expected && c.kh == c.kw, AVC_ERR_ARG, "avc_hgfilter_pack: %s: kernel %dx%d, expected %d taps", name, c.kh, c.kw, taps_expected);
+    AVC_REQUIRE(c.cin % 32 == 0 && c.cin <= MAX_CIN && c.cout % 32 == 0 && c.cout <= 256, AVC_ERR_ARG,
+                "avc_hgfilter_pack: %s: (%d <- %d) channels; multiples of 32 up to 256 are supported", name, c.cout, c.cin);
+    d.cout = c.cout; d.cin = c.cin; d.taps = taps_expected;
+    const int taps = taps_expected, nchunk = c.cin / 32;
+    double m = 0.0;
+    const size_t nw = (size_t)c.cout * c.cin * taps;
+    for (size_t i = 0; i < nw; ++i) {
+        AVC_REQUIRE(std::isfinite(c.w[i]), AVC_ERR_ARG, "avc_hgfilter_pack: %s: non-finite weight", name);
+        m = std::fmax(m, std::fabs((double)c.w[i]));
+    }
+    int sw = 0;
+    if (m > 0.0) { int ex; std::frexp(m, &ex); sw = 10 - ex; }      // largest |w| 2^sw in [2^9, 2^10): the lo halves stay normal fp16 numbers
+    sw = std::max(-40, std::min(40, sw));
+    d.wscale_inv = (float)std::ldexp(1.0, -sw);
+    // one stream per CT in {1, 2, 4} that divides the tile count: [CT == 1 | CT == 2 | CT == 4] back to back
+    const int ntile = c.cout / 32;
+    std::vector<uint8_t> stream;
+    unsigned off[3] = {0, 0, 0};
+    for (int v = 0; v < 3; ++v) {
+        const int CT = 1 << v;
+        off[v] = (unsigned)stream.size();
+        if (ntile % CT) continue;
+        for (int slice = 0; slice < ntile / CT; ++slice)
+            for (int ch = 0; ch < nchunk; ++ch)
+                for (int t = 0; t < taps; ++t)
+                    for (int kk = 0; kk < 2; ++kk)
+                        for (int tl = 0; tl < CT; ++tl) {
+                            const size_t base = stream.size();
+                            stream.resize(base + 2048);
+                            _Float16 *hi = reinterpret_cast<_Float16 *>(stream.data() + base), *lo = hi + 512;
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int el = 0; el < 8; ++el) {
+                                    const int co = 32 * (slice * CT + tl) + (lane & 31), ci = 32 * ch + 16 * kk + 8 * (lane >> 5) + el;
+                                    const float w = std::ldexp(c.w[((size_t)co * c.cin + ci) * taps + t], sw);
+                                    const _Float16 hh = (_Float16)w;
+                                    hi[lane * 8 + el] = hh;
+                                    lo[lane * 8 + el] = (_Float16)(w - (float)hh);
+                                }
+                        }
+    }
+    d.wbytes = (unsigned)stream.size();
+    uint8_t *dev = nullptr;
+    if (int rc = upload_vec(e, stream, &dev)) return rc;
+    d.wstream = reinterpret_cast<char *>(dev);
+    d.off[0] = off[0]; d.off[1] = off[1]; d.off[2] = off[2];
+    if (c.b) { std::vector<float> b(c.b, c.b + c.cout); if (int rc = upload_vec(e, b, &d.bias)) return rc; }
+    return AVC_OK;
+}
+
+
+static int pack_norm(Encoder *e, const avc_groupnorm &g, int C, DevNorm &d, const char *name)
+{
+    AVC_REQUIRE(g.gamma && g.beta, AVC_ERR_ARG, "avc_hgfilter_pack: %s: NULL gamma / beta", name);
+    AVC_REQUIRE(g.channels == C && g.groups == 32 && C % 32 == 0 && C <= MAX_CIN, AVC_ERR_ARG,
+                "avc_hgfilter_pack: %s: GroupNorm(%d, %d), expected GroupNorm(32, %d)", name, g.groups, g.channels, C);
+    d.C = C; d.groups = g.groups; d.eps = g.eps;
+    std::vector<float> ga(g.gamma, g.gamma + C), be(g.beta, g.beta + C);
+    if (int rc = upload_vec(e, ga, &d.gamma)) return rc;
+    return upload_vec(e, be, &d.beta);
+}
+
+static int pack_block(Encoder *e, const avc_convblock &b, int cin, int cout, DevBlock &d, const char *name)
+{
+    char nm[96];
+    const int co[3] = {cout / 2, cout / 4, cout / 4}, ci[3] = {cin, cout / 2, cout / 4};
+    d.cin = cin; d.cout = cout;
+    for (int i = 0; i < 3; ++i) {
+        snprintf(nm, sizeof nm, "%s.conv%d", name, i + 1);
+        AVC_REQUIRE(b.conv[i].cout == co[i] && b.conv[i].cin == ci[i], AVC_ERR_ARG, "avc_hgfilter_pack: %s: weight (%d,%d,..), expected (%d,%d,3,3)", nm,
+                    b.conv[i].cout, b.conv[i].cin, co[i], ci[i]);
+        AVC_REQUIRE(!b.conv[i].b, AVC_ERR_ARG, "avc_hgfilter_pack: %s has no bias in the reference (HGFilters.py:29-31)", nm);
+        if (int rc = pack_conv(e, b.conv[i], 9, d.conv[i], nm)) return rc;
+        snprintf(nm, sizeof nm, "%s.bn%d", name, i + 1);
+        if (int rc = pack_norm(e, b.bn[i], ci[i], d.bn[i], nm)) return rc;
+    }
+    d.has_ds = cin != cout;
+    AVC_REQUIRE(d.has_ds == (b.downsample.w != nullptr), AVC_ERR_ARG, "avc_hgfilter_pack: %s: a 1x1 projection exists exactly when in_planes != out_planes (HGFilters.py:51-58)", name);
+    if (d.has_ds) {
+        snprintf(nm, sizeof nm, "%s.downsample.2", name);
+        AVC_REQUIRE(b.downsample.cout == cout && b.downsample.cin == cin && !b.downsample.b, AVC_ERR_ARG, "avc_hgfilter_pack: %s: bad shape or a bias", nm);
+        if (int rc = pack_conv(e, b.downsample, 1, d.ds, nm)) return rc;
+        snprintf(nm, sizeof nm, "%s.bn4", name);
+        if (int rc = pack_norm(e, b.bn[3], cin, d.bn[3], nm)) return rc;
+    }
+    return AVC_OK;
+}
+
+int pack_encoder(avc_ctx *ctx, const avc_hgfilter *net)
+{
+    if (!ctx->encoder) ctx->encoder = new Encoder();
+    Encoder *e = static_cast<Encoder *>(ctx->encoder);
+    free_plan(e);
+    free_weights(e);
+    AVC_REQUIRE(net->depth >= 1 && net->depth <= 6 && net->hourglass, AVC_ERR_ARG, "avc_hgfilter_pack: depth %d", net->depth);
+    // conv1: 7x7 stride 2, 6 -> 64, bias; repacked [tap][ci][co] for the direct kernel
+    const avc_conv2d &c1 = net->conv1;
+    AVC_REQUIRE(c1.w && c1.b && c1.cout == C1_CO && c1.cin == C1_CI && c1.kh == C1_K && c1.kw == C1_K, AVC_ERR_ARG,
+                "avc_hgfilter_pack: conv1 must be Conv2d(6, 64, 7, stride 2, padding 3) with a bias (HGFilters.py:134)");
+    {
+        std::vector<float> w((size_t)C1_K * C1_K * C1_CI * C1_CO), b(c1.b, c1.b + C1_CO);
+        for (int co = 0; co < C1_CO; ++co)
+            for (int ci = 0; ci < C1_CI; ++ci)
+                for (int t = 0; t < C1_K * C1_K; ++t) w[((size_t)t * C1_CI + ci) * C1_CO + co] = c1.w[((size_t)co * C1_CI + ci) * C1_K * C1_K + t];
+        if (int rc = upload_vec(e, w, &e->conv1.w_direct)) return rc;
+        if (int rc = upload_vec(e, b, &e->conv1.bias)) return rc;
+    }
+    if (int rc = pack_norm(e, net->bn1, 64, e->bn1, "bn1")) return rc;
+    if (int rc = pack_block(e, net->conv2, 64, 128, e->conv2, "conv2")) return rc;
+    if (int rc = pack_block(e, net->conv3, 128, 128, e->conv3, "conv3")) return rc;
+    if (int rc = pack_block(e, net->conv4, 128, 256, e->conv4, "conv4")) return rc;
+    e->depth = net->depth;
+    e->hg.resize(3 * net->depth + 1);
+    for (int i = 0; i < 3 * net->depth + 1; ++i) {
+        char nm[32]; snprintf(nm, sizeof nm, "m0[%d]", i);
+        if (int rc = pack_block(e, net->hourglass[i], 256, 256, e->hg[i], nm)) return rc;
+    }
+    if (int rc = pack_block(e, net->top_m, 256, 256, e->top_m, "top_m_0")) return rc;
+    AVC_REQUIRE(net->conv_last.cout == 256 && net->conv_last.cin == 256 && net->conv_last.b, AVC_ERR_ARG, "avc_hgfilter_pack: conv_last0 must be Conv2d(256, 256, 1) with a bias");
+    if (int rc = pack_conv(e, net->conv_last, 1, e->conv_last, "conv_last0")) return rc;
+    if (int rc = pack_norm(e, net->bn_end, 256, e->bn_end, "bn_end0")) return rc;
+    AVC_REQUIRE(net->l.cin == 256 && net->l.cout == 32 && net->l.b, AVC_ERR_ARG, "avc_hgfilter_pack: l0 must be Conv2d(256, 32, 1) with a bias (the decoder samples 32 channels)");
+    if (int rc = pack_conv(e, net->l, 1, e->l, "l0")) return rc;
+    e->packed = true;
+    return AVC_OK;
+}
+
+// ---- launch plan -----------------------------------------------------------------------------------------------------
+struct Planner {
+    avc_ctx *ctx; Encoder *e; std::vector<void *> allocs; bool lastwg; int rc = AVC_OK;
+    float gn_eps = 1e-5f; int gn_groups = 32;
+
+    void *alloc(size_t bytes, bool zero = false)
+    {
+        void *d = nullptr;
+        if (rc) return nullptr;
+        if (hipMalloc(&d, std::max<size_t>(bytes, 16)) != hipSuccess) { set_error("avc_hgfilter_forward: out of device memory"); rc = AVC_ERR_HIP; return nullptr; }
+        allocs.push_back(d);
+        if (zero) hipMemset(d, 0, std::max<size_t>(bytes, 16));
+        return d;
+    }
+    Tensor tensor(int H, int W, int C)
+    {
+        Tensor t; t.H = H; t.W = W; t.C = C;
+        t.data = static_cast<float *>(alloc(sizeof(float) * (size_t)H * W * C));
+        t.stats = static_cast<float *>(alloc(sizeof(float) * 2 * 256, true));
+        return t;
+    }
+    StatOut stat(const Tensor &t, int first_channel, int channels, int ntiles)
+    {
+        StatOut s{};
+        s.cpg = t.C / gn_groups;
+        s.groups = channels / s.cpg;
+        s.part = static_cast<float *>(alloc(sizeof(float) * 2 * (size_t)s.groups * ntiles));
+        s.stats = t.stats + 2 * (first_channel / s.cpg);
+        s.inv_n = 1.0f / ((float)s.cpg * (float)t.H * (float)t.W);
+        s.eps = gn_eps;
+        return s;
+    }
+    unsigned *counter() { return lastwg ? static_cast<unsigned *>(alloc(sizeof(unsigned), true)) : nullptr; }
+    void finish(const StatOut &a, const StatOut &b, int ntiles)
+    {
+        if (lastwg || (!a.part && !b.part)) return;
+        Launch f{}; f.kind = L_FINAL; f.fa = a; f.fb = b; f.fn = ntiles; f.grid = 1;
+        e->plan.push_back(f);
+    }
+
+    // conv: x (through gn + ReLU when gn != null) -> raw (with statistics when raw_stats) and / or y[:, ycoff ...] = conv + res
+    void conv(const DevConv &w, const Tensor &x, const DevNorm *gn, Tensor *raw, bool raw_stats, Tensor *y, const Tensor *res, int ycoff)
+    {
+        if (rc) return;
+        Launch L{}; L.kind = L_CONV;
+        L.TAPS = w.taps; L.norm = gn != nullptr;
+        L.TWC = x.W >= 32 ? 32 : 16;
+        L.CT = conv_ct(w.cout); L.PT = L.TWC == 32 ? 2 : 1;
+        auto wgs = [&](int CT, int PT) { const int rows = 4 * PT * (32 / L.TWC); return ((x.H + rows - 1) / rows) * ((x.W + L.TWC - 1) / L.TWC) * (w.cout / (32 * CT)); };
+        while (wgs(L.CT, L.PT) < ctx->num_cus) {
+            if (L.PT == 2) L.PT = 1;
+            else if (L.CT > 1) L.CT /= 2;
+            else break;
+        }
+        const int rows = 4 * L.PT * (32 / L.TWC);
+        ConvArgs &a = L.conv;
+        a.x = x.data; a.H = x.H; a.W = x.W; a.Cin = x.C;
+        a.in_stats = x.stats; a.gamma = gn ? gn->gamma : nullptr; a.beta = gn ? gn->beta : nullptr; a.in_cpg = gn ? x.C / gn->groups : 1;
+        a.in_scale = gn ? 16.0f : 1.0f;
+        const int v = L.CT == 4 ? 2 : (L.CT == 2 ? 1 : 0);
+        a.slice_bytes = (unsigned)(x.C / 32) * w.taps * 2 * L.CT * 2048;
+        a.wstream = w.wstream + w.off[v]; a.wbytes = a.slice_bytes * (w.cout / (32 * L.CT));
+        a.bias = w.bias; a.out_scale = w.wscale_inv / a.in_scale; a.Cout = w.cout;
+        a.raw = raw ? raw->data : nullptr;
+        a.y = y ? y->data : nullptr; a.res = res ? res->data : nullptr; a.yC = y ? y->C : 0; a.ycoff = ycoff;
+        a.tiles_x = (x.W + L.TWC - 1) / L.TWC; a.tiles_y = (x.H + rows - 1) / rows;
+        const int ntiles = a.tiles_x * a.tiles_y;
+        if (raw && raw_stats) a.st_raw = stat(*raw, 0, w.cout, ntiles);
+        if (y) a.st_y = stat(*y, ycoff, w.cout, ntiles);
+        a.counter = (a.st_raw.part || a.st_y.part) ? counter() : nullptr;
+        L.grid = (unsigned)(ntiles * (w.cout / (32 * L.CT)));
+        e->plan.push_back(L);
+        finish(a.st_raw, a.st_y, ntiles);
+    }
+
+    Tensor block(const DevBlock &b, const Tensor &x)
+    {
+        Tensor y = tensor(x.H, x.W, b.cout), o1 = tensor(x.H, x.W, b.cout / 2), o2 = tensor(x.H, x.W, b.cout / 4), r;
+        const Tensor *res = &x;
+        if (b.has_ds) { r = tensor(x.H, x.W, b.cout); conv(b.ds, x, &b.bn[3], &r, false, nullptr, nullptr, 0); res = &r; }
+        conv(b.conv[0], x, &b.bn[0], &o1, true, &y, res, 0);
+        conv(b.conv[1], o1, &b.bn[1], &o2, true, &y, res, b.cout / 2);
+        conv(b.conv[2], o2, &b.bn[2], nullptr, false, &y, res, b.cout / 2 + b.cout / 4);
+        return y;
+    }
+
+    Tensor elementwise(LaunchKind kind, const Tensor &a, const Tensor *b, int H, int W, const DevNorm *gn = nullptr)
+    {
+        Tensor out = tensor(H, W, a.C);
+        if (rc) return out;
+        Launch L{}; L.kind = kind;
+        EltArgs &g = L.elt;
+        g.a = a.data; g.b = b ? b->data : nullptr; g.out = out.data; g.H = H; g.W = W; g.C = a.C;
+        g.Hb = b ? b->H : a.H; g.Wb = b ? b->W : a.W;
+        if (gn) { g.in_stats = a.stats; g.gamma = gn->gamma; g.beta = gn->beta; g.in_cpg = a.C / gn->groups; }
+        const int npix = H * W;
+        g.ppw = std::max(16, (npix + 511) / 512);
+        g.ntiles = (npix + g.ppw - 1) / g.ppw;
+        g.st = stat(out, 0, a.C, g.ntiles);
+        g.counter = counter();
+        L.grid = (unsigned)g.ntiles;
+        e->plan.push_back(L);
+        StatOut none{};
+        finish(g.st, none, g.ntiles);
+        return out;
+    }
+
+    Tensor level(int lvl, const Tensor &x)
+    {
+        const int d = e->depth;
+        Tensor up1 = block(e->hg[2 * (d - lvl)], x);
+        Tensor low = elementwise(L_POOL, x, nullptr, x.H / 2, x.W / 2);
+        low = block(e->hg[2 * (d - lvl) + 1], low);
+        low = lvl > 1 ? level(lvl - 1, low) : block(e->hg[2 * d], low);
+        low = block(e->hg[2 * d + lvl], low);
+        return elementwise(L_UPADD, up1, &low, x.H, x.W);
+    }
+};
+
+template <int CT, int PT, int TAPS, int TWC, bool NORM>
+static int launch_conv_t(const ConvArgs &a, unsigned grid, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) {
+        AVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<CT, PT, TAPS, TWC, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<CT, PT, TAPS, TWC, NORM>), dim3(grid), dim3(256), LDS_TOTAL, s, a);
+    return AVC_OK;
+}
+
+static int launch_conv(const Launch &L, hipStream_t s)
+{
+#define AVC_ENC_CASE(CT_, PT_, TAPS_, TWC_, NORM_) \
+    if (L.CT == CT_ && L.PT == PT_ && L.TAPS == TAPS_ && L.TWC == TWC_ && L.norm == NORM_) return launch_conv_t<CT_, PT_, TAPS_, TWC_, NORM_>(L.conv, L.grid, s);
+#define AVC_ENC_CT(PT_, TAPS_, TWC_, NORM_) AVC_ENC_CASE(1, PT_, TAPS_, TWC_, NORM_) AVC_ENC_CASE(2, PT_, TAPS_, TWC_, NORM_) AVC_ENC_CASE(4, PT_, TAPS_, TWC_, NORM_)
+#define AVC_ENC_GEO(TAPS_, NORM_) AVC_ENC_CT(2, TAPS_, 32, NORM_) AVC_ENC_CT(1, TAPS_, 32, NORM_) AVC_ENC_CT(1, TAPS_, 16, NORM_)
+    AVC_ENC_GEO(9, true)
+    AVC_ENC_GEO(1, true)
+    AVC_ENC_GEO(1, false)
+#undef AVC_ENC_GEO
+#undef AVC_ENC_CT
+#undef AVC_ENC_CASE
+    set_error("avc_hgfilter_forward: no kernel for CT %d PT %d taps %d tile width %d norm %d", L.CT, L.PT, L.TAPS, L.TWC, (int)L.norm);
+    return AVC_ERR_STATE;
+}
+
+static int run_plan(Encoder *e, hipStream_t s)
+{
+    static bool attr1 = false;
+    if (!attr1) {
+        AVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS));
+        attr1 = true;
+    }
+    for (const Launch &L : e->plan) {
+        switch (L.kind) {
+        case L_CONV1: hipLaunchKernelGGL(conv1_kernel, dim3(L.grid), dim3(256), C1_LDS, s, L.c1); break;
+        case L_CONV: if (int rc = launch_conv(L, s)) return rc; break;
+        case L_POOL: hipLaunchKernelGGL(avgpool_kernel, dim3(L.grid), dim3(256), 0, s, L.elt); break;
+        case L_UPADD: hipLaunchKernelGGL(upadd_kernel, dim3(L.grid), dim3(256), 0, s, L.elt); break;
+        case L_NORMRELU: hipLaunchKernelGGL(normrelu_kernel, dim3(L.grid), dim3(256), 0, s, L.elt); break;
+        case L_FINAL: hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(256), 0, s, L.fa, L.fb, L.fn); break;
+        }
+    }
+    AVC_HIP(hipGetLastError());
+    return AVC_OK;
+}
+
+static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
+{
+    free_plan(e);
+    const int H1 = (Hin - 1) / 2 + 1, W1 = (Win - 1) / 2 + 1;
+    AVC_REQUIRE(H1 % (1 << e->depth) == 0 && W1 % (1 << e->depth) == 0, AVC_ERR_ARG,
+                "avc_hgfilter_forward: a %d x %d image gives %d x %d features, which the depth-%d hourglass cannot halve %d times and add back "
+                "(up1 + up2, HGFilters.py:118: the reference raises a size mismatch)", Hin, Win, H1, W1, e->depth, e->depth);
+    Planner P{ctx, e, {}, ctx->opt.enc_lastwg != 0};
+    P.gn_eps = e->bn1.eps; P.gn_groups = e->bn1.groups;
+    e->in_buf = static_cast<float *>(P.alloc(sizeof(float) * 6 * (size_t)Hin * Win));
+    // conv1 + statistics of bn1
+    Tensor t0 = P.tensor(H1, W1, C1_CO);
+    if (!P.rc) {
+        Launch L{}; L.kind = L_CONV1;
+        Conv1Args &a = L.c1;
+        a.img = e->in_buf; a.Hin = Hin; a.Win = Win; a.H = H1; a.W = W1; a.w = e->conv1.w_direct; a.bias = e->conv1.bias; a.out = t0.data;
+        a.tiles_x = (W1 + C1_T - 1) / C1_T; a.tiles_y = (H1 + C1_T - 1) / C1_T;
+        a.st = P.stat(t0, 0, C1_CO, a.tiles_x * a.tiles_y);
+        a.counter = P.counter();
+        L.grid = (unsigned)(a.tiles_x * a.tiles_y);
+        e->plan.push_back(L);
+        StatOut none{};
+        P.finish(a.st, none, a.tiles_x * a.tiles_y);
+    }
+    Tensor x = P.elementwise(L_NORMRELU, t0, nullptr, H1, W1, &e->bn1);          // relu(bn1(conv1 x))        HGFilters.py:178
+    x = P.block(e->conv2, x);                                                    // 'no_down'                  :184-185
+    e->normx = x;
+    x = P.block(e->conv3, x);
+    x = P.block(e->conv4, x);
+    x = P.level(e->depth, x);                                                    // the hourglass              :199
+    x = P.block(e->top_m, x);                                                    //                            :202
+    Tensor cl = P.tensor(H1, W1, 256), out = P.tensor(H1, W1, 32);
+    P.conv(e->conv_last, x, nullptr, &cl, true, nullptr, nullptr, 0);            // conv_last0 on the raw block output   :204-205
+    P.conv(e->l, cl, &e->bn_end, &out, false, nullptr, nullptr, 0);              // l0(relu(bn_end0(.)))                  :207
+    e->out = out;
+    e->plan_allocs = P.allocs;
+    if (P.rc) { free_plan(e); return P.rc; }
+    e->Hin = Hin; e->Win = Win; e->lastwg = ctx->opt.enc_lastwg;
+    // record the launches once as a hipGraph (replayed with one hipGraphLaunch per frame)
+    if (ctx->opt.enc_graph) {
+        if (!e->cap_stream) AVC_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+        // first a plain run: hipFuncSetAttribute calls and module loading must not happen inside a capture
+        if (int rc = run_plan(e, e->cap_stream)) { free_plan(e); return rc; }
+        AVC_HIP(hipStreamSynchronize(e->cap_stream));
+        AVC_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = run_plan(e, e->cap_stream);
+        hipGraph_t g = nullptr;
+        const hipError_t ee = hipStreamEndCapture(e->cap_stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); free_plan(e); return rc; }
+        AVC_HIP(ee);
+        e->graph = g;
+        AVC_HIP(hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
+    }
+    return AVC_OK;
+}
+
+int encoder_forward(avc_ctx *ctx, const float *image, int H, int W, float *feat_out, float *normx_out, int bind, hipStream_t s)
+{
+    Encoder *e = static_cast<Encoder *>(ctx->encoder);
+    AVC_REQUIRE(e && e->packed, AVC_ERR_STATE, "avc_hgfilter_forward: no encoder weights (call avc_hgfilter_pack first)");
+    AVC_REQUIRE(image && H >= 2 && W >= 2 && (int64_t)H * W <= (1 << 22), AVC_ERR_ARG, "avc_hgfilter_forward: NULL image or unsupported size %d x %d", H, W);
+    if (e->Hin != H || e->Win != W || e->lastwg != ctx->opt.enc_lastwg || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
+        // (re)building frees buffers a replay in flight may still use
+        AVC_HIP(hipDeviceSynchronize());
+        if (int rc = build_plan(ctx, e, H, W)) return rc;
+    }
+    AVC_HIP(hipMemcpyAsync(e->in_buf, image, sizeof(float) * 6 * (size_t)H * W, hipMemcpyDeviceToDevice, s));
+    if (e->exec) AVC_HIP(hipGraphLaunch(e->exec, s));
+    else if (int rc = run_plan(e, s)) return rc;
+    const Tensor &o = e->out;
+    const int HW = o.H * o.W;
+    if (feat_out) hipLaunchKernelGGL(hwc_to_nchw_kernel, dim3((HW + 63) / 64, (o.C + 63) / 64), dim3(256), 0, s, o.data, feat_out, o.C, HW);
+    if (normx_out) hipLaunchKernelGGL(hwc_to_nchw_kernel, dim3((HW + 63) / 64, (e->normx.C + 63) / 64), dim3(256), 0, s, e->normx.data, normx_out, e->normx.C, HW);
+    if (bind) {
+        if (!ctx->img_feat_hwc || ctx->img_C != o.C || ctx->img_H != o.H || ctx->img_W != o.W) {
+            AVC_HIP(hipStreamSynchronize(s));          // a query on another stream may still read the old map
+            if (ctx->img_feat_hwc) AVC_HIP(hipFree(ctx->img_feat_hwc));
+            ctx->img_feat_hwc = nullptr;
+            AVC_HIP(hipMalloc((void **)&ctx->img_feat_hwc, sizeof(float) * (size_t)o.C * HW));
+            ctx->img_C = o.C; ctx->img_H = o.H; ctx->img_W = o.W;
+        }
+        AVC_HIP(hipMemcpyAsync(ctx->img_feat_hwc, o.data, sizeof(float) * (size_t)o.C * HW, hipMemcpyDeviceToDevice, s));
+    }
+    AVC_HIP(hipGetLastError());
+    return AVC_OK;
+}
+
+// a tensor of the last forward, for tests: index into the launch plan -> the launch's raw / y output as NCHW
+int encoder_debug_tensor(avc_ctx *ctx, int launch, int which, float *out, int *C, int *H, int *W, hipStream_t s)
+{
+    Encoder *e = static_cast<Encoder *>(ctx->encoder);
+    AVC_REQUIRE(e && launch >= 0 && launch < (int)e->plan.size(), AVC_ERR_ARG, "avc_hgfilter_debug_tensor: launch %d of %d", launch, e ? (int)e->plan.size() : 0);
+    const Launch &L = e->plan[launch];
+    const float *src = nullptr; int c = 0, h = 0, w = 0;
+    if (L.kind == L_CONV1) { src = L.c1.out; c = C1_CO; h = L.c1.H; w = L.c1.W; }
+    else if (L.kind == L_CONV) { src = which ? L.conv.y : L.conv.raw; c = which ? L.conv.yC : L.conv.Cout; h = L.conv.H; w = L.conv.W; }
+    else if (L.kind != L_FINAL) { src = L.elt.out; c = L.elt.C; h = L.elt.H; w = L.elt.W; }
+    *C = c; *H = h; *W = w;
+    if (L.kind == L_CONV) *C = c | (L.CT << 16) | (L.PT << 20) | (L.TAPS << 24);
+    if (out && src) hipLaunchKernelGGL(hwc_to_nchw_kernel, dim3((h * w + 63) / 64, (c + 63) / 64), dim3(256), 0, s, src, out, c, h * w);
+    AVC_HIP(hipGetLastError());
+    return src ? AVC_OK : 1;
+}
+
+}  // namespace enc
+}  // namespace avc

@@ -1,32 +1,18 @@
 """Image-feature producer: PIFu stacked hourglass as the reference configures it
 (`HGFilter(1, 4, 6, 32, 'group', 'no_down', False)`, network/arch_recon.py:29; HGFilters.py:124-219).
-Runs once per frame on PyTorch-ROCm / MIOpen (232 GFLOP); its sampling is fused into the HIP
-recon-query kernel.  state_dict-compatible with the reference (203 keys under `image_encoder.`).
+
+The modules below are WEIGHT CONTAINERS, state_dict-compatible with the reference (203 keys under `image_encoder.`): the
+encoder itself is hand-written HIP for gfx950 (csrc/conv_enc.hip: implicit-GEMM convolutions on split-fp16 MFMA, GroupNorm +
+ReLU applied while the consumer stages its input, statistics produced by the convolution before, one hipGraph per input size),
+reached through `avc_hgfilter_pack` / `avc_hgfilter_forward`.  There is no PyTorch / MIOpen path: `forward` raises without the
+library or on a CPU tensor (rounds 1-3 ran these layers on MIOpen: ~200 launches and 5.3 ms of kernels per 512^2 frame).
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 def _norm(kind, c):
     return nn.GroupNorm(32, c) if kind == 'group' else nn.BatchNorm2d(c)
-
-
-def norm_relu(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
-    """relu(norm(x)) -- every normalisation of the encoder is followed by one (HGFilters.py:64-66,178,204).
-    On the GPU a GroupNorm goes through the fused HIP op (avc_group_norm): eager PyTorch spends more time in its
-    55 statistics launches per frame than in the convolutions.  Inference only (no autograd through the HIP op)."""
-    if isinstance(m, nn.GroupNorm) and x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad):
-        from .. import _lib
-        x = x.contiguous()
-        y = torch.empty_like(x)
-        N, C = x.shape[0], x.shape[1]
-        _lib.check(_lib.lib().avc_group_norm(_lib.ctx(x.device), x.data_ptr(), N, C, x.numel() // (N * C), m.num_groups,
-                                             m.weight.data_ptr() if m.weight is not None else None,
-                                             m.bias.data_ptr() if m.bias is not None else None, float(m.eps), 1, y.data_ptr(),
-                                             _lib.stream_ptr(x.device)))
-        return y
-    return F.relu(m(x))
 
 
 class ConvBlock(nn.Module):
@@ -45,11 +31,7 @@ class ConvBlock(nn.Module):
             self.downsample = nn.Sequential(self.bn4, nn.ReLU(True), nn.Conv2d(cin, cout, 1, 1, bias=False))
 
     def forward(self, x):
-        o1 = self.conv1(norm_relu(self.bn1, x))
-        o2 = self.conv2(norm_relu(self.bn2, o1))
-        o3 = self.conv3(norm_relu(self.bn3, o2))
-        res = x if self.downsample is None else self.downsample[2](norm_relu(self.bn4, x))
-        return torch.cat([o1, o2, o3], 1) + res
+        raise RuntimeError('ConvBlock is evaluated inside avc_hgfilter_forward (HGFilter.forward); it has no stand-alone path')
 
 
 class HourGlass(nn.Module):
@@ -65,22 +47,15 @@ class HourGlass(nn.Module):
         for level in range(1, depth + 1):
             self.add_module(f'b3_{level}', ConvBlock(n_features, n_features, norm))
 
-    def _level(self, level, x):
-        up1 = self._modules[f'b1_{level}'](x)
-        low = self._modules[f'b2_{level}'](F.avg_pool2d(x, 2, stride=2))
-        low = self._level(level - 1, low) if level > 1 else self._modules['b2_plus_1'](low)
-        low = self._modules[f'b3_{level}'](low)
-        return up1 + F.interpolate(low, scale_factor=2, mode='bicubic', align_corners=True)
-
     def forward(self, x):
-        return self._level(self.depth, x)
+        raise RuntimeError('HourGlass is evaluated inside avc_hgfilter_forward (HGFilter.forward); it has no stand-alone path')
 
 
 class HGFilter(nn.Module):
     def __init__(self, stack, depth, in_ch, last_ch, norm='batch', down_type='conv64', use_sigmoid=True):
         super().__init__()
-        if down_type != 'no_down' or stack != 1:
-            raise NotImplementedError("only stack=1, down_type='no_down' (what ReconNetwork builds) is on the path")
+        if down_type != 'no_down' or stack != 1 or norm != 'group':
+            raise NotImplementedError("only stack=1, norm='group', down_type='no_down' (what ReconNetwork builds) is on the path")
         self.n_stack, self.use_sigmoid = stack, use_sigmoid
         self.conv1 = nn.Conv2d(in_ch, 64, 7, 2, 3)
         self.bn1 = _norm(norm, 64)
@@ -92,12 +67,48 @@ class HGFilter(nn.Module):
         self.conv_last0 = nn.Conv2d(256, 256, 1)
         self.bn_end0 = _norm(norm, 256)
         self.l0 = nn.Conv2d(256, last_ch, 1)
+        self._packed = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, '_packed', None))
+
+    def __getstate__(self):                        # the pack token refers to a live context: never pickled / deep-copied
+        d = dict(self.__dict__)
+        d['_packed'] = None
+        return d
+
+    def _ctx(self, device):
+        """The device's context with THIS module's weights packed (again after load_state_dict / in-place edits / another module's pack)."""
+        from .. import _lib
+        ctx = _lib.ctx(device)
+        ver = (ctx, id(self), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        if self._packed != ver or not _lib.owns(ctx, 'hgfilter', ver):
+            w = _lib.HGFilterWeights(self)
+            _lib.check(_lib.lib().avc_hgfilter_pack(ctx, w.struct))
+            self._packed = ver
+            _lib.set_owner(ctx, 'hgfilter', ver)
+        return ctx
+
+    def encode(self, x, want_feat=True, want_normx=False, bind=False):
+        """One avc_hgfilter_forward per batch item.  x (B,6,H,W) float32 on the HIP device -> (feat (B,last_ch,H1,W1) | None, normx | None);
+        bind=True also makes the (last) item's feature map the context's image feature map (no NCHW round trip, B must be 1)."""
+        from .. import _lib
+        if not x.is_cuda:
+            raise RuntimeError('HGFilter runs on the HIP device only (csrc/conv_enc.hip); there is no CPU path')
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError('HGFilter: inference only -- call under torch.no_grad() (training is out of scope, SURVEY.md section 2)')
+        if bind and x.shape[0] != 1:
+            raise ValueError('HGFilter.encode(bind=True): one frame at a time (B == 1)')
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        ctx = self._ctx(x.device)
+        feat = torch.empty((B, self.l0.out_channels, H1, W1), dtype=torch.float32, device=x.device) if want_feat else None
+        normx = torch.empty((B, 128, H1, W1), dtype=torch.float32, device=x.device) if want_normx else None
+        for b in range(B):
+            _lib.check(_lib.lib().avc_hgfilter_forward(ctx, x[b].data_ptr(), H, W, feat[b].data_ptr() if want_feat else None,
+                                                       normx[b].data_ptr() if want_normx else None, 1 if bind else 0, _lib.stream_ptr(x.device)))
+        return feat, normx
 
     def forward(self, x):
-        x = norm_relu(self.bn1, self.conv1(x))
-        normx = x = self.conv2(x)                       # 'no_down' branch (HGFilters.py:184-185)
-        x = self.conv4(self.conv3(x))
-        ll = self.top_m_0(self.m0(x))
-        ll = norm_relu(self.bn_end0, self.conv_last0(ll))
-        out = self.l0(ll)
-        return [torch.tanh(out) if self.use_sigmoid else out], normx
+        """-> ([outputs[-1]], normx)   (HGFilters.py:176-219 with stack == 1)"""
+        feat, normx = self.encode(x, want_feat=True, want_normx=True)
+        return [torch.tanh(feat) if self.use_sigmoid else feat], normx

@@ -1,6 +1,6 @@
 """Host-side mirror of the reference's `network/arch_recon.py` (ReconNetwork, :9-76).
 
-`image_encoder` (HGFilter) runs once per frame on PyTorch-ROCm / MIOpen; the per-point decoder
+`image_encoder` (HGFilter) runs once per frame as hand-written HIP (csrc/conv_enc.hip); the per-point decoder
 (bilinear 32-channel sample + z + weight-normed LeakyReLU MLP + sigmoid) runs in recon_kernel
 (csrc/fused_mlp.hip).  state_dict keys match recon_net.pt.
 """
@@ -25,49 +25,33 @@ class ReconNetwork(nn.Module):
         self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, '_packed_version', None))
 
     def get_feat_maps(self, image):
-        """`self.image_encoder(image)[0]` (arch_recon.py:52-53).  On the HIP device the encoder's ~200 launches per frame (MIOpen convolutions, the fused
-        GroupNorm op, bicubic up-sampling, adds / cats: ~5 ms of kernels that the host needs ~8 ms to enqueue) are recorded ONCE per input shape and set
-        of weights as a hipGraph (torch.cuda.CUDAGraph) and replayed with one launch per frame: the same kernels on the same arguments -- results are bit
-        for bit those of the eager call (tests/test_gpu_producers.py).  `config.hg_graph = False` keeps the eager launches."""
-        from .unets import deterministic_convs
+        """`self.image_encoder(image)[0]` (arch_recon.py:52-53): the hand-written HIP encoder (csrc/conv_enc.hip), replayed as one hipGraph per
+        input size (`config.hg_graph`, avc_set_option "enc_graph"; plain launches of the same kernels give the same bits)."""
         from .. import config
-        if image.is_cuda and getattr(config, 'hg_graph', True) and not torch.is_grad_enabled():
-            out = self._graph_feat_maps(image)
-            if out is not None:
-                return out
-        with deterministic_convs():              # bit-identical feature maps from call to call (see unets.deterministic_convs)
-            feat_maps, _ = self.image_encoder(image)
-        return feat_maps
+        if image.is_cuda:
+            _lib.set_option('enc_graph', 1 if getattr(config, 'hg_graph', True) else 0, image.device)
+        feat, _ = self.image_encoder.encode(image, want_feat=True)
+        return [feat]
 
-    def _graph_feat_maps(self, image):
-        from .unets import deterministic_convs
-        key = (tuple(image.shape), image.dtype, image.device, tuple(p._version for p in self.image_encoder.parameters()),
-               tuple(p.data_ptr() for p in self.image_encoder.parameters()))
-        g = getattr(self, '_hg_graph', None)
-        if g is None or g['key'] != key:
-            if getattr(self, '_hg_graph_failed', None) == key:
-                return None
-            try:
-                static_in = image.detach().clone()
-                side = torch.cuda.Stream(device=image.device)
-                side.wait_stream(torch.cuda.current_stream(image.device))
-                with torch.cuda.stream(side), deterministic_convs():
-                    for _ in range(2):          # MIOpen's solution search, workspace and the GroupNorm op's scratch: all settled before the capture
-                        self.image_encoder(static_in)
-                torch.cuda.current_stream(image.device).wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                with deterministic_convs(), torch.cuda.graph(graph):
-                    feat_maps, _ = self.image_encoder(static_in)
-                g = self._hg_graph = {'key': key, 'graph': graph, 'in': static_in, 'out': feat_maps}
-            except Exception as e:              # noqa: BLE001 -- a capture the runtime refuses falls back to the eager launches of the same kernels, once, loudly
-                import warnings
-                warnings.warn(f'HGFilter: hipGraph capture failed ({type(e).__name__}: {e}); launching eagerly')
-                self._hg_graph_failed = key
-                self._hg_graph = None
-                return None
-        g['in'].copy_(image)
-        g['graph'].replay()
-        return [t.clone() for t in g['out']]       # the graph's output buffers are rewritten by the next replay
+    def bind_feat_map(self, image):
+        """The encoder's output for this frame becomes the context's image feature map directly (channel-last as the decoder reads it: no NCHW
+        tensor, no avc_set_img_feat_map).  -> the token `decode` / `decode_grid` take in place of a feature map."""
+        from .. import config
+        _lib.set_option('enc_graph', 1 if getattr(config, 'hg_graph', True) else 0, image.device)
+        self.image_encoder.encode(image, want_feat=False, bind=True)
+        ctx = _lib.ctx(image.device)
+        token = ('bound', id(self), int(image.data_ptr()), tuple(image.shape))
+        _lib.set_owner(ctx, 'img_feat_map', token)
+        return token
+
+    def _set_map(self, ctx, img_feat_map, dev):
+        if isinstance(img_feat_map, tuple):                       # bind_feat_map's token
+            if not _lib.owns(ctx, 'img_feat_map', img_feat_map):
+                raise RuntimeError('decode: the bound image feature map has been replaced since bind_feat_map()')
+            return
+        m = img_feat_map
+        _lib.check(_lib.lib().avc_set_img_feat_map(ctx, _lib.dev_ptr(m, name='img_feat_map'), m.shape[0], m.shape[1], m.shape[2], _lib.stream_ptr(dev)))
+        _lib.set_owner(ctx, 'img_feat_map', None)
 
     def _ctx(self, device):
         ctx = _lib.ctx(device)
@@ -87,14 +71,14 @@ class ReconNetwork(nn.Module):
         (include/avcap.h avc_recon_query_grid: ~1e-6 from `infer` on the same points), everything else is bit-identical to `infer`.  -> (1,N)"""
         with torch.no_grad():
             imgs = torch.cat([items['front_normal'], items['back_normal']], dim=1)
-            img_feat_map = self.get_feat_maps(imgs)[-1].contiguous()
-            return self.decode_grid(axes, res, img_feat_map, items['cano_smpl_center'], index)
+            return self.decode_grid(axes, res, self.bind_feat_map(imgs), items['cano_smpl_center'], index)
 
     def decode_grid(self, axes, res, img_feat_map, center, index=None):
         import ctypes as C
         res = [int(r) for r in res]
         dev = axes[0].device
-        if img_feat_map.shape[0] != 1:
+        bound = isinstance(img_feat_map, tuple)
+        if not bound and img_feat_map.shape[0] != 1:
             raise ValueError('decode_grid: one frame at a time (B == 1)')
         N = res[0] * res[1] * res[2] if index is None else int(index.numel())
         for a, r in zip(axes, res):
@@ -102,8 +86,7 @@ class ReconNetwork(nn.Module):
                 raise ValueError(f'decode_grid: axis table of {a.numel()} entries for a resolution of {r}')
         ctx = self._ctx(dev)
         out = torch.empty((1, N), dtype=torch.float32, device=dev)
-        m = img_feat_map[0]
-        _lib.check(_lib.lib().avc_set_img_feat_map(ctx, _lib.dev_ptr(m, name='img_feat_map'), m.shape[0], m.shape[1], m.shape[2], _lib.stream_ptr(dev)))
+        self._set_map(ctx, img_feat_map if bound else img_feat_map[0], dev)
         ax = (_lib.dev_ptr(axes[0], name='axis_x'), _lib.dev_ptr(axes[1], name='axis_y'), _lib.dev_ptr(axes[2], name='axis_z'))
         if index is None:
             _lib.check(_lib.lib().avc_recon_query_grid(ctx, *ax, (C.c_int32 * 3)(*res), _lib.f3(center[0]), out.data_ptr(), _lib.stream_ptr(dev)))
@@ -121,18 +104,20 @@ class ReconNetwork(nn.Module):
             pts = items['cano_pts'].contiguous()
             B, N, _ = pts.shape
             imgs = torch.cat([items['front_normal'], items['back_normal']], dim=1)
-            img_feat_map = self.get_feat_maps(imgs)[-1].contiguous()
-            return self.decode(pts, img_feat_map, items['cano_smpl_center'])
+            if B == 1:
+                return self.decode(pts, self.bind_feat_map(imgs), items['cano_smpl_center'])
+            return self.decode(pts, self.get_feat_maps(imgs)[-1], items['cano_smpl_center'])
 
     def decode(self, pts, img_feat_map, center):
         """The per-point loop of infer (arch_recon.py:55-73) for a given feature map."""
         B, N, _ = pts.shape
         ctx = self._ctx(pts.device)
         out = torch.empty((B, N), dtype=torch.float32, device=pts.device)
+        bound = isinstance(img_feat_map, tuple)
+        if bound and B != 1:
+            raise ValueError('decode: a bound feature map serves one frame (B == 1)')
         for b in range(B):
-            m = img_feat_map[b]
-            _lib.check(_lib.lib().avc_set_img_feat_map(ctx, _lib.dev_ptr(m, name='img_feat_map'), m.shape[0], m.shape[1], m.shape[2],
-                                                       _lib.stream_ptr(pts.device)))
+            self._set_map(ctx, img_feat_map if bound else img_feat_map[b], pts.device)
             _lib.check(_lib.lib().avc_recon_query(ctx, _lib.dev_ptr(pts[b], name='cano_pts'), N, _lib.f3(center[b]),
                                                   out[b].data_ptr(), _lib.stream_ptr(pts.device)))
         # the reference concatenates (B,1,n) chunks and squeezes dim 0 (arch_recon.py:73-76): (1,N) for B == 1, which is what

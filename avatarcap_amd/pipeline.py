@@ -157,7 +157,7 @@ class FramePipeline:
         rn = self.recon_net
         with _stage('avc/hgfilter'):
             imgs = torch.cat([items['front_normal'], items['back_normal']], dim=1)                 # arch_recon.py:51-53
-            img_feat_map = rn.get_feat_maps(imgs)[-1].contiguous()
+            img_feat_map = rn.bind_feat_map(imgs)                                                  # the encoder's channel-last output IS the decoder's map
         with _stage('avc/recon_query'):
             if kind == 'dense':
                 out = rn.decode_grid(self.ds.grid_axes, self.vol_res, img_feat_map, items['cano_smpl_center'])                      # :440, on the grid (column-folded)

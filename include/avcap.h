@@ -76,6 +76,45 @@ int avc_set_pose_feat_map(avc_ctx *ctx, const float *map_nchw_dev, int C, int H,
 /* img_feat_map = HGFilter(cat(front,back))[-1], (1,C=32,H,W) (network/arch_recon.py:51-52) */
 int avc_set_img_feat_map(avc_ctx *ctx, const float *map_nchw_dev, int C, int H, int W, avc_stream stream);
 
+/* ---- the image encoder -------------------------------------------------------------------------
+ * ReconNetwork.image_encoder = HGFilter(1, 4, 6, 32, 'group', 'no_down', False) (network/arch_recon.py:29;
+ * network/HGFilters.py:124-219 HGFilter, :33-75 ConvBlock, :77-121 HourGlass), hand-written for gfx950
+ * (csrc/conv_enc.hip): implicit-GEMM convolutions on split-fp16 MFMA with GroupNorm + ReLU applied while
+ * the input tile is staged, GroupNorm statistics produced by the convolution before, avg_pool / bicubic
+ * up-sampling as small fused kernels, the whole encoder replayed as one hipGraph.
+ *
+ * Weights exactly as the state_dict stores them (host pointers, copied at pack time):
+ *   avc_conv2d     w (cout, cin, kh, kw) row-major, b (cout) or NULL
+ *   avc_groupnorm  gamma, beta (channels); torch.nn.GroupNorm(groups, channels, eps)
+ *   avc_convblock  conv1..3 (3x3, no bias), downsample[2] (1x1, no bias; w == NULL when in == out planes),
+ *                  bn1..bn4 (bn4 is only read when the projection exists)
+ *   avc_hgfilter   conv1 (7x7 s2 p3), bn1, conv2..4, the hourglass' 3 depth + 1 blocks in the order
+ *                  b1_d, b2_d, b1_{d-1}, b2_{d-1}, ..., b1_1, b2_1, b2_plus_1, b3_1, ..., b3_d, then top_m_0,
+ *                  conv_last0 (1x1), bn_end0, l0 (1x1).  Only stack == 1, 'group' norm, 'no_down' are on the path. */
+typedef struct { const float *w, *b; int32_t cout, cin, kh, kw; } avc_conv2d;
+typedef struct { const float *gamma, *beta; int32_t channels, groups; float eps; } avc_groupnorm;
+typedef struct { avc_conv2d conv[3]; avc_conv2d downsample; avc_groupnorm bn[4]; } avc_convblock;
+typedef struct {
+    avc_conv2d conv1; avc_groupnorm bn1;
+    avc_convblock conv2, conv3, conv4;
+    int32_t depth; const avc_convblock *hourglass;
+    avc_convblock top_m;
+    avc_conv2d conv_last; avc_groupnorm bn_end; avc_conv2d l;
+} avc_hgfilter;
+int avc_hgfilter_pack(avc_ctx *ctx, const avc_hgfilter *net);
+/* HGFilter.forward (network/HGFilters.py:176-219) for one image: image_dev (6, H, W) NCHW as the reference passes
+ * cat(front_normal, back_normal) -> outputs[-1] = l0(...) as feat_out_dev (32, H1, W1) NCHW (or NULL) and normx
+ * (the conv2 block's output) as normx_out_dev (128, H1, W1) (or NULL), H1 = (H - 1) / 2 + 1.  With
+ * bind_img_feat_map != 0 the context's image feature map (avc_set_img_feat_map) becomes this frame's feature map without
+ * the NCHW round trip.  H1 and W1 must be divisible by 2^depth (the reference adds up1 + up2 of equal size). */
+int avc_hgfilter_forward(avc_ctx *ctx, const float *image_dev, int H, int W, float *feat_out_dev, float *normx_out_dev,
+                         int bind_img_feat_map, avc_stream stream);
+
+/* Test hook: the output of launch `launch` of the last avc_hgfilter_forward's plan (which = 0: the launch's own output, 1: the block output y
+ * it adds its slice to) as NCHW; *C, *H, *W receive its shape (for a convolution *C also carries the tile configuration in its high bits).
+ * out_nchw_dev may be NULL (shape query).  Returns 1 when the launch has no such output, a negative status on errors. */
+int avc_hgfilter_debug_tensor(avc_ctx *ctx, int launch, int which, float *out_nchw_dev, int32_t *C, int32_t *H, int32_t *W, avc_stream stream);
+
 /* GroupNorm of the image encoder, with the ReLU that follows every one of them fused in
  * (network/HGFilters.py:46-49,64-66,141,165,178,204; torch.nn.GroupNorm semantics: per (n, group) mean and
  * biased variance over (C/G, H, W), y = (x - mean) / sqrt(var + eps) * gamma[c] + beta[c]).
@@ -259,7 +298,10 @@ int avc_timing_read_cycles(avc_ctx *ctx, int which, double *avg_cycles_out, int6
  *                                    point queries instead of ~1e-6 from them
  *   "mlp_blocks"   0 (default: one persistent workgroup per CU) | n
  *   "knn_search"   0 (default: per wave) | 1 per-lane grid search | 2 cooperative grid search | 3 exhaustive scan -- all four return the same bits
- *   "fusion_graph" 1 (default: the fusion iterations replay a hipGraph) | 0 plain launches */
+ *   "fusion_graph" 1 (default: the fusion iterations replay a hipGraph) | 0 plain launches
+ *   "enc_graph"    1 (default: avc_hgfilter_forward replays a hipGraph) | 0 plain launches -- same kernels, same bits
+ *   "enc_lastwg"   1 (default: a convolution's last workgroup folds the GroupNorm partials it and its peers wrote) | 0 a launch of its own does --
+ *                  same summation order, same bits */
 int avc_set_option(avc_ctx *ctx, const char *name, int value);
 
 #ifdef __cplusplus

@@ -1,4 +1,4 @@
-"""The two per-frame convolutional producers ON THE GPU (PyTorch-ROCm / MIOpen + the fused GroupNorm op) against goldens produced
+"""The two per-frame convolutional producers ON THE GPU (the U-Net on MIOpen, HGFilter on the hand-written HIP encoder) against goldens produced
 by the reference's own modules on the CPU: UnetNoCond7DS (network/unets.py:169-229) at 128^2 and at its real 256^2 input,
 HGFilter (network/HGFilters.py:124-219) at 64^2 and at its real 512^2 input, and ReconNetwork.infer end to end (arch_recon.py:45-76).
 Bar: north_star's 1e-4 on O(1) outputs (relative to max(1, |golden|_max)); the measured errors are printed.  Also: the producers must give
@@ -43,28 +43,102 @@ def test_unet7ds_on_miopen_matches_reference(golden):
         assert torch.equal(first, again), float((first - again).abs().max())  # first call == later calls, bit for bit
 
 
-def test_hgfilter_on_miopen_matches_reference(golden):
+def _hg():
     from avatarcap_amd.network.HGFilters import HGFilter
     hg = HGFilter(1, 4, 6, 32, 'group', 'no_down', False).to('cuda').eval()
     syn.load_synth(hg, gi.SEED_NET)
+    return hg
+
+
+def _walk_plan(hg, x, tol=1e-4):
+    """Every launch of the HIP encoder's plan against the stock-torch restatement of the same tensor (tests/torch_hgfilter.py, fp32 on the GPU):
+    names the first launch that disagrees.  Returns the worst relative error and the plan's launch kinds."""
+    import ctypes as C
+    from avatarcap_amd import _lib
+    from torch_hgfilter import hgfilter_trace
+    with torch.no_grad():
+        hg.encode(x)
+        torch.cuda.synchronize()
+        trace = hgfilter_trace(hg, x)
+    ctx, L = _lib.ctx(x.device), _lib.lib()
+    launch, worst, report = 0, 0.0, []
+    for name, which, ref in trace:
+        while True:                                   # skip launches without a tensor (separate statistics launches)
+            c, h, w = C.c_int32(), C.c_int32(), C.c_int32()
+            rc = L.avc_hgfilter_debug_tensor(ctx, launch, 1 if which == 'y' else 0, None, C.byref(c), C.byref(h), C.byref(w), None)
+            assert rc >= 0, L.avc_last_error()
+            if rc == 0:
+                break
+            launch += 1
+        cfg = c.value >> 16
+        ch = c.value & 0xffff
+        assert (ch, h.value, w.value) == tuple(ref.shape[1:]), (name, launch, (ch, h.value, w.value), tuple(ref.shape))
+        got = torch.empty_like(ref[0])
+        _lib.check(L.avc_hgfilter_debug_tensor(ctx, launch, 1 if which == 'y' else 0, got.data_ptr(), C.byref(c), C.byref(h), C.byref(w), _lib.stream_ptr(x.device)))
+        torch.cuda.synchronize()
+        e = float((got - ref[0]).abs().max()) / max(1.0, float(ref.abs().max()))
+        report.append((launch, name, tuple(ref.shape[1:]), f'CT{cfg & 15} PT{(cfg >> 4) & 15} taps{cfg >> 8}' if cfg else '', e))
+        worst = max(worst, e)
+        launch += 1
+    for r in report:
+        print('  launch %3d %-22s %-16s %-16s %.3e' % r)
+    bad = [r for r in report if not r[4] < tol]
+    assert not bad, f'first launch off: {bad[0]}'
+    return worst
+
+
+@pytest.mark.parametrize('res', [64, 512])
+def test_hgfilter_launch_by_launch(res):
+    """The hand-written encoder (csrc/conv_enc.hip), every intermediate tensor against stock torch ops on the same device."""
+    hg = _hg()
+    x = _t(gi.normal_maps(res)[None])
+    worst = _walk_plan(hg, x)
+    print(f'HGFilter {res}^2, HIP encoder vs stock torch ops launch by launch: worst {worst:.3e} (relative to max(1, |ref|max))')
+
+
+def test_hgfilter_matches_reference(golden):
+    """HGFilter.forward on the HIP encoder against goldens of the reference's own module on the CPU (64^2 and the real 512^2 input)."""
+    hg = _hg()
     with torch.no_grad():
         for res, gold in ((64, golden['G7_hg_samples']), (512, PG['G7_hg512_samples'])):
-            y = hg(_t(gi.normal_maps(res)[None]))[0][-1][0]
-            assert y.shape == (32, res // 2, res // 2)
+            outs, normx = hg(_t(gi.normal_maps(res)[None]))
+            y = outs[-1][0]
             q = res // 2
+            assert y.shape == (32, q, q) and normx.shape == (1, 128, q, q)
             got = y[:, torch.from_numpy(gi.PIX[:, 0] % q).cuda(), torch.from_numpy(gi.PIX[:, 1] % q).cuda()].cpu().numpy()
             e = _rel(got, gold)
-            print(f'HGFilter {res}^2 on MIOpen + avc_group_norm vs reference (CPU): {e:.3e} relative to max(1, |g|max = {np.abs(gold).max():.2f})')
+            print(f'HGFilter {res}^2 on the HIP encoder vs reference (CPU): {e:.3e} relative to max(1, |g|max = {np.abs(gold).max():.2f})')
             assert e < 1e-4
         assert abs(float(y.abs().mean()) / float(PG['G7_hg512_absmean']) - 1) < 1e-5
         nm = _t(gi.normal_maps(512, seed=78)[None])
         first = hg(nm)[0][-1].clone()
         again = hg(nm)[0][-1]
-        assert torch.equal(first, again), float((first - again).abs().max())
+        assert torch.equal(first, again), float((first - again).abs().max())          # deterministic: no floating-point atomics anywhere
+
+
+def test_hgfilter_switches_change_nothing():
+    """hipGraph replay vs plain launches, last-workgroup statistics vs a statistics launch of their own: the same bits; new weights are picked up."""
+    from avatarcap_amd import _lib
+    hg = _hg()
+    a = _t(gi.normal_maps(512, seed=78)[None])
+    with torch.no_grad():
+        base = hg(a)[0][-1].clone()
+        try:
+            for g, l in ((0, 1), (1, 0), (0, 0)):
+                _lib.set_option('enc_graph', g)
+                _lib.set_option('enc_lastwg', l)
+                assert torch.equal(hg(a)[0][-1], base), (g, l)
+        finally:
+            _lib.set_option('enc_graph', 1)
+            _lib.set_option('enc_lastwg', 1)
+        b = _t(gi.normal_maps(512, seed=79)[None])
+        assert not torch.equal(hg(b)[0][-1], base) and torch.equal(hg(a)[0][-1], base)     # a second input through the same graph
+        syn.load_synth(hg, gi.SEED_NET + 3)
+        assert not torch.equal(hg(a)[0][-1], base)                                          # new weights: packed again
 
 
 def test_recon_infer_end_to_end_at_512(golden):
-    """HGFilter on MIOpen + fused decoder vs the reference's infer() on the CPU, at the real 512^2 map size and at 64^2."""
+    """HGFilter on the HIP encoder + fused decoder vs the reference's infer() on the CPU, at the real 512^2 map size and at 64^2."""
     from avatarcap_amd.network.arch_recon import ReconNetwork
     rn = ReconNetwork().to('cuda').eval()
     syn.load_synth(rn, gi.SEED_NET)
@@ -79,31 +153,3 @@ def test_recon_infer_end_to_end_at_512(golden):
         assert e < 1e-4
 
 
-def test_hgfilter_graph_replay_equals_eager_launches():
-    """ReconNetwork.get_feat_maps replays the encoder as a hipGraph (config.hg_graph): the same kernels on the same arguments -- the feature map is bit
-    for bit the eager call's, for a second input through the same graph, after new weights (re-capture), and the replay really is taken."""
-    from avatarcap_amd import config
-    from avatarcap_amd.network.arch_recon import ReconNetwork
-    rn = ReconNetwork().to('cuda').eval()
-    syn.load_synth(rn, gi.SEED_NET)
-    a, b = _t(gi.normal_maps(512, seed=78)[None]), _t(gi.normal_maps(512, seed=79)[None])
-    with torch.no_grad():
-        config.hg_graph = False
-        try:
-            ea, eb = rn.get_feat_maps(a)[-1].clone(), rn.get_feat_maps(b)[-1].clone()
-        finally:
-            config.hg_graph = True
-        ga = rn.get_feat_maps(a)[-1]
-        assert rn._hg_graph is not None and getattr(rn, '_hg_graph_failed', None) is None          # captured, not fallen back
-        gb = rn.get_feat_maps(b)[-1]
-        assert torch.equal(ga, ea) and torch.equal(gb, eb)
-        assert torch.equal(rn.get_feat_maps(a)[-1], ea) and ga.data_ptr() != rn.get_feat_maps(a)[-1].data_ptr()   # fresh tensors, not the graph's buffers
-        key = rn._hg_graph['key']
-        syn.load_synth(rn, gi.SEED_NET + 3)                                                          # new weights: the graph is recorded again
-        gc = rn.get_feat_maps(a)[-1]
-        assert rn._hg_graph['key'] != key and not torch.equal(gc, ea)
-        config.hg_graph = False
-        try:
-            assert torch.equal(rn.get_feat_maps(a)[-1], gc)
-        finally:
-            config.hg_graph = True

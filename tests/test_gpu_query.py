@@ -233,7 +233,14 @@ def test_recon_grid_subset_query(res, n):
 @pytest.mark.parametrize('shape,G', [((1, 64, 128, 128), 32), ((2, 96, 17, 23), 32), ((1, 256, 16, 16), 32), ((3, 8, 5, 7), 4)])
 def test_group_norm_relu_matches_torch(shape, G):
     """avc_group_norm against torch.nn.functional.group_norm (+ relu); odd sizes take the unaligned path."""
-    from avatarcap_amd.network.HGFilters import norm_relu
+    from avatarcap_amd import _lib
+
+    def norm_relu(m, x):                               # the stand-alone op of the C-ABI (the encoder itself fuses its GroupNorms: csrc/conv_enc.hip)
+        y = torch.empty_like(x)
+        N, Cc = x.shape[0], x.shape[1]
+        _lib.check(_lib.lib().avc_group_norm(_lib.ctx(x.device), x.data_ptr(), N, Cc, x.numel() // (N * Cc), m.num_groups, m.weight.data_ptr(),
+                                             m.bias.data_ptr(), float(m.eps), 1, y.data_ptr(), _lib.stream_ptr(x.device)))
+        return y
     g = torch.Generator().manual_seed(sum(shape))
     m = torch.nn.GroupNorm(G, shape[1]).cuda()
     with torch.no_grad():
