@@ -58,6 +58,8 @@ struct Options {
     int fusion_graph = 1;     // normal-fusion iterations replayed as a hipGraph (AVC_FUSION_NO_GRAPH=1 -> 0)
     int enc_graph = 1;        // the image encoder's launches replayed as a hipGraph
     int enc_lastwg = 1;       // GroupNorm statistics folded by the last workgroup of the producing launch (0: by a launch of their own)
+    int enc_ksplit = 1;       // convolutions with few workgroups split K over several (partial sums in HBM, added in a fixed order by the last to arrive)
+    int enc_fork = 1;         // the hourglass' upper branches (b1_k) run on a second stream beside the lower ones
 };
 
 }  // namespace avc

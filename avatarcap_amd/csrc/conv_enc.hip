@@ -56,12 +56,7 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_in
 
 // ---- LDS map of conv_mfma_kernel ---------------------------------------------------------------------------------------
 constexpr int PIXB = 144;                       // bytes per staged pixel: 32 channels x (hi, lo) halves + 16 pad (odd multiple of 16: conflict-free b128 reads)
-constexpr int ACT_BYTES = 49152;                // one staged chunk: up to 340 halo pixels
-constexpr int RING_SLOT = 16384, RING_SLOTS = 3;
-constexpr int LDS_ACT0 = 0, LDS_ACT1 = ACT_BYTES, LDS_RING = 2 * ACT_BYTES;
-constexpr int LDS_AB = LDS_RING + RING_SLOTS * RING_SLOT;       // (a, b) of the prologue's affine map per input channel (<= 256)
-constexpr int LDS_FLAG = LDS_AB + 2048;
-constexpr int LDS_TOTAL = LDS_FLAG + 64;
+constexpr int RING_SLOT = 16384;                // one slot of the weight ring: a group of 4 / CT taps
 constexpr int MAX_CIN = 256;
 
 // Group statistics a launch contributes to (torch.nn.GroupNorm: mean and biased variance over (C/G, H, W)).
@@ -93,6 +88,9 @@ struct ConvArgs {
     StatOut st_raw, st_y;
     unsigned *counter;           // ticket of the last-workgroup reduction (self-resetting); null = a finalise launch follows
     int tiles_x, tiles_y;
+    int ksplit;                  // workgroups per (tile, slice): each walks Cin / 32 / ksplit chunks of K (1: no split)
+    float *kpart;                // split-K: [tile x slice][ksplit][accumulator registers][256 threads] raw sums
+    unsigned *kcounter;          // split-K: one ticket per (tile, slice)
 };
 
 __device__ __forceinline__ float relu_bits(float x)
@@ -116,42 +114,69 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigne
 __device__ __forceinline__ constexpr int d_row0(int r) { return (r & 3) + 8 * (r >> 2); }      // + 4 h
 
 // ---- statistics: fold the per-tile partials of `groups` groups into (mean, rstd); one workgroup, fixed order, double ------------
+// Partials are written and read with device-scope (sc1) accesses: they cross XCDs, whose L2s are not coherent with each other.
+__device__ __forceinline__ void store_partial(float *part, size_t index, float s, float q)
+{
+    const unsigned long long v = (unsigned long long)__builtin_bit_cast(unsigned, s) | ((unsigned long long)__builtin_bit_cast(unsigned, q) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(part) + index, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void finalize_stats(const StatOut &st, int ntiles, int tid)
 {
     if (!st.part) return;
     const int lane = tid & 63, wave = tid >> 6;
-    for (int g = wave; g < st.groups; g += 4) {
-        double s = 0.0, q = 0.0;
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(st.part) + (size_t)g * ntiles;
-        for (int t = lane; t < ntiles; t += 64) {
-            // device-scope load: the partials were written by workgroups on other XCDs (their L2s are not coherent with ours)
-            const unsigned long long v = __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s += (double)__builtin_bit_cast(float, (unsigned)v);
-            q += (double)__builtin_bit_cast(float, (unsigned)(v >> 32));
+    constexpr int U = 4;                                   // groups in flight per wave: every load of a pass is issued before the first add
+    for (int g0 = wave * U; g0 < st.groups; g0 += 4 * U) {
+        double s[U], q[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] = q[u] = 0.0;
+        for (int t0 = 0; t0 < ntiles; t0 += 256) {
+            unsigned long long v[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = t0 + 64 * k + lane, g = g0 + u;
+                    v[u][k] = (t < ntiles && g < st.groups)
+                                  ? __hip_atomic_load(reinterpret_cast<const unsigned long long *>(st.part) + (size_t)g * ntiles + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                  : 0ull;
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s[u] += (double)__builtin_bit_cast(float, (unsigned)v[u][k]);
+                    q[u] += (double)__builtin_bit_cast(float, (unsigned)(v[u][k] >> 32));
+                }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-        if (lane == 0) {
-            const double mean = s * (double)st.inv_n, var = fmax(q * (double)st.inv_n - mean * mean, 0.0);
-            st.stats[2 * g] = (float)mean;
-            st.stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)st.eps));
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { s[u] += __shfl_xor(s[u], o); q[u] += __shfl_xor(q[u], o); }
+            if (lane == 0 && g0 + u < st.groups) {
+                const double mean = s[u] * (double)st.inv_n, var = fmax(q[u] * (double)st.inv_n - mean * mean, 0.0);
+                st.stats[2 * (g0 + u)] = (float)mean;
+                st.stats[2 * (g0 + u) + 1] = (float)(1.0 / sqrt(var + (double)st.eps));
+            }
         }
     }
 }
 
-// the tail every statistics-producing kernel shares: publish this workgroup's partials, take a ticket, the last one folds
+// The tail every statistics-producing kernel shares: this workgroup's partials are out (sc1 stores, acknowledged: vmcnt(0)), take a ticket, the
+// last workgroup folds.  No __threadfence(): at device scope it is an L2 write-back + invalidate per workgroup, with 4 MB of freshly written
+// activations dirty in every XCD's L2 -- measured +18 us per convolution, 1 ms per frame.  The partials are the only data that crosses
+// workgroups inside a launch, and every access to them is a device-scope one.
 __device__ __forceinline__ void stats_tail(const StatOut &a, const StatOut &b, unsigned *counter, int ntiles, unsigned total_wgs, int tid, char *smem_flag)
 {
     if (!counter) return;
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *reinterpret_cast<volatile unsigned *>(smem_flag) = (t == total_wgs - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (*reinterpret_cast<volatile unsigned *>(smem_flag)) {
-        __threadfence();
         finalize_stats(a, ntiles, tid);
         finalize_stats(b, ntiles, tid);
         if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -168,28 +193,41 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(StatOut a, StatOut 
 // CT: 32-channel output tiles per workgroup (B operands), PT: 32-pixel tiles per wave (A operands), TAPS: 9 (3x3, pad 1) or 1,
 // TWC: image columns of a pixel tile (32: one image row; 16: two rows of 16 -- images narrower than 32),
 // NORM: the input goes through relu(GroupNorm(.)) while it is staged (else: raw).
+// LDS map (per instantiation): [staged chunk A | staged chunk B | weight ring of RS 16-KiB slots | (a, b) table | flag].
+template <int PT, int TAPS, int TWC>
+struct ConvGeo {
+    static constexpr int PTR = 32 / TWC;                          // image rows of one pixel tile
+    static constexpr int ROWS = 4 * PT * PTR;                     // image rows of the workgroup's tile
+    static constexpr int PAD = TAPS == 9 ? 1 : 0;
+    static constexpr int RP = TAPS == 9 ? (TWC == 32 ? 34 : 32) : TWC;      // LDS row pitch in pixels (32 for the 16-wide 3x3 tile: bank note in DESIGN.md)
+    static constexpr int HR = ROWS + 2 * PAD, HC = TWC + 2 * PAD;
+    static constexpr int NPIX = HR * RP;
+    static constexpr int ACTB = (NPIX * PIXB + 1023) & ~1023;
+    static constexpr int RS_FIT = (163840 - 2048 - 64 - 2 * ACTB) / RING_SLOT;
+    static constexpr int RS = RS_FIT > 6 ? 6 : RS_FIT;            // ring slots; RS - 1 groups of weights are in flight
+    static constexpr int L_ACT0 = 0, L_ACT1 = ACTB, L_RING = 2 * ACTB, L_AB = L_RING + RS * RING_SLOT, L_FLAG = L_AB + 2048, L_TOTAL = L_FLAG + 64;
+    static_assert(RS >= 3, "no room for the weight ring");
+};
+
 template <int CT, int PT, int TAPS, int TWC, bool NORM>
 __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PTR = 32 / TWC;                          // image rows of one pixel tile
-    constexpr int ROWS = 4 * PT * PTR;                     // image rows of the workgroup's tile
-    constexpr int PAD = TAPS == 9 ? 1 : 0;
-    constexpr int RP = TAPS == 9 ? (TWC == 32 ? 34 : 32) : TWC;      // LDS row pitch in pixels (pitch 32 for the 16-wide tile: see the bank note in DESIGN.md)
-    constexpr int HR = ROWS + 2 * PAD, HC = TWC + 2 * PAD;
-    constexpr int NPIX = HR * RP;
-    static_assert(NPIX * PIXB <= ACT_BYTES, "staged tile does not fit its LDS buffer");
+    using Geo = ConvGeo<PT, TAPS, TWC>;
+    constexpr int PTR = Geo::PTR, ROWS = Geo::ROWS, PAD = Geo::PAD, RP = Geo::RP, HC = Geo::HC, NPIX = Geo::NPIX;
+    constexpr int LDS_ACT0 = Geo::L_ACT0, LDS_ACT1 = Geo::L_ACT1, LDS_RING = Geo::L_RING, LDS_AB = Geo::L_AB, LDS_FLAG = Geo::L_FLAG;
+    constexpr int RS = Geo::RS, LA = RS - 1;                // ring slots, groups of weights in flight
     constexpr int NPIECE = (NPIX * 8 + 255) / 256;         // 16-byte pieces (4 channels of one pixel) per thread and chunk
-    constexpr int STEP_BYTES = 2 * CT * 2048;              // weights of one (chunk, tap): 2 k-steps x CT tiles x [hi | lo]
-    static_assert(STEP_BYTES <= RING_SLOT, "ring slot too small");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int slices = p.Cout / (32 * CT);
-    const int slice = blockIdx.x % slices, tile = blockIdx.x / slices;
+    // blockIdx -> (k slice, channel slice, pixel tile): a workgroup walks the chunks [c0, c1) of the input channels (split-K launches: ksplit > 1)
+    const int ks = blockIdx.x % p.ksplit, wg = blockIdx.x / p.ksplit;
+    const int slice = wg % slices, tile = wg / slices;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int y0 = ty * ROWS, x0 = tx * TWC;
-    const int nchunks = p.Cin >> 5, nsteps = nchunks * TAPS;
+    const int cpk = (p.Cin >> 5) / p.ksplit, c0 = ks * cpk, c1 = c0 + cpk;
 
     // ---- the prologue's affine map per input channel: relu(a x + b), a = gamma rstd, b = beta - mean a (both times in_scale)
     if (tid < p.Cin) {
@@ -245,23 +283,56 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
             unsigned h01, l01, h23, l23;
             split2(v0, v1, h01, l01);
             split2(v2, v3, h23, l23);
-            if (goff[i] < 0) { h01 = l01 = h23 = l23 = 0u; }
+            const bool in = goff[i] >= 0;                  // zero padding is applied to the normalised tensor: out-of-image pieces are zeros, not relu(b)
+            h01 = in ? h01 : 0u; l01 = in ? l01 : 0u; h23 = in ? h23 : 0u; l23 = in ? l23 : 0u;
             const unsigned a = buf + ((tid >> 3) + 32 * i) * PIXB + sub * 8;
             *reinterpret_cast<u32x2 *>(smem + a) = u32x2{h01, h23};
             *reinterpret_cast<u32x2 *>(smem + a + 64) = u32x2{l01, l23};
         }
     };
 
-    // ---- weights: buffer LDS-DMA into the ring; wave w moves the w-th quarter of a step (CT pieces of 1 KiB)
+    // ---- weights: buffer LDS-DMA into the ring.  A ring slot (16 KiB) holds a GROUP of G = 4 / CT consecutive taps of one chunk (the stream
+    // is [chunk][tap][k-step][tile], so a group is contiguous); groups restart with every chunk (3x3: CT 4 -> 9 groups of 1 tap, CT 2 -> 5 of
+    // 2, 2, 2, 2, 1, CT 1 -> 3 of 4, 4, 1), one barrier per group, LA = RS - 1 groups in flight: the small-tile kernels are bound by how many
+    // bytes of weights a CU has in flight (their workgroups are few and each streams its slice once, mostly from HBM).
+    // Wave w moves the w-th quarter of a group, 1 KiB per instruction.
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p.wstream), 0, (int)p.wbytes, 0x00027000);
-    const unsigned wbase = slice * p.slice_bytes + wave * (CT * 1024);
+    const unsigned wbase = slice * p.slice_bytes;
     const unsigned lane16 = lane * 16u;
-    auto dma_step = [&](int step) {
-        const unsigned so = wbase + (unsigned)step * STEP_BYTES;
-        const unsigned dst = LDS_RING + (unsigned)(step % RING_SLOTS) * RING_SLOT + wave * (CT * 1024);
-        static_for<CT>([&](auto ic) {
+    constexpr int TAP_BYTES = 2 * CT * 2048;                // one (chunk, tap): 2 k-steps x CT tiles x [hi | lo]
+    constexpr int G = TAPS == 1 ? 1 : 4 / CT, NG = (TAPS + G - 1) / G;
+    auto group_taps = [](int g) constexpr { return (g + 1) * G <= TAPS ? G : TAPS - g * G; };
+    const int ngroups = cpk * NG;
+    // group gi = (c - c0) NG + g (g compile-time) -> ring slot gi % RS
+    auto dma_group = [&](auto gc, int gi) {
+        constexpr int g = decltype(gc)::value, PW = group_taps(g) * CT;                   // 1 KiB pieces per wave
+        const int c = c0 + gi / NG;
+        const unsigned so = wbase + (unsigned)(c * TAPS + g * G) * TAP_BYTES + wave * (PW * 1024);
+        const unsigned dst = LDS_RING + (unsigned)(gi % RS) * RING_SLOT + wave * (PW * 1024);
+        static_for<PW>([&](auto ic) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void *)(smem + dst), 16, (int)lane16, (int)so, decltype(ic)::value * 1024, 0);
         });
+    };
+    auto dma_any = [&](int gi) {                            // run-time group residue
+        const int g = gi % NG;
+        static_for<NG>([&](auto gc) { if (g == decltype(gc)::value) dma_group(gc, gi); });
+    };
+    // "group gi + 1 has landed": in-order completion -> at most the operations issued after its last piece may still be outstanding: the groups
+    // gi + 2 .. gi + min(LA, groups left) (g = gi % NG compile-time, `left` = groups after gi) and, when they were issued behind it, the staging
+    // loads of the next chunk
+    auto wait_next = [&](auto gc, int left, bool staged) {
+        constexpr int g = decltype(gc)::value;
+        bool done = false;
+        static_for<LA>([&](auto kc) {
+            constexpr int k = LA - decltype(kc)::value;     // LA, LA - 1, ..., 1
+            constexpr int n = [&] { int a = 0; for (int i = 2; i <= k; ++i) a += group_taps((g + i) % NG) * CT; return a; }();
+            if (!done && left >= k) {
+                done = true;
+                if (staged) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n + NPIECE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory");
+            }
+        });
+        if (!done) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
 
     // ---- A-operand addresses: pixel tile n of this wave = tile row q = wave PT + n; lane (j, h) reads 8 channels of pixel j
@@ -272,12 +343,12 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         abase[n] = (unsigned)(((q * PTR + r) * RP + cc) * PIXB + h * 16);
     }
 
-    load_acts(0);
-    dma_step(0);
-    if (nsteps > 1) dma_step(1);
+    load_acts(c0);
+    dma_any(0);
     __syncthreads();                                        // the (a, b) table
-    store_acts(0, LDS_ACT0, 0, NPIECE);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    store_acts(c0, LDS_ACT0, 0, NPIECE);
+    for (int gi = 1; gi < LA && gi < ngroups; ++gi) dma_any(gi);
+    wait_next(std::integral_constant<int, NG - 1>{}, ngroups < LA ? ngroups : LA, false);        // group 0 (= "group -1 + 1")
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
@@ -289,57 +360,111 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.0f;
 
-    for (int c = 0; c < nchunks; ++c) {
-        const unsigned abuf = (c & 1) ? LDS_ACT1 : LDS_ACT0, nbuf = (c & 1) ? LDS_ACT0 : LDS_ACT1;
-        const bool more = c + 1 < nchunks;
-        static_for<TAPS>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            const int step = c * TAPS + t;
-            if (t == 0 && more) load_acts(c + 1);
-            const bool dma = step + 2 < nsteps;
-            if (dma) dma_step(step + 2);
-            const unsigned wb = LDS_RING + (unsigned)(step % RING_SLOTS) * RING_SLOT + lane16;
-            constexpr int toff = TAPS == 9 ? ((t / 3) * RP + (t % 3)) * PIXB : 0;
+    // the next chunk's staged tile is transformed and written late: consuming a staging load waits for every weight group requested before it
+    // (vmcnt completes in order), so it is consumed where those groups are due anyway: from the second group on when two are in flight, in the
+    // chunk's last group otherwise
+    constexpr int T0 = TAPS == 1 ? 0 : (LA == 2 ? G : G * (NG - 1));
+    for (int c = c0; c < c1; ++c) {
+        const unsigned abuf = ((c - c0) & 1) ? LDS_ACT1 : LDS_ACT0, nbuf = ((c - c0) & 1) ? LDS_ACT0 : LDS_ACT1;
+        const bool more = c + 1 < c1;
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value, NT = group_taps(g);
+            const int gi = (c - c0) * NG + g;
+            if (g == 0 && more) load_acts(c + 1);
+            // group gi + LA goes into the slot group gi - 1 was read from (every wave is past the barrier that ended it)
+            if (gi + LA < ngroups) dma_group(std::integral_constant<int, (g + LA) % NG>{}, gi + LA);
+            const unsigned wb = LDS_RING + (unsigned)(gi % RS) * RING_SLOT + lane16;
+            static_for<NT>([&](auto tc) {
+                constexpr int tl = decltype(tc)::value, t = g * G + tl;
+                constexpr int toff = TAPS == 9 ? ((t / 3) * RP + (t % 3)) * PIXB : 0;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                half8 bh[CT], bl[CT], ah[PT], al[PT];
+                for (int kk = 0; kk < 2; ++kk) {
+                    half8 bh[CT], bl[CT], ah[PT], al[PT];
 #pragma unroll
-                for (int m = 0; m < CT; ++m) {
-                    bh[m] = *reinterpret_cast<const half8 *>(smem + wb + (kk * CT + m) * 2048);
-                    bl[m] = *reinterpret_cast<const half8 *>(smem + wb + (kk * CT + m) * 2048 + 1024);
+                    for (int m = 0; m < CT; ++m) {
+                        bh[m] = *reinterpret_cast<const half8 *>(smem + wb + ((tl * 2 + kk) * CT + m) * 2048);
+                        bl[m] = *reinterpret_cast<const half8 *>(smem + wb + ((tl * 2 + kk) * CT + m) * 2048 + 1024);
+                    }
+#pragma unroll
+                    for (int n = 0; n < PT; ++n) {
+                        ah[n] = *reinterpret_cast<const half8 *>(smem + abuf + abase[n] + toff + kk * 32);
+                        al[n] = *reinterpret_cast<const half8 *>(smem + abuf + abase[n] + toff + kk * 32 + 64);
+                    }
+#pragma unroll
+                    for (int n = 0; n < PT; ++n)
+#pragma unroll
+                        for (int m = 0; m < CT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bh[m], acc[n][m], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < PT; ++n)
+#pragma unroll
+                        for (int m = 0; m < CT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bl[m], acc[n][m], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < PT; ++n)
+#pragma unroll
+                        for (int m = 0; m < CT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[n], bh[m], acc[n][m], 0, 0, 0);
                 }
-#pragma unroll
-                for (int n = 0; n < PT; ++n) {
-                    ah[n] = *reinterpret_cast<const half8 *>(smem + abuf + abase[n] + toff + kk * 32);
-                    al[n] = *reinterpret_cast<const half8 *>(smem + abuf + abase[n] + toff + kk * 32 + 64);
+                if (more) {
+                    if constexpr (t >= T0) store_acts(c + 1, nbuf, ((t - T0) * NPIECE) / (TAPS - T0), ((t - T0 + 1) * NPIECE) / (TAPS - T0));
                 }
-#pragma unroll
-                for (int n = 0; n < PT; ++n)
-#pragma unroll
-                    for (int m = 0; m < CT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bh[m], acc[n][m], 0, 0, 0);
-#pragma unroll
-                for (int n = 0; n < PT; ++n)
-#pragma unroll
-                    for (int m = 0; m < CT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bl[m], acc[n][m], 0, 0, 0);
-#pragma unroll
-                for (int n = 0; n < PT; ++n)
-#pragma unroll
-                    for (int m = 0; m < CT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[n], bh[m], acc[n][m], 0, 0, 0);
-            }
-            // the next chunk's tile: its pieces are spread over taps 1..8 (3x3) or all behind the one step (1x1)
-            if (more) {
-                if constexpr (TAPS == 9) {
-                    if constexpr (t >= 1) store_acts(c + 1, nbuf, ((t - 1) * NPIECE) / 8, (t * NPIECE) / 8);
-                } else {
-                    store_acts(c + 1, nbuf, 0, NPIECE);
-                }
-            }
-            // step + 1's weights have landed (only this step's own DMA may still fly), every LDS write is done
-            if (dma) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            });
+            // the staging loads count as "issued behind group gi + 1" while the group that was requested in their own step (group gi0 + LA)
+            // is later than gi + 1
+            wait_next(gc, ngroups - 1 - gi, more && g < LA - 1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         });
+    }
+
+    // ---- split-K: every k slice leaves its raw accumulators in HBM; the last one to arrive (ticket) adds all of them in slice order -- its
+    // own included, re-read, so that the sum does not depend on who is last -- and goes on to the epilogue.  Device-scope accesses, no fences
+    // (see stats_tail).
+    if (p.ksplit > 1) {
+        constexpr int NV = PT * CT * 8;                        // 8-byte pieces per thread (device-scope accesses are at most 64 bits wide)
+        typedef unsigned long long u64;
+        u64 *mine = reinterpret_cast<u64 *>(p.kpart) + ((size_t)wg * p.ksplit + ks) * (NV * 256) + tid;
+#pragma unroll
+        for (int n = 0; n < PT; ++n)
+#pragma unroll
+            for (int m = 0; m < CT; ++m)
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    // (through named floats: __builtin_bit_cast applied to a vector-element lvalue reads element 0 -- hipcc 7.2)
+                    const float a0 = acc[n][m][2 * v], a1 = acc[n][m][2 * v + 1];
+                    const u64 val = (u64)__builtin_bit_cast(unsigned, a0) | ((u64)__builtin_bit_cast(unsigned, a1) << 32);
+                    __hip_atomic_store(mine + ((n * CT + m) * 8 + v) * 256, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(p.kcounter + wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<volatile unsigned *>(smem + LDS_FLAG) = (t == (unsigned)p.ksplit - 1) ? 1u : 0u;
+            if (t == (unsigned)p.ksplit - 1) __hip_atomic_store(p.kcounter + wg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!*reinterpret_cast<volatile unsigned *>(smem + LDS_FLAG)) return;
+        const u64 *all = reinterpret_cast<const u64 *>(p.kpart) + (size_t)wg * p.ksplit * (NV * 256) + tid;
+#pragma unroll
+        for (int n = 0; n < PT; ++n)
+#pragma unroll
+            for (int m = 0; m < CT; ++m) {
+                u64 val[8][8];                                 // [k slice (at most 8)][piece]: every load of a tile is issued before the first add
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int v = 0; v < 8; ++v)
+                        val[k][v] = k < p.ksplit ? __hip_atomic_load(all + ((size_t)k * NV + (n * CT + m) * 8 + v) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    float lo = 0.0f, hi = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        lo += __builtin_bit_cast(float, (unsigned)val[k][v]);
+                        hi += __builtin_bit_cast(float, (unsigned)(val[k][v] >> 32));
+                    }
+                    acc[n][m][2 * v] = lo; acc[n][m][2 * v + 1] = hi;
+                }
+            }
+        __syncthreads();
     }
 
     // ---- epilogue: lane (j, h) owns channel co = 32 (slice CT + m) + j and, per pixel tile, the 16 pixels d_row0(r) + 4 h
@@ -406,15 +531,14 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
                     const f32x2 v = *reinterpret_cast<const f32x2 *>(red + ((kind * 4 + w) * 32 * CT + tid) * 2);
                     s += v[0]; q += v[1];
                 }
-                *reinterpret_cast<f32x2 *>(st.part + ((size_t)(slice * gps + tid) * ntiles + tile) * 2) = f32x2{s, q};
+                store_partial(st.part, (size_t)(slice * gps + tid) * ntiles + tile, s, q);
             }
         };
         publish(p.st_raw, 0);
         publish(p.st_y, 1);
-        stats_tail(p.st_raw, p.st_y, p.counter, ntiles, gridDim.x, tid, smem + LDS_FLAG);
+        stats_tail(p.st_raw, p.st_y, p.counter, ntiles, gridDim.x / p.ksplit, tid, smem + LDS_FLAG);
     }
 }
-
 
 // ---- conv1: 7x7, stride 2, pad 3, 6 -> 64 channels, bias (HGFilters.py:134) -------------------------------------------------
 // 2.5 of the encoder's 232 GFLOP: fp32 FMAs, no MFMA.  The input is the reference's NCHW image (6, Hin, Win); a workgroup
@@ -522,7 +646,7 @@ __global__ __launch_bounds__(256, 1) void conv1_kernel(const Conv1Args p)
     if (tid < p.st.groups) {
         float ss = 0.0f, qq = 0.0f;
         for (int c = 0; c < p.st.cpg; ++c) { ss += red2[2 * (tid * p.st.cpg + c)]; qq += red2[2 * (tid * p.st.cpg + c) + 1]; }
-        *reinterpret_cast<f32x2 *>(p.st.part + ((size_t)tid * ntiles + tile) * 2) = f32x2{ss, qq};
+        store_partial(p.st.part, (size_t)tid * ntiles + tile, ss, qq);
     }
     StatOut none{};
     stats_tail(p.st, none, p.counter, ntiles, gridDim.x, tid, smem + C1_LDS - 64);
@@ -567,7 +691,7 @@ __device__ __forceinline__ void elt_body(const EltArgs &p, F &&value)
         float ss = 0.0f, qq = 0.0f;
         for (int c = tid * p.st.cpg; c < (tid + 1) * p.st.cpg; ++c)
             for (int k = 0; k < nsub; ++k) { const float *r = red + ((k * c4n + (c >> 2)) * 8 + 2 * (c & 3)); ss += r[0]; qq += r[1]; }
-        *reinterpret_cast<f32x2 *>(p.st.part + ((size_t)tid * p.ntiles + blockIdx.x) * 2) = f32x2{ss, qq};
+        store_partial(p.st.part, (size_t)tid * p.ntiles + blockIdx.x, ss, qq);
     }
     StatOut none{};
     stats_tail(p.st, none, p.counter, p.ntiles, gridDim.x, tid, reinterpret_cast<char *>(flag));
@@ -677,7 +801,7 @@ struct DevBlock { DevConv conv[3], ds; bool has_ds = false; DevNorm bn[4]; int c
 
 struct Tensor { float *data = nullptr; int H = 0, W = 0, C = 0; float *stats = nullptr; };   // stats: (mean, rstd) x 32 groups
 
-enum LaunchKind { L_CONV1, L_CONV, L_POOL, L_UPADD, L_NORMRELU, L_FINAL };
+enum LaunchKind { L_CONV1, L_CONV, L_POOL, L_UPADD, L_NORMRELU, L_FINAL, L_FORK, L_JOIN };
 struct Launch {
     LaunchKind kind;
     ConvArgs conv; int CT = 0, PT = 0, TAPS = 0, TWC = 0; bool norm = false;
@@ -685,6 +809,8 @@ struct Launch {
     EltArgs elt;
     StatOut fa, fb; int fn = 0;      // L_FINAL
     unsigned grid = 0;
+    int side = 0;                    // 1: the launch goes to the side stream (the hourglass' upper branches run beside the lower ones)
+    int event = -1;                  // L_FORK: the side stream waits for the main stream here; L_JOIN: the main stream waits for the side stream
 };
 
 struct Encoder {
@@ -702,7 +828,9 @@ struct Encoder {
     float *in_buf = nullptr;
     Tensor out, normx;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-    hipStream_t cap_stream = nullptr;
+    hipStream_t cap_stream = nullptr, side_stream = nullptr;
+    std::vector<hipEvent_t> events;
+    int fork = -1, ksplit = -1;
 };
 
 static void free_plan(Encoder *e)
@@ -710,6 +838,8 @@ static void free_plan(Encoder *e)
     if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
     if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
     for (void *p : e->plan_allocs) hipFree(p);
+    for (hipEvent_t ev : e->events) hipEventDestroy(ev);
+    e->events.clear();
     e->plan_allocs.clear(); e->plan.clear(); e->Hin = e->Win = 0; e->in_buf = nullptr;
 }
 static void free_weights(Encoder *e)
@@ -726,6 +856,7 @@ void release_encoder(avc_ctx *ctx)
     free_plan(e);
     free_weights(e);
     if (e->cap_stream) hipStreamDestroy(e->cap_stream);
+    if (e->side_stream) hipStreamDestroy(e->side_stream);
     delete e;
     ctx->encoder = nullptr;
 }
@@ -880,6 +1011,18 @@ int pack_encoder(avc_ctx *ctx, const avc_hgfilter *net)
 struct Planner {
     avc_ctx *ctx; Encoder *e; std::vector<void *> allocs; bool lastwg; int rc = AVC_OK;
     float gn_eps = 1e-5f; int gn_groups = 32;
+    int side = 0; bool fork = false;
+
+    void push(Launch L) { L.side = side; e->plan.push_back(L); }
+    void sync(LaunchKind kind)
+    {
+        if (!fork || rc) return;
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("avc_hgfilter_forward: hipEventCreate failed"); rc = AVC_ERR_HIP; return; }
+        e->events.push_back(ev);
+        Launch L{}; L.kind = kind; L.event = (int)e->events.size() - 1;
+        e->plan.push_back(L);
+    }
 
     void *alloc(size_t bytes, bool zero = false)
     {
@@ -913,7 +1056,7 @@ struct Planner {
     {
         if (lastwg || (!a.part && !b.part)) return;
         Launch f{}; f.kind = L_FINAL; f.fa = a; f.fb = b; f.fn = ntiles; f.grid = 1;
-        e->plan.push_back(f);
+        push(f);
     }
 
     // conv: x (through gn + ReLU when gn != null) -> raw (with statistics when raw_stats) and / or y[:, ycoff ...] = conv + res
@@ -946,8 +1089,17 @@ struct Planner {
         if (raw && raw_stats) a.st_raw = stat(*raw, 0, w.cout, ntiles);
         if (y) a.st_y = stat(*y, ycoff, w.cout, ntiles);
         a.counter = (a.st_raw.part || a.st_y.part) ? counter() : nullptr;
-        L.grid = (unsigned)(ntiles * (w.cout / (32 * L.CT)));
-        e->plan.push_back(L);
+        // few workgroups, each streaming its whole K serially, are bound by the latency of their weight stream: split K over more of them
+        const int wg = ntiles * (w.cout / (32 * L.CT)), nchunk = x.C / 32;
+        a.ksplit = 1;
+        if (ctx->opt.enc_ksplit)
+            while (a.ksplit < nchunk && a.ksplit < 8 && 2 * wg * a.ksplit <= ctx->num_cus) a.ksplit *= 2;
+        if (a.ksplit > 1) {
+            a.kpart = static_cast<float *>(alloc(sizeof(float) * (size_t)wg * a.ksplit * 256 * L.PT * L.CT * 16));
+            a.kcounter = static_cast<unsigned *>(alloc(sizeof(unsigned) * wg, true));
+        }
+        L.grid = (unsigned)(wg * a.ksplit);
+        push(L);
         finish(a.st_raw, a.st_y, ntiles);
     }
 
@@ -977,7 +1129,7 @@ struct Planner {
         g.st = stat(out, 0, a.C, g.ntiles);
         g.counter = counter();
         L.grid = (unsigned)g.ntiles;
-        e->plan.push_back(L);
+        push(L);
         StatOut none{};
         finish(g.st, none, g.ntiles);
         return out;
@@ -986,11 +1138,17 @@ struct Planner {
     Tensor level(int lvl, const Tensor &x)
     {
         const int d = e->depth;
+        // the upper branch (b1) needs only x: it runs on the side stream beside the whole lower branch (pool, b2, the inner levels, b3), whose
+        // small launches leave most of the chip idle (HGFilters.py:98-118: up1 and low1..low3 meet at up1 + up2)
+        sync(L_FORK);
+        side = fork ? 1 : 0;
         Tensor up1 = block(e->hg[2 * (d - lvl)], x);
+        side = 0;
         Tensor low = elementwise(L_POOL, x, nullptr, x.H / 2, x.W / 2);
         low = block(e->hg[2 * (d - lvl) + 1], low);
         low = lvl > 1 ? level(lvl - 1, low) : block(e->hg[2 * d], low);
         low = block(e->hg[2 * d + lvl], low);
+        sync(L_JOIN);
         return elementwise(L_UPADD, up1, &low, x.H, x.W);
     }
 };
@@ -1000,10 +1158,12 @@ static int launch_conv_t(const ConvArgs &a, unsigned grid, hipStream_t s)
 {
     static bool attr = false;
     if (!attr) {
-        AVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<CT, PT, TAPS, TWC, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+        AVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<CT, PT, TAPS, TWC, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    ConvGeo<PT, TAPS, TWC>::L_TOTAL));
         attr = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<CT, PT, TAPS, TWC, NORM>), dim3(grid), dim3(256), LDS_TOTAL, s, a);
+    constexpr int lds = ConvGeo<PT, TAPS, TWC>::L_TOTAL;
+    hipLaunchKernelGGL((conv_mfma_kernel<CT, PT, TAPS, TWC, NORM>), dim3(grid), dim3(256), lds, s, a);
     return AVC_OK;
 }
 
@@ -1023,7 +1183,7 @@ static int launch_conv(const Launch &L, hipStream_t s)
     return AVC_ERR_STATE;
 }
 
-static int run_plan(Encoder *e, hipStream_t s)
+static int run_plan(Encoder *e, hipStream_t main_stream)
 {
     static bool attr1 = false;
     if (!attr1) {
@@ -1031,7 +1191,10 @@ static int run_plan(Encoder *e, hipStream_t s)
         attr1 = true;
     }
     for (const Launch &L : e->plan) {
+        hipStream_t s = L.side ? e->side_stream : main_stream;
         switch (L.kind) {
+        case L_FORK: AVC_HIP(hipEventRecord(e->events[L.event], main_stream)); AVC_HIP(hipStreamWaitEvent(e->side_stream, e->events[L.event], 0)); break;
+        case L_JOIN: AVC_HIP(hipEventRecord(e->events[L.event], e->side_stream)); AVC_HIP(hipStreamWaitEvent(main_stream, e->events[L.event], 0)); break;
         case L_CONV1: hipLaunchKernelGGL(conv1_kernel, dim3(L.grid), dim3(256), C1_LDS, s, L.c1); break;
         case L_CONV: if (int rc = launch_conv(L, s)) return rc; break;
         case L_POOL: hipLaunchKernelGGL(avgpool_kernel, dim3(L.grid), dim3(256), 0, s, L.elt); break;
@@ -1053,6 +1216,8 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
                 "(up1 + up2, HGFilters.py:118: the reference raises a size mismatch)", Hin, Win, H1, W1, e->depth, e->depth);
     Planner P{ctx, e, {}, ctx->opt.enc_lastwg != 0};
     P.gn_eps = e->bn1.eps; P.gn_groups = e->bn1.groups;
+    P.fork = ctx->opt.enc_fork != 0;
+    if (P.fork && !e->side_stream) AVC_HIP(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
     e->in_buf = static_cast<float *>(P.alloc(sizeof(float) * 6 * (size_t)Hin * Win));
     // conv1 + statistics of bn1
     Tensor t0 = P.tensor(H1, W1, C1_CO);
@@ -1064,7 +1229,7 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
         a.st = P.stat(t0, 0, C1_CO, a.tiles_x * a.tiles_y);
         a.counter = P.counter();
         L.grid = (unsigned)(a.tiles_x * a.tiles_y);
-        e->plan.push_back(L);
+        P.push(L);
         StatOut none{};
         P.finish(a.st, none, a.tiles_x * a.tiles_y);
     }
@@ -1081,7 +1246,7 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
     e->out = out;
     e->plan_allocs = P.allocs;
     if (P.rc) { free_plan(e); return P.rc; }
-    e->Hin = Hin; e->Win = Win; e->lastwg = ctx->opt.enc_lastwg;
+    e->Hin = Hin; e->Win = Win; e->lastwg = ctx->opt.enc_lastwg; e->fork = ctx->opt.enc_fork; e->ksplit = ctx->opt.enc_ksplit;
     // record the launches once as a hipGraph (replayed with one hipGraphLaunch per frame)
     if (ctx->opt.enc_graph) {
         if (!e->cap_stream) AVC_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
@@ -1105,7 +1270,7 @@ int encoder_forward(avc_ctx *ctx, const float *image, int H, int W, float *feat_
     Encoder *e = static_cast<Encoder *>(ctx->encoder);
     AVC_REQUIRE(e && e->packed, AVC_ERR_STATE, "avc_hgfilter_forward: no encoder weights (call avc_hgfilter_pack first)");
     AVC_REQUIRE(image && H >= 2 && W >= 2 && (int64_t)H * W <= (1 << 22), AVC_ERR_ARG, "avc_hgfilter_forward: NULL image or unsupported size %d x %d", H, W);
-    if (e->Hin != H || e->Win != W || e->lastwg != ctx->opt.enc_lastwg || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
+    if (e->Hin != H || e->Win != W || e->lastwg != ctx->opt.enc_lastwg || e->fork != ctx->opt.enc_fork || e->ksplit != ctx->opt.enc_ksplit || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
         // (re)building frees buffers a replay in flight may still use
         AVC_HIP(hipDeviceSynchronize());
         if (int rc = build_plan(ctx, e, H, W)) return rc;
@@ -1140,9 +1305,9 @@ int encoder_debug_tensor(avc_ctx *ctx, int launch, int which, float *out, int *C
     const float *src = nullptr; int c = 0, h = 0, w = 0;
     if (L.kind == L_CONV1) { src = L.c1.out; c = C1_CO; h = L.c1.H; w = L.c1.W; }
     else if (L.kind == L_CONV) { src = which ? L.conv.y : L.conv.raw; c = which ? L.conv.yC : L.conv.Cout; h = L.conv.H; w = L.conv.W; }
-    else if (L.kind != L_FINAL) { src = L.elt.out; c = L.elt.C; h = L.elt.H; w = L.elt.W; }
+    else if (L.kind == L_POOL || L.kind == L_UPADD || L.kind == L_NORMRELU) { src = L.elt.out; c = L.elt.C; h = L.elt.H; w = L.elt.W; }
     *C = c; *H = h; *W = w;
-    if (L.kind == L_CONV) *C = c | (L.CT << 16) | (L.PT << 20) | (L.TAPS << 24);
+    if (L.kind == L_CONV) *C = c | (L.CT << 16) | (L.PT << 20) | (L.TAPS << 24) | ((L.conv.ksplit > 1 ? 1 : 0) << 30);
     if (out && src) hipLaunchKernelGGL(hwc_to_nchw_kernel, dim3((h * w + 63) / 64, (c + 63) / 64), dim3(256), 0, s, src, out, c, h * w);
     AVC_HIP(hipGetLastError());
     return src ? AVC_OK : 1;

@@ -77,7 +77,7 @@ def _walk_plan(hg, x, tol=1e-4):
         _lib.check(L.avc_hgfilter_debug_tensor(ctx, launch, 1 if which == 'y' else 0, got.data_ptr(), C.byref(c), C.byref(h), C.byref(w), _lib.stream_ptr(x.device)))
         torch.cuda.synchronize()
         e = float((got - ref[0]).abs().max()) / max(1.0, float(ref.abs().max()))
-        report.append((launch, name, tuple(ref.shape[1:]), f'CT{cfg & 15} PT{(cfg >> 4) & 15} taps{cfg >> 8}' if cfg else '', e))
+        report.append((launch, name, tuple(ref.shape[1:]), f'CT{cfg & 15} PT{(cfg >> 4) & 15} taps{(cfg >> 8) & 31}{" splitK" if cfg >> 14 else ""}' if cfg else '', e))
         worst = max(worst, e)
         launch += 1
     for r in report:
@@ -117,24 +117,46 @@ def test_hgfilter_matches_reference(golden):
 
 
 def test_hgfilter_switches_change_nothing():
-    """hipGraph replay vs plain launches, last-workgroup statistics vs a statistics launch of their own: the same bits; new weights are picked up."""
+    """hipGraph replay vs plain launches, last-workgroup statistics vs a statistics launch of their own, the hourglass' upper branches on a second
+    stream or not: the same bits; new weights are picked up."""
     from avatarcap_amd import _lib
     hg = _hg()
     a = _t(gi.normal_maps(512, seed=78)[None])
     with torch.no_grad():
         base = hg(a)[0][-1].clone()
         try:
-            for g, l in ((0, 1), (1, 0), (0, 0)):
+            for g, l, f in ((0, 1, 1), (1, 0, 1), (0, 0, 0), (1, 1, 0)):      # (split-K changes the rounding: see the next test)
                 _lib.set_option('enc_graph', g)
                 _lib.set_option('enc_lastwg', l)
-                assert torch.equal(hg(a)[0][-1], base), (g, l)
+                _lib.set_option('enc_fork', f)
+                assert torch.equal(hg(a)[0][-1], base), (g, l, f)
         finally:
             _lib.set_option('enc_graph', 1)
             _lib.set_option('enc_lastwg', 1)
+            _lib.set_option('enc_fork', 1)
         b = _t(gi.normal_maps(512, seed=79)[None])
         assert not torch.equal(hg(b)[0][-1], base) and torch.equal(hg(a)[0][-1], base)     # a second input through the same graph
         syn.load_synth(hg, gi.SEED_NET + 3)
         assert not torch.equal(hg(a)[0][-1], base)                                          # new weights: packed again
+
+
+def test_hgfilter_without_split_k():
+    """avc_set_option "enc_ksplit" 0: every convolution walks its whole K in one workgroup per tile (the small hourglass levels then run on a handful of
+    CUs).  Both forms are held to the launch-by-launch reference; they differ from each other by fp32 rounding only."""
+    from avatarcap_amd import _lib
+    hg = _hg()
+    x = _t(gi.normal_maps(512)[None])
+    with torch.no_grad():
+        a = hg(x)[0][-1].clone()
+        _lib.set_option('enc_ksplit', 0)
+        try:
+            worst = _walk_plan(hg, x)
+            b = hg(x)[0][-1].clone()
+        finally:
+            _lib.set_option('enc_ksplit', 1)
+    d = float((a - b).abs().max()) / max(1.0, float(a.abs().max()))
+    print(f'without split-K: worst launch {worst:.3e}; feature map with vs without split-K {d:.3e}')
+    assert d < 2e-5
 
 
 def test_recon_infer_end_to_end_at_512(golden):
