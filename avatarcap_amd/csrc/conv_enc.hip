@@ -121,26 +121,30 @@ __device__ __forceinline__ void store_partial(float *part, size_t index, float s
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(part) + index, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void finalize_stats(const StatOut &st, int ntiles, int tid)
+// Both kinds of a launch (its raw output's groups, its slice of the block output's groups) are folded in ONE pass: wave w takes the groups
+// w, w + 4, ... of the concatenated list, every load of the pass is in flight before the first add (a device-scope load is a ~1-2 us round trip;
+// three dependent passes of them were 6 of the 9 us this tail cost a small convolution).
+__device__ __forceinline__ void finalize_stats(const StatOut &a, const StatOut &b, int ntiles, int tid)
 {
-    if (!st.part) return;
     const int lane = tid & 63, wave = tid >> 6;
-    constexpr int U = 4;                                   // groups in flight per wave: every load of a pass is issued before the first add
-    for (int g0 = wave * U; g0 < st.groups; g0 += 4 * U) {
+    const int na = a.part ? a.groups : 0, nb = b.part ? b.groups : 0, total = na + nb;
+    constexpr int U = 16;                                  // groups per wave and pass: 64 groups cover every launch of the encoder
+    for (int base = 0; base < total; base += 4 * U) {
         double s[U], q[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) s[u] = q[u] = 0.0;
         for (int t0 = 0; t0 < ntiles; t0 += 256) {
             unsigned long long v[U][4];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u) {
+                const int g = base + wave + 4 * u;
+                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(g < na ? a.part : b.part) + (size_t)(g < na ? g : g - na) * ntiles;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int t = t0 + 64 * k + lane, g = g0 + u;
-                    v[u][k] = (t < ntiles && g < st.groups)
-                                  ? __hip_atomic_load(reinterpret_cast<const unsigned long long *>(st.part) + (size_t)g * ntiles + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                  : 0ull;
+                    const int t = t0 + 64 * k + lane;
+                    v[u][k] = (g < total && t < ntiles) ? __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                 }
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -151,12 +155,16 @@ __device__ __forceinline__ void finalize_stats(const StatOut &st, int ntiles, in
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            const int g = base + wave + 4 * u;
+            if (g >= total) continue;                      // wave-uniform
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { s[u] += __shfl_xor(s[u], o); q[u] += __shfl_xor(q[u], o); }
-            if (lane == 0 && g0 + u < st.groups) {
+            if (lane == 0) {
+                const StatOut &st = g < na ? a : b;
+                const int gl = g < na ? g : g - na;
                 const double mean = s[u] * (double)st.inv_n, var = fmax(q[u] * (double)st.inv_n - mean * mean, 0.0);
-                st.stats[2 * (g0 + u)] = (float)mean;
-                st.stats[2 * (g0 + u) + 1] = (float)(1.0 / sqrt(var + (double)st.eps));
+                st.stats[2 * gl] = (float)mean;
+                st.stats[2 * gl + 1] = (float)(1.0 / sqrt(var + (double)st.eps));
             }
         }
     }
@@ -177,16 +185,14 @@ __device__ __forceinline__ void stats_tail(const StatOut &a, const StatOut &b, u
     }
     __syncthreads();
     if (*reinterpret_cast<volatile unsigned *>(smem_flag)) {
-        finalize_stats(a, ntiles, tid);
-        finalize_stats(b, ntiles, tid);
+        finalize_stats(a, b, ntiles, tid);
         if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 __global__ __launch_bounds__(256) void stats_finalize_kernel(StatOut a, StatOut b, int ntiles)
 {
-    finalize_stats(a, ntiles, threadIdx.x);
-    finalize_stats(b, ntiles, threadIdx.x);
+    finalize_stats(a, b, ntiles, threadIdx.x);
 }
 
 // ---- the convolution ---------------------------------------------------------------------------------------------------
@@ -198,9 +204,11 @@ template <int PT, int TAPS, int TWC>
 struct ConvGeo {
     static constexpr int PTR = 32 / TWC;                          // image rows of one pixel tile
     static constexpr int ROWS = 4 * PT * PTR;                     // image rows of the workgroup's tile
-    static constexpr int PAD = TAPS == 9 ? 1 : 0;
-    static constexpr int RP = TAPS == 9 ? (TWC == 32 ? 34 : 32) : TWC;      // LDS row pitch in pixels (32 for the 16-wide 3x3 tile: bank note in DESIGN.md)
-    static constexpr int HR = ROWS + 2 * PAD, HC = TWC + 2 * PAD;
+    // halo: 3x3 pad 1; 4x4 (the space-to-depth form of conv1's 7x7 stride 2 pad 3) 2 before and 1 after; 1x1 none
+    static constexpr int PAD = TAPS == 9 ? 1 : (TAPS == 16 ? 2 : 0), PADH = TAPS == 9 ? 1 : (TAPS == 16 ? 1 : 0);
+    static constexpr int KW = TAPS == 9 ? 3 : (TAPS == 16 ? 4 : 1);
+    static constexpr int HR = ROWS + PAD + PADH, HC = TWC + PAD + PADH;
+    static constexpr int RP = TAPS == 1 ? TWC : (TWC == 32 ? HC : 32);       // LDS row pitch in pixels (32 for the 16-wide tiles: bank note in DESIGN.md)
     static constexpr int NPIX = HR * RP;
     static constexpr int ACTB = (NPIX * PIXB + 1023) & ~1023;
     static constexpr int RS_FIT = (163840 - 2048 - 64 - 2 * ACTB) / RING_SLOT;
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Geo = ConvGeo<PT, TAPS, TWC>;
-    constexpr int PTR = Geo::PTR, ROWS = Geo::ROWS, PAD = Geo::PAD, RP = Geo::RP, HC = Geo::HC, NPIX = Geo::NPIX;
+    constexpr int PTR = Geo::PTR, ROWS = Geo::ROWS, PAD = Geo::PAD, RP = Geo::RP, HC = Geo::HC, NPIX = Geo::NPIX, KW = Geo::KW;
     constexpr int LDS_ACT0 = Geo::L_ACT0, LDS_ACT1 = Geo::L_ACT1, LDS_RING = Geo::L_RING, LDS_AB = Geo::L_AB, LDS_FLAG = Geo::L_FLAG;
     constexpr int RS = Geo::RS, LA = RS - 1;                // ring slots, groups of weights in flight
     constexpr int NPIECE = (NPIX * 8 + 255) / 256;         // 16-byte pieces (4 channels of one pixel) per thread and chunk
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
             const int iy = y0 - PAD + hr, ix = x0 - PAD + hc;
             const bool ok = (i * 32 + (tid >> 3)) < NPIX && hc < HC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             goff[i] = ok ? ((iy * p.W + ix) * p.Cin + sub * 4) * 4 : (int)0x80000000;
-            hc += 32;                                      // next piece: 32 staged pixels on (RP is 32 or 34: at most one row wrap)
+            hc += 32;                                      // next piece: 32 staged pixels on (RP is 32, 34 or 35: at most one row wrap)
             if (hc >= RP) { hc -= RP; ++hr; }
             if (RP < 32 && hc >= RP) { hc -= RP; ++hr; }  // RP == 16 (1x1 on the narrow tile)
         }
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
             const unsigned wb = LDS_RING + (unsigned)(gi % RS) * RING_SLOT + lane16;
             static_for<NT>([&](auto tc) {
                 constexpr int tl = decltype(tc)::value, t = g * G + tl;
-                constexpr int toff = TAPS == 9 ? ((t / 3) * RP + (t % 3)) * PIXB : 0;
+                constexpr int toff = ((t / KW) * RP + (t % KW)) * PIXB;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     half8 bh[CT], bl[CT], ah[PT], al[PT];
@@ -541,115 +549,27 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
 }
 
 // ---- conv1: 7x7, stride 2, pad 3, 6 -> 64 channels, bias (HGFilters.py:134) -------------------------------------------------
-// 2.5 of the encoder's 232 GFLOP: fp32 FMAs, no MFMA.  The input is the reference's NCHW image (6, Hin, Win); a workgroup
-// computes a 16 x 16 tile of output pixels x 64 channels out of LDS (37 x 37 x 6 input tile, all 18,816 weights as [tap][ci][co]);
-// a thread owns 4 horizontally adjacent pixels x 16 channels.  Output channel-last (H1, W1, 64) + GroupNorm partials of bn1.
-constexpr int C1_CO = 64, C1_CI = 6, C1_K = 7, C1_T = 16, C1_IN = 2 * C1_T + C1_K - 2;     // 37
-constexpr int C1_LDS_W = C1_K * C1_K * C1_CI * C1_CO * 4;                                   // 75,264 B
-constexpr int C1_LDS_IN = C1_CI * C1_IN * (C1_IN + 1) * 4;                                  // 33,744 B (row pitch 38)
-constexpr int C1_LDS = C1_LDS_W + C1_LDS_IN + 64;
+// A stride-2 convolution is a stride-1 convolution of the space-to-depth image: (6, Hin, Win) -> (H1, W1, 24 = 2 x 2 x 6) with the 7x7 kernel
+// zero-extended to 8x8 = 4x4 taps over the 24 channels (input row 2 o - 3 + k, k = 0..6, is row o - 2 + ty of parity py with k = 2 ty + py - 1).
+// The 24 channels are padded to the 32 of one K chunk; conv_mfma_kernel<.., TAPS = 16, .., NORM = false> does the rest (1.3x the MACs of the
+// direct form, on the matrix pipe: the fp32-FMA kernel of the first cut was 60 - 70 us, 2.5 % of the encoder's FLOPs in 3 % of its time).
+struct S2dArgs { const float *img; int Hin, Win, H, W; float *out; };      // out (H, W, 32) channel-last
 
-struct Conv1Args {
-    const float *img;            // (6, Hin, Win)
-    int Hin, Win, H, W;          // output H x W
-    const float *w;              // [49][6][64] (repacked by pack)
-    const float *bias;           // (64)
-    float *out;                  // (H, W, 64)
-    StatOut st;
-    unsigned *counter;
-    int tiles_x, tiles_y;
-};
-
-__global__ __launch_bounds__(256, 1) void conv1_kernel(const Conv1Args p)
+__global__ __launch_bounds__(256) void s2d_kernel(const S2dArgs p)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *wl = reinterpret_cast<float *>(smem);
-    float *il = reinterpret_cast<float *>(smem + C1_LDS_W);
-    const int tid = threadIdx.x;
-    const int tile = blockIdx.x, ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    const int oy0 = ty * C1_T, ox0 = tx * C1_T;
-    for (int i = tid; i < C1_K * C1_K * C1_CI * C1_CO / 4; i += 256)
-        reinterpret_cast<f32x4 *>(wl)[i] = reinterpret_cast<const f32x4 *>(p.w)[i];
-    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
-    for (int i = tid; i < C1_CI * C1_IN * C1_IN; i += 256) {
-        const int ci = i / (C1_IN * C1_IN), r = i - ci * (C1_IN * C1_IN), yy = r / C1_IN, xx = r - yy * C1_IN;
-        const int iy = iy0 + yy, ix = ix0 + xx;
-        float v = 0.0f;
-        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) v = p.img[((size_t)ci * p.Hin + iy) * p.Win + ix];
-        il[(ci * C1_IN + yy) * (C1_IN + 1) + xx] = v;
-    }
-    __syncthreads();
-    const int cg = tid & 3, pg = tid >> 2;            // 16 channels cg*16.., pixel group: row pg / 4, columns 4 (pg % 4) ..
-    const int py = pg >> 2, px = (pg & 3) * 4;
-    float acc[4][16];
+    const int i = blockIdx.x * 256 + threadIdx.x, quad = i & 7, pix = i >> 3;
+    if (pix >= p.H * p.W) return;
+    const int oy = pix / p.W, ox = pix - oy * p.W;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[k][c] = 0.0f;
-    for (int ci = 0; ci < C1_CI; ++ci)
-        for (int dy = 0; dy < C1_K; ++dy) {
-            const float *row = il + (ci * C1_IN + 2 * py + dy) * (C1_IN + 1) + 2 * px;
-            float in[13];
-#pragma unroll
-            for (int k = 0; k < 13; ++k) in[k] = row[k];
-#pragma unroll
-            for (int dx = 0; dx < C1_K; ++dx) {
-                const float *wp = wl + ((dy * C1_K + dx) * C1_CI + ci) * C1_CO + cg * 16;
-                float w[16];
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    const f32x4 v = reinterpret_cast<const f32x4 *>(wp)[c4];
-                    w[4 * c4] = v[0]; w[4 * c4 + 1] = v[1]; w[4 * c4 + 2] = v[2]; w[4 * c4 + 3] = v[3];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) acc[k][c] = __builtin_fmaf(in[2 * k + dx], w[c], acc[k][c]);
-            }
-        }
-    // bias, store, per-channel sums over this thread's valid pixels
-    float s[16], q[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) s[c] = q[c] = 0.0f;
-    const int oy = oy0 + py;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int ox = ox0 + px + k;
-        if (oy < p.H && ox < p.W) {
-            float *dst = p.out + ((size_t)oy * p.W + ox) * C1_CO + cg * 16;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = acc[k][4 * c4 + e] + p.bias[cg * 16 + 4 * c4 + e];
-                    v[e] = t; s[4 * c4 + e] += t; q[4 * c4 + e] += t * t;
-                }
-                reinterpret_cast<f32x4 *>(dst)[c4] = v;
-            }
+    for (int e = 0; e < 4; ++e) {
+        const int ch = quad * 4 + e;                      // (py * 2 + px) * 6 + c
+        if (ch < 24) {
+            const int par = ch / 6, c = ch - par * 6, iy = 2 * oy + (par >> 1), ix = 2 * ox + (par & 1);
+            if (iy < p.Hin && ix < p.Win) v[e] = p.img[((size_t)c * p.Hin + iy) * p.Win + ix];
         }
     }
-    if (!p.st.part) return;
-    __syncthreads();                                   // the input tile is dead: reuse it as [pixel group][64 channels](s, q)
-    float *red = il;                                   // 64 x 64 x 2 floats = 32 KiB
-#pragma unroll
-    for (int c = 0; c < 16; ++c) *reinterpret_cast<f32x2 *>(red + ((pg * 64) + cg * 16 + c) * 2) = f32x2{s[c], q[c]};
-    __syncthreads();
-    float *red2 = wl;                                  // per-channel totals (weights are dead too)
-    if (tid < 64) {
-        float ss = 0.0f, qq = 0.0f;
-        for (int g = 0; g < 64; ++g) { const f32x2 v = *reinterpret_cast<const f32x2 *>(red + (g * 64 + tid) * 2); ss += v[0]; qq += v[1]; }
-        red2[2 * tid] = ss; red2[2 * tid + 1] = qq;
-    }
-    __syncthreads();
-    const int ntiles = p.tiles_x * p.tiles_y;
-    if (tid < p.st.groups) {
-        float ss = 0.0f, qq = 0.0f;
-        for (int c = 0; c < p.st.cpg; ++c) { ss += red2[2 * (tid * p.st.cpg + c)]; qq += red2[2 * (tid * p.st.cpg + c) + 1]; }
-        store_partial(p.st.part, (size_t)tid * ntiles + tile, ss, qq);
-    }
-    StatOut none{};
-    stats_tail(p.st, none, p.counter, ntiles, gridDim.x, tid, smem + C1_LDS - 64);
+    *reinterpret_cast<f32x4 *>(p.out + (size_t)pix * 32 + quad * 4) = v;
 }
 
 // ---- avg_pool2d(2, stride 2) + statistics of the pooled tensor (HGFilters.py:103) ------------------------------------------------
@@ -750,6 +670,83 @@ __global__ __launch_bounds__(256) void upadd_kernel(const EltArgs p)
     });
 }
 
+// The same, tiled: an 8 x 16 tile of output pixels x 64 channels per workgroup.  The 8 x 12 source pixels the tile's taps can touch are staged
+// once in LDS (clamped: the border replication is baked into the staged tile) and every output takes its 16 taps from there -- 16 LDS reads
+// instead of 16 global loads per output float4; 24 KiB of LDS and one barrier, so six workgroups share a CU and hide each other's latencies
+// (a two-pass separable form through a second LDS buffer was slower: three dependent phases per workgroup, two workgroups per CU).
+// Same operation order per output as the direct kernel.
+constexpr int UT_H = 8, UT_W = 16, UT_C = 64, UT_SR = 8, UT_SC = 12;
+struct UpTiledArgs { EltArgs e; int tiles_x, tiles_y; };
+
+__global__ __launch_bounds__(256) void upadd_tiled_kernel(const UpTiledArgs a)
+{
+    const EltArgs &p = a.e;
+    __shared__ __attribute__((aligned(16))) float src[UT_SR * UT_SC * UT_C];     // 24 KiB
+    __shared__ unsigned flag[16];
+    const int tid = threadIdx.x;
+    const int nt = a.tiles_x * a.tiles_y, tile = blockIdx.x % nt, chunk = blockIdx.x / nt;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int oy0 = ty * UT_H, ox0 = tx * UT_W, c0 = chunk * UT_C;
+    const float sy = p.H > 1 ? (float)(p.Hb - 1) / (float)(p.H - 1) : 0.0f, sx = p.W > 1 ? (float)(p.Wb - 1) / (float)(p.W - 1) : 0.0f;
+    const int ylo = min((int)floorf(sy * (float)oy0), p.Hb - 1) - 1, xlo = min((int)floorf(sx * (float)ox0), p.Wb - 1) - 1;
+    const int quad = tid & 15;
+    // up1 of this thread's 8 outputs: in flight while the source tile is staged
+    f32x4 up[UT_H * UT_W / 16];
+#pragma unroll
+    for (int i = 0; i < UT_H * UT_W / 16; ++i) {
+        const int pp = (tid >> 4) + 16 * i, oy = oy0 + (pp >> 4), ox = ox0 + (pp & 15);
+        up[i] = (oy < p.H && ox < p.W) ? *reinterpret_cast<const f32x4 *>(p.a + ((size_t)oy * p.W + ox) * p.C + c0 + quad * 4) : f32x4{0, 0, 0, 0};
+    }
+    for (int i = tid; i < UT_SR * UT_SC * (UT_C / 4); i += 256) {
+        const int qd = i & 15, cell = i >> 4, r = cell / UT_SC, c = cell - r * UT_SC;
+        const int yy = min(max(ylo + r, 0), p.Hb - 1), xx = min(max(xlo + c, 0), p.Wb - 1);
+        *reinterpret_cast<f32x4 *>(src + cell * UT_C + qd * 4) = *reinterpret_cast<const f32x4 *>(p.b + ((size_t)yy * p.Wb + xx) * p.C + c0 + qd * 4);
+    }
+    __syncthreads();
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < UT_H * UT_W / 16; ++i) {
+        const int pp = (tid >> 4) + 16 * i, y = pp >> 4, x = pp & 15;
+        const int oy = oy0 + y, ox = ox0 + x;
+        if (oy >= p.H || ox >= p.W) continue;
+        const float ry = sy * (float)oy, rx = sx * (float)ox;
+        const int iy = min((int)floorf(ry), p.Hb - 1), ix = min((int)floorf(rx), p.Wb - 1);
+        float cy[4], cx[4];
+        cubic_coeffs(fminf(fmaxf(ry - (float)iy, 0.0f), 1.0f), cy);
+        cubic_coeffs(fminf(fmaxf(rx - (float)ix, 0.0f), 1.0f), cx);
+        const int rb = min(max(iy - 1 - ylo, 0), UT_SR - 4), cb = min(max(ix - 1 - xlo, 0), UT_SC - 4);
+        const float *base = src + (rb * UT_SC + cb) * UT_C + quad * 4;
+        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float *row = base + m * UT_SC * UT_C;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(row), v1 = *reinterpret_cast<const f32x4 *>(row + UT_C);
+            const f32x4 v2 = *reinterpret_cast<const f32x4 *>(row + 2 * UT_C), v3 = *reinterpret_cast<const f32x4 *>(row + 3 * UT_C);
+            const f32x4 r = v0 * cx[0] + v1 * cx[1] + v2 * cx[2] + v3 * cx[3];
+            acc = m == 0 ? r * cy[0] : acc + r * cy[m];
+        }
+        const f32x4 v = up[i] + acc;
+        *reinterpret_cast<f32x4 *>(p.out + ((size_t)oy * p.W + ox) * p.C + c0 + quad * 4) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+    }
+    if (!p.st.part) return;
+    __syncthreads();
+    float *red = src;                                              // [16 pixel lanes][64 channels](s, q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x2 *>(red + (((tid >> 4) * UT_C) + quad * 4 + e) * 2) = f32x2{s[e], q[e]};
+    __syncthreads();
+    const int gpc = UT_C / p.st.cpg;                               // groups of this workgroup's 64 channels
+    if (tid < gpc) {
+        float ss = 0.0f, qq = 0.0f;
+        for (int c = tid * p.st.cpg; c < (tid + 1) * p.st.cpg; ++c)
+            for (int k = 0; k < 16; ++k) { const f32x2 v = *reinterpret_cast<const f32x2 *>(red + (k * UT_C + c) * 2); ss += v[0]; qq += v[1]; }
+        store_partial(p.st.part, (size_t)(chunk * gpc + tid) * nt + tile, ss, qq);
+    }
+    StatOut none{};
+    stats_tail(p.st, none, p.counter, nt, gridDim.x, tid, reinterpret_cast<char *>(flag));
+}
+
 // relu(GroupNorm(a)) materialised (HGFilters.py:178: the block that follows normalises THIS tensor again and needs its statistics)
 __global__ __launch_bounds__(256) void normrelu_kernel(const EltArgs p)
 {
@@ -791,7 +788,6 @@ __global__ void hwc_to_nchw_kernel(const float *__restrict__ src, float *__restr
 struct DevConv {            // a packed convolution
     char *wstream = nullptr; unsigned wbytes = 0;
     float *bias = nullptr;  // device (cout) or null
-    float *w_direct = nullptr;   // conv1 only: [49][6][64] fp32
     float wscale_inv = 1.0f;     // 2^-sw
     int cout = 0, cin = 0, taps = 0;
     unsigned off[3] = {0, 0, 0}; // byte offset of the stream packed for CT = 1, 2, 4
@@ -801,12 +797,12 @@ struct DevBlock { DevConv conv[3], ds; bool has_ds = false; DevNorm bn[4]; int c
 
 struct Tensor { float *data = nullptr; int H = 0, W = 0, C = 0; float *stats = nullptr; };   // stats: (mean, rstd) x 32 groups
 
-enum LaunchKind { L_CONV1, L_CONV, L_POOL, L_UPADD, L_NORMRELU, L_FINAL, L_FORK, L_JOIN };
+enum LaunchKind { L_S2D, L_CONV, L_POOL, L_UPADD, L_UPADD_TILED, L_NORMRELU, L_FINAL, L_FORK, L_JOIN };
 struct Launch {
     LaunchKind kind;
     ConvArgs conv; int CT = 0, PT = 0, TAPS = 0, TWC = 0; bool norm = false;
-    Conv1Args c1;
-    EltArgs elt;
+    S2dArgs s2d;
+    EltArgs elt; int ut_x = 0, ut_y = 0;     // (L_UPADD_TILED: the tile grid)
     StatOut fa, fb; int fn = 0;      // L_FINAL
     unsigned grid = 0;
     int side = 0;                    // 1: the launch goes to the side stream (the hourglass' upper branches run beside the lower ones)
@@ -975,17 +971,23 @@ int pack_encoder(avc_ctx *ctx, const avc_hgfilter *net)
     free_plan(e);
     free_weights(e);
     AVC_REQUIRE(net->depth >= 1 && net->depth <= 6 && net->hourglass, AVC_ERR_ARG, "avc_hgfilter_pack: depth %d", net->depth);
-    // conv1: 7x7 stride 2, 6 -> 64, bias; repacked [tap][ci][co] for the direct kernel
+    // conv1: 7x7 stride 2 pad 3, 6 -> 64, bias -> 4x4 taps over the 24 (padded to 32) space-to-depth channels
     const avc_conv2d &c1 = net->conv1;
-    AVC_REQUIRE(c1.w && c1.b && c1.cout == C1_CO && c1.cin == C1_CI && c1.kh == C1_K && c1.kw == C1_K, AVC_ERR_ARG,
+    AVC_REQUIRE(c1.w && c1.b && c1.cout == 64 && c1.cin == 6 && c1.kh == 7 && c1.kw == 7, AVC_ERR_ARG,
                 "avc_hgfilter_pack: conv1 must be Conv2d(6, 64, 7, stride 2, padding 3) with a bias (HGFilters.py:134)");
     {
-        std::vector<float> w((size_t)C1_K * C1_K * C1_CI * C1_CO), b(c1.b, c1.b + C1_CO);
-        for (int co = 0; co < C1_CO; ++co)
-            for (int ci = 0; ci < C1_CI; ++ci)
-                for (int t = 0; t < C1_K * C1_K; ++t) w[((size_t)t * C1_CI + ci) * C1_CO + co] = c1.w[((size_t)co * C1_CI + ci) * C1_K * C1_K + t];
-        if (int rc = upload_vec(e, w, &e->conv1.w_direct)) return rc;
-        if (int rc = upload_vec(e, b, &e->conv1.bias)) return rc;
+        std::vector<float> w((size_t)64 * 32 * 16, 0.0f);
+        for (int co = 0; co < 64; ++co)
+            for (int par = 0; par < 4; ++par)
+                for (int c = 0; c < 6; ++c)
+                    for (int ty = 0; ty < 4; ++ty)
+                        for (int tx = 0; tx < 4; ++tx) {
+                            const int ky = 2 * ty + (par >> 1) - 1, kx = 2 * tx + (par & 1) - 1;
+                            if (ky < 0 || ky > 6 || kx < 0 || kx > 6) continue;
+                            w[((size_t)co * 32 + par * 6 + c) * 16 + ty * 4 + tx] = c1.w[((size_t)co * 6 + c) * 49 + ky * 7 + kx];
+                        }
+        const avc_conv2d s2d{w.data(), c1.b, 64, 32, 4, 4};
+        if (int rc = pack_conv(e, s2d, 16, e->conv1, "conv1")) return rc;
     }
     if (int rc = pack_norm(e, net->bn1, 64, e->bn1, "bn1")) return rc;
     if (int rc = pack_block(e, net->conv2, 64, 128, e->conv2, "conv2")) return rc;
@@ -1060,24 +1062,24 @@ struct Planner {
     }
 
     // conv: x (through gn + ReLU when gn != null) -> raw (with statistics when raw_stats) and / or y[:, ycoff ...] = conv + res
-    void conv(const DevConv &w, const Tensor &x, const DevNorm *gn, Tensor *raw, bool raw_stats, Tensor *y, const Tensor *res, int ycoff)
+    void conv(const DevConv &w, const Tensor &x, const DevNorm *gn, Tensor *raw, bool raw_stats, Tensor *y, const Tensor *res, int ycoff, float raw_in_scale = 1.0f)
     {
         if (rc) return;
         Launch L{}; L.kind = L_CONV;
         L.TAPS = w.taps; L.norm = gn != nullptr;
         L.TWC = x.W >= 32 ? 32 : 16;
-        L.CT = conv_ct(w.cout); L.PT = L.TWC == 32 ? 2 : 1;
+        L.CT = conv_ct(w.cout); L.PT = (L.TWC == 32 && w.taps != 16) ? 2 : 1;
         auto wgs = [&](int CT, int PT) { const int rows = 4 * PT * (32 / L.TWC); return ((x.H + rows - 1) / rows) * ((x.W + L.TWC - 1) / L.TWC) * (w.cout / (32 * CT)); };
         while (wgs(L.CT, L.PT) < ctx->num_cus) {
             if (L.PT == 2) L.PT = 1;
-            else if (L.CT > 1) L.CT /= 2;
+            else if (L.CT > 1 && w.taps != 16) L.CT /= 2;
             else break;
         }
         const int rows = 4 * L.PT * (32 / L.TWC);
         ConvArgs &a = L.conv;
         a.x = x.data; a.H = x.H; a.W = x.W; a.Cin = x.C;
         a.in_stats = x.stats; a.gamma = gn ? gn->gamma : nullptr; a.beta = gn ? gn->beta : nullptr; a.in_cpg = gn ? x.C / gn->groups : 1;
-        a.in_scale = gn ? 16.0f : 1.0f;
+        a.in_scale = gn ? 16.0f : raw_in_scale;
         const int v = L.CT == 4 ? 2 : (L.CT == 2 ? 1 : 0);
         a.slice_bytes = (unsigned)(x.C / 32) * w.taps * 2 * L.CT * 2048;
         a.wstream = w.wstream + w.off[v]; a.wbytes = a.slice_bytes * (w.cout / (32 * L.CT));
@@ -1124,11 +1126,21 @@ struct Planner {
         g.Hb = b ? b->H : a.H; g.Wb = b ? b->W : a.W;
         if (gn) { g.in_stats = a.stats; g.gamma = gn->gamma; g.beta = gn->beta; g.in_cpg = a.C / gn->groups; }
         const int npix = H * W;
-        g.ppw = std::max(16, (npix + 511) / 512);
-        g.ntiles = (npix + g.ppw - 1) / g.ppw;
-        g.st = stat(out, 0, a.C, g.ntiles);
-        g.counter = counter();
-        L.grid = (unsigned)g.ntiles;
+        if (kind == L_UPADD && a.C % UT_C == 0 && H >= 2 * UT_H && W >= UT_W) {       // the tiled form (every level of the 512^2 path but the lowest)
+            L.kind = L_UPADD_TILED;
+            L.ut_x = (W + UT_W - 1) / UT_W; L.ut_y = (H + UT_H - 1) / UT_H;
+            g.ntiles = L.ut_x * L.ut_y;
+            g.ppw = UT_H * UT_W;
+            g.st = stat(out, 0, a.C, g.ntiles);
+            g.counter = counter();
+            L.grid = (unsigned)(g.ntiles * (a.C / UT_C));
+        } else {
+            g.ppw = std::max(16, (npix + 511) / 512);
+            g.ntiles = (npix + g.ppw - 1) / g.ppw;
+            g.st = stat(out, 0, a.C, g.ntiles);
+            g.counter = counter();
+            L.grid = (unsigned)g.ntiles;
+        }
         push(L);
         StatOut none{};
         finish(g.st, none, g.ntiles);
@@ -1140,11 +1152,12 @@ struct Planner {
         const int d = e->depth;
         // the upper branch (b1) needs only x: it runs on the side stream beside the whole lower branch (pool, b2, the inner levels, b3), whose
         // small launches leave most of the chip idle (HGFilters.py:98-118: up1 and low1..low3 meet at up1 + up2)
+        // (the pool goes first: a small launch that shares the chip with a one-workgroup-per-CU convolution waits for that launch's end)
+        Tensor low = elementwise(L_POOL, x, nullptr, x.H / 2, x.W / 2);
         sync(L_FORK);
         side = fork ? 1 : 0;
         Tensor up1 = block(e->hg[2 * (d - lvl)], x);
         side = 0;
-        Tensor low = elementwise(L_POOL, x, nullptr, x.H / 2, x.W / 2);
         low = block(e->hg[2 * (d - lvl) + 1], low);
         low = lvl > 1 ? level(lvl - 1, low) : block(e->hg[2 * d], low);
         low = block(e->hg[2 * d + lvl], low);
@@ -1176,6 +1189,8 @@ static int launch_conv(const Launch &L, hipStream_t s)
     AVC_ENC_GEO(9, true)
     AVC_ENC_GEO(1, true)
     AVC_ENC_GEO(1, false)
+    AVC_ENC_CASE(2, 1, 16, 32, false)
+    AVC_ENC_CASE(2, 1, 16, 16, false)
 #undef AVC_ENC_GEO
 #undef AVC_ENC_CT
 #undef AVC_ENC_CASE
@@ -1185,20 +1200,16 @@ static int launch_conv(const Launch &L, hipStream_t s)
 
 static int run_plan(Encoder *e, hipStream_t main_stream)
 {
-    static bool attr1 = false;
-    if (!attr1) {
-        AVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS));
-        attr1 = true;
-    }
     for (const Launch &L : e->plan) {
         hipStream_t s = L.side ? e->side_stream : main_stream;
         switch (L.kind) {
         case L_FORK: AVC_HIP(hipEventRecord(e->events[L.event], main_stream)); AVC_HIP(hipStreamWaitEvent(e->side_stream, e->events[L.event], 0)); break;
         case L_JOIN: AVC_HIP(hipEventRecord(e->events[L.event], e->side_stream)); AVC_HIP(hipStreamWaitEvent(main_stream, e->events[L.event], 0)); break;
-        case L_CONV1: hipLaunchKernelGGL(conv1_kernel, dim3(L.grid), dim3(256), C1_LDS, s, L.c1); break;
+        case L_S2D: hipLaunchKernelGGL(s2d_kernel, dim3(L.grid), dim3(256), 0, s, L.s2d); break;
         case L_CONV: if (int rc = launch_conv(L, s)) return rc; break;
         case L_POOL: hipLaunchKernelGGL(avgpool_kernel, dim3(L.grid), dim3(256), 0, s, L.elt); break;
         case L_UPADD: hipLaunchKernelGGL(upadd_kernel, dim3(L.grid), dim3(256), 0, s, L.elt); break;
+        case L_UPADD_TILED: { UpTiledArgs u{L.elt, L.ut_x, L.ut_y}; hipLaunchKernelGGL(upadd_tiled_kernel, dim3(L.grid), dim3(256), 0, s, u); break; }
         case L_NORMRELU: hipLaunchKernelGGL(normrelu_kernel, dim3(L.grid), dim3(256), 0, s, L.elt); break;
         case L_FINAL: hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(256), 0, s, L.fa, L.fb, L.fn); break;
         }
@@ -1219,20 +1230,15 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
     P.fork = ctx->opt.enc_fork != 0;
     if (P.fork && !e->side_stream) AVC_HIP(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
     e->in_buf = static_cast<float *>(P.alloc(sizeof(float) * 6 * (size_t)Hin * Win));
-    // conv1 + statistics of bn1
-    Tensor t0 = P.tensor(H1, W1, C1_CO);
+    // conv1 (space-to-depth, then 4x4 taps on the matrix pipe) + statistics of bn1
+    Tensor sd = P.tensor(H1, W1, 32), t0 = P.tensor(H1, W1, 64);
     if (!P.rc) {
-        Launch L{}; L.kind = L_CONV1;
-        Conv1Args &a = L.c1;
-        a.img = e->in_buf; a.Hin = Hin; a.Win = Win; a.H = H1; a.W = W1; a.w = e->conv1.w_direct; a.bias = e->conv1.bias; a.out = t0.data;
-        a.tiles_x = (W1 + C1_T - 1) / C1_T; a.tiles_y = (H1 + C1_T - 1) / C1_T;
-        a.st = P.stat(t0, 0, C1_CO, a.tiles_x * a.tiles_y);
-        a.counter = P.counter();
-        L.grid = (unsigned)(a.tiles_x * a.tiles_y);
+        Launch L{}; L.kind = L_S2D;
+        L.s2d = S2dArgs{e->in_buf, Hin, Win, H1, W1, sd.data};
+        L.grid = (unsigned)((H1 * W1 * 8 + 255) / 256);
         P.push(L);
-        StatOut none{};
-        P.finish(a.st, none, a.tiles_x * a.tiles_y);
     }
+    P.conv(e->conv1, sd, nullptr, &t0, true, nullptr, nullptr, 0, 16.0f);         // the image is a normal map in [-1, 1]
     Tensor x = P.elementwise(L_NORMRELU, t0, nullptr, H1, W1, &e->bn1);          // relu(bn1(conv1 x))        HGFilters.py:178
     x = P.block(e->conv2, x);                                                    // 'no_down'                  :184-185
     e->normx = x;
@@ -1303,9 +1309,8 @@ int encoder_debug_tensor(avc_ctx *ctx, int launch, int which, float *out, int *C
     AVC_REQUIRE(e && launch >= 0 && launch < (int)e->plan.size(), AVC_ERR_ARG, "avc_hgfilter_debug_tensor: launch %d of %d", launch, e ? (int)e->plan.size() : 0);
     const Launch &L = e->plan[launch];
     const float *src = nullptr; int c = 0, h = 0, w = 0;
-    if (L.kind == L_CONV1) { src = L.c1.out; c = C1_CO; h = L.c1.H; w = L.c1.W; }
-    else if (L.kind == L_CONV) { src = which ? L.conv.y : L.conv.raw; c = which ? L.conv.yC : L.conv.Cout; h = L.conv.H; w = L.conv.W; }
-    else if (L.kind == L_POOL || L.kind == L_UPADD || L.kind == L_NORMRELU) { src = L.elt.out; c = L.elt.C; h = L.elt.H; w = L.elt.W; }
+    if (L.kind == L_CONV) { src = which ? L.conv.y : L.conv.raw; c = which ? L.conv.yC : L.conv.Cout; h = L.conv.H; w = L.conv.W; }
+    else if (L.kind == L_POOL || L.kind == L_UPADD || L.kind == L_UPADD_TILED || L.kind == L_NORMRELU) { src = L.elt.out; c = L.elt.C; h = L.elt.H; w = L.elt.W; }
     *C = c; *H = h; *W = w;
     if (L.kind == L_CONV) *C = c | (L.CT << 16) | (L.PT << 20) | (L.TAPS << 24) | ((L.conv.ksplit > 1 ? 1 : 0) << 30);
     if (out && src) hipLaunchKernelGGL(hwc_to_nchw_kernel, dim3((h * w + 63) / 64, (c + 63) / 64), dim3(256), 0, s, src, out, c, h * w);

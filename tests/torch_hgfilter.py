@@ -25,9 +25,9 @@ def _block(b, x, trace, name):
 
 
 def _level(hg, lvl, x, trace):
-    up1 = _block(hg._modules[f'b1_{lvl}'], x, trace, f'b1_{lvl}')
     low = F.avg_pool2d(x, 2, stride=2)
     trace.append((f'pool_{lvl}', 'raw', low))
+    up1 = _block(hg._modules[f'b1_{lvl}'], x, trace, f'b1_{lvl}')
     low = _block(hg._modules[f'b2_{lvl}'], low, trace, f'b2_{lvl}')
     low = _level(hg, lvl - 1, low, trace) if lvl > 1 else _block(hg._modules['b2_plus_1'], low, trace, 'b2_plus_1')
     low = _block(hg._modules[f'b3_{lvl}'], low, trace, f'b3_{lvl}')

@@ -1,15 +1,16 @@
 """Kernel timeline of the last encoder frame in a rocprofv3 rocpd database (gpurun_out/prof_enc/enc_results.db): start, duration, gap to the
-previous kernel's end on the same stream, grid, name.  `python tools/prof_timeline.py <db> [first-kernel-substring]`"""
+previous kernel's end on the same queue, grid, name.  `python tools/prof_timeline.py <db> [frame index, default the last]`"""
 import sqlite3
 import sys
 
 db = sys.argv[1]
-first = sys.argv[2] if len(sys.argv) > 2 else 'conv1_kernel'
+first = 's2d_kernel'
+which = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end, grid_x, workgroup_x, stream_id, queue_id from kernels order by start").fetchall()
 idx = [i for i, r in enumerate(rows) if first in r[0]]
-i0 = idx[-1]
-seq = rows[i0:]
+i0 = idx[which]
+seq = rows[i0:(idx[which + 1] if which != -1 and which + 1 < len(idx) else len(rows))]
 t0 = seq[0][1]
 last_end = {}
 tot = {}
