@@ -72,7 +72,9 @@ struct StatOut {
 struct ConvArgs {
     const float *x;              // input (H, W, Cin) channel-last
     int H, W, Cin;
-    const float *in_stats;       // (mean, rstd) per group of x  (NORM launches)
+    const float *in_stats;       // (mean, rstd) per group of x  (NORM launches), or
+    const float *in_part;        // ... the producers' per-tile partials [group][in_tiles](sum, sum of squares), folded here (in_tiles in 1..32)
+    int in_tiles; float in_inv_n, in_eps;
     const float *gamma, *beta;   // the consumer's GroupNorm affine
     int in_cpg;
     float in_scale;              // power of two folded into (a, b): keeps small activations' lo halves normal
@@ -127,7 +129,7 @@ __device__ __forceinline__ void store_partial(float *part, size_t index, float s
 __device__ __forceinline__ void finalize_stats(const StatOut &a, const StatOut &b, int ntiles, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    const int na = a.part ? a.groups : 0, nb = b.part ? b.groups : 0, total = na + nb;
+    const int na = (a.part && a.stats) ? a.groups : 0, nb = (b.part && b.stats) ? b.groups : 0, total = na + nb;
     constexpr int U = 16;                                  // groups per wave and pass: 64 groups cover every launch of the encoder
     for (int base = 0; base < total; base += 4 * U) {
         double s[U], q[U];
@@ -242,7 +244,26 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         float a = p.in_scale, b = 0.0f;
         if constexpr (NORM) {
             const int g = tid / p.in_cpg;
-            const float mean = p.in_stats[2 * g], rstd = p.in_stats[2 * g + 1];
+            float mean, rstd;
+            if (p.in_tiles > 0) {
+                // The producers of a small tensor (<= 32 tiles) leave their partials unfolded: every consumer folds them itself, in the order of
+                // finalize_stats (a butterfly over the tiles, in double), and the producers are spared the ticket and the fold -- two device-scope
+                // round trips at the end of launches that are nothing but latency.
+                double sv[32], qv[32];
+#pragma unroll
+                for (int t = 0; t < 32; ++t) {
+                    const f32x2 v = t < p.in_tiles ? *reinterpret_cast<const f32x2 *>(p.in_part + ((size_t)g * p.in_tiles + t) * 2) : f32x2{0.0f, 0.0f};
+                    sv[t] = (double)v[0]; qv[t] = (double)v[1];
+                }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+                    for (int l = 0; l < o; ++l) { sv[l] += sv[l + o]; qv[l] += qv[l + o]; }
+                const double m = sv[0] * (double)p.in_inv_n, var = fmax(qv[0] * (double)p.in_inv_n - m * m, 0.0);
+                mean = (float)m; rstd = (float)(1.0 / sqrt(var + (double)p.in_eps));
+            } else {
+                mean = p.in_stats[2 * g]; rstd = p.in_stats[2 * g + 1];
+            }
             a = p.gamma[tid] * rstd;
             b = (p.beta[tid] - mean * a) * p.in_scale;
             a *= p.in_scale;
@@ -795,7 +816,8 @@ struct DevConv {            // a packed convolution
 struct DevNorm { float *gamma = nullptr, *beta = nullptr; int C = 0, groups = 32; float eps = 1e-5f; };
 struct DevBlock { DevConv conv[3], ds; bool has_ds = false; DevNorm bn[4]; int cin = 0, cout = 0; };
 
-struct Tensor { float *data = nullptr; int H = 0, W = 0, C = 0; float *stats = nullptr; };   // stats: (mean, rstd) x 32 groups
+struct Tensor { float *data = nullptr; int H = 0, W = 0, C = 0; float *stats = nullptr;       // stats: (mean, rstd) x 32 groups, or (small tensors)
+                float *part = nullptr; int part_tiles = 0; bool stats_used = false; };                                  // the producers' partials [group][part_tiles], folded by the consumers
 
 enum LaunchKind { L_S2D, L_CONV, L_POOL, L_UPADD, L_UPADD_TILED, L_NORMRELU, L_FINAL, L_FORK, L_JOIN };
 struct Launch {
@@ -826,7 +848,7 @@ struct Encoder {
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr, side_stream = nullptr;
     std::vector<hipEvent_t> events;
-    int fork = -1, ksplit = -1;
+    int fork = -1, ksplit = -1, defer = -1;
 };
 
 static void free_plan(Encoder *e)
@@ -1013,7 +1035,7 @@ int pack_encoder(avc_ctx *ctx, const avc_hgfilter *net)
 struct Planner {
     avc_ctx *ctx; Encoder *e; std::vector<void *> allocs; bool lastwg; int rc = AVC_OK;
     float gn_eps = 1e-5f; int gn_groups = 32;
-    int side = 0; bool fork = false;
+    int side = 0; bool fork = false, defer = true;
 
     void push(Launch L) { L.side = side; e->plan.push_back(L); }
     void sync(LaunchKind kind)
@@ -1042,13 +1064,22 @@ struct Planner {
         t.stats = static_cast<float *>(alloc(sizeof(float) * 2 * 256, true));
         return t;
     }
-    StatOut stat(const Tensor &t, int first_channel, int channels, int ntiles)
+    StatOut stat(Tensor &t, int first_channel, int channels, int ntiles)
     {
         StatOut s{};
         s.cpg = t.C / gn_groups;
         s.groups = channels / s.cpg;
-        s.part = static_cast<float *>(alloc(sizeof(float) * 2 * (size_t)s.groups * ntiles));
-        s.stats = t.stats + 2 * (first_channel / s.cpg);
+        if (defer && ntiles <= 32 && (t.part_tiles == 0 || t.part_tiles == ntiles) && !(t.part_tiles == 0 && t.stats_used)) {
+            // a small tensor: its producers (one, or the three convolutions of a block, same tile grid) write into ONE table the consumers fold
+            if (!t.part) { t.part = static_cast<float *>(alloc(sizeof(float) * 2 * (size_t)gn_groups * ntiles, true)); t.part_tiles = ntiles; }
+            s.part = t.part + 2 * (size_t)(first_channel / s.cpg) * ntiles;
+            s.stats = nullptr;                         // no fold on the producer's side
+        } else {
+            if (t.part_tiles) { set_error("avc_hgfilter_forward: internal: mixed statistics modes on one tensor"); rc = AVC_ERR_STATE; }
+            t.stats_used = true;
+            s.part = static_cast<float *>(alloc(sizeof(float) * 2 * (size_t)s.groups * ntiles));
+            s.stats = t.stats + 2 * (first_channel / s.cpg);
+        }
         s.inv_n = 1.0f / ((float)s.cpg * (float)t.H * (float)t.W);
         s.eps = gn_eps;
         return s;
@@ -1056,7 +1087,7 @@ struct Planner {
     unsigned *counter() { return lastwg ? static_cast<unsigned *>(alloc(sizeof(unsigned), true)) : nullptr; }
     void finish(const StatOut &a, const StatOut &b, int ntiles)
     {
-        if (lastwg || (!a.part && !b.part)) return;
+        if (lastwg || (!a.stats && !b.stats)) return;
         Launch f{}; f.kind = L_FINAL; f.fa = a; f.fb = b; f.fn = ntiles; f.grid = 1;
         push(f);
     }
@@ -1078,7 +1109,9 @@ struct Planner {
         const int rows = 4 * L.PT * (32 / L.TWC);
         ConvArgs &a = L.conv;
         a.x = x.data; a.H = x.H; a.W = x.W; a.Cin = x.C;
-        a.in_stats = x.stats; a.gamma = gn ? gn->gamma : nullptr; a.beta = gn ? gn->beta : nullptr; a.in_cpg = gn ? x.C / gn->groups : 1;
+        a.in_stats = x.stats; a.in_part = x.part; a.in_tiles = gn ? x.part_tiles : 0; a.in_eps = gn_eps;
+        a.in_inv_n = gn ? 1.0f / ((float)(x.C / gn->groups) * (float)x.H * (float)x.W) : 0.0f;
+        a.gamma = gn ? gn->gamma : nullptr; a.beta = gn ? gn->beta : nullptr; a.in_cpg = gn ? x.C / gn->groups : 1;
         a.in_scale = gn ? 16.0f : raw_in_scale;
         const int v = L.CT == 4 ? 2 : (L.CT == 2 ? 1 : 0);
         a.slice_bytes = (unsigned)(x.C / 32) * w.taps * 2 * L.CT * 2048;
@@ -1090,7 +1123,7 @@ struct Planner {
         const int ntiles = a.tiles_x * a.tiles_y;
         if (raw && raw_stats) a.st_raw = stat(*raw, 0, w.cout, ntiles);
         if (y) a.st_y = stat(*y, ycoff, w.cout, ntiles);
-        a.counter = (a.st_raw.part || a.st_y.part) ? counter() : nullptr;
+        a.counter = (a.st_raw.stats || a.st_y.stats) ? counter() : nullptr;
         // few workgroups, each streaming its whole K serially, are bound by the latency of their weight stream: split K over more of them
         const int wg = ntiles * (w.cout / (32 * L.CT)), nchunk = x.C / 32;
         a.ksplit = 1;
@@ -1124,6 +1157,7 @@ struct Planner {
         EltArgs &g = L.elt;
         g.a = a.data; g.b = b ? b->data : nullptr; g.out = out.data; g.H = H; g.W = W; g.C = a.C;
         g.Hb = b ? b->H : a.H; g.Wb = b ? b->W : a.W;
+        if (gn && a.part_tiles) { set_error("avc_hgfilter_forward: internal: the norm + ReLU launch takes folded statistics"); rc = AVC_ERR_STATE; }
         if (gn) { g.in_stats = a.stats; g.gamma = gn->gamma; g.beta = gn->beta; g.in_cpg = a.C / gn->groups; }
         const int npix = H * W;
         if (kind == L_UPADD && a.C % UT_C == 0 && H >= 2 * UT_H && W >= UT_W) {       // the tiled form (every level of the 512^2 path but the lowest)
@@ -1132,13 +1166,13 @@ struct Planner {
             g.ntiles = L.ut_x * L.ut_y;
             g.ppw = UT_H * UT_W;
             g.st = stat(out, 0, a.C, g.ntiles);
-            g.counter = counter();
+            g.counter = g.st.stats ? counter() : nullptr;
             L.grid = (unsigned)(g.ntiles * (a.C / UT_C));
         } else {
-            g.ppw = std::max(16, (npix + 511) / 512);
+            g.ppw = npix <= 1024 ? std::max(16, (npix + 31) / 32) : std::max(16, (npix + 511) / 512);      // small tensors: <= 32 tiles (their consumers fold them)
             g.ntiles = (npix + g.ppw - 1) / g.ppw;
             g.st = stat(out, 0, a.C, g.ntiles);
-            g.counter = counter();
+            g.counter = g.st.stats ? counter() : nullptr;
             L.grid = (unsigned)g.ntiles;
         }
         push(L);
@@ -1228,10 +1262,12 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
     Planner P{ctx, e, {}, ctx->opt.enc_lastwg != 0};
     P.gn_eps = e->bn1.eps; P.gn_groups = e->bn1.groups;
     P.fork = ctx->opt.enc_fork != 0;
+    P.defer = ctx->opt.enc_defer != 0;
     if (P.fork && !e->side_stream) AVC_HIP(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
     e->in_buf = static_cast<float *>(P.alloc(sizeof(float) * 6 * (size_t)Hin * Win));
     // conv1 (space-to-depth, then 4x4 taps on the matrix pipe) + statistics of bn1
     Tensor sd = P.tensor(H1, W1, 32), t0 = P.tensor(H1, W1, 64);
+    t0.stats_used = true;                                  // its consumer is the norm + ReLU launch, which takes folded statistics
     if (!P.rc) {
         Launch L{}; L.kind = L_S2D;
         L.s2d = S2dArgs{e->in_buf, Hin, Win, H1, W1, sd.data};
@@ -1252,7 +1288,7 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
     e->out = out;
     e->plan_allocs = P.allocs;
     if (P.rc) { free_plan(e); return P.rc; }
-    e->Hin = Hin; e->Win = Win; e->lastwg = ctx->opt.enc_lastwg; e->fork = ctx->opt.enc_fork; e->ksplit = ctx->opt.enc_ksplit;
+    e->Hin = Hin; e->Win = Win; e->lastwg = ctx->opt.enc_lastwg; e->fork = ctx->opt.enc_fork; e->ksplit = ctx->opt.enc_ksplit; e->defer = ctx->opt.enc_defer;
     // record the launches once as a hipGraph (replayed with one hipGraphLaunch per frame)
     if (ctx->opt.enc_graph) {
         if (!e->cap_stream) AVC_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
@@ -1276,7 +1312,7 @@ int encoder_forward(avc_ctx *ctx, const float *image, int H, int W, float *feat_
     Encoder *e = static_cast<Encoder *>(ctx->encoder);
     AVC_REQUIRE(e && e->packed, AVC_ERR_STATE, "avc_hgfilter_forward: no encoder weights (call avc_hgfilter_pack first)");
     AVC_REQUIRE(image && H >= 2 && W >= 2 && (int64_t)H * W <= (1 << 22), AVC_ERR_ARG, "avc_hgfilter_forward: NULL image or unsupported size %d x %d", H, W);
-    if (e->Hin != H || e->Win != W || e->lastwg != ctx->opt.enc_lastwg || e->fork != ctx->opt.enc_fork || e->ksplit != ctx->opt.enc_ksplit || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
+    if (e->Hin != H || e->Win != W || e->lastwg != ctx->opt.enc_lastwg || e->fork != ctx->opt.enc_fork || e->ksplit != ctx->opt.enc_ksplit || e->defer != ctx->opt.enc_defer || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
         // (re)building frees buffers a replay in flight may still use
         AVC_HIP(hipDeviceSynchronize());
         if (int rc = build_plan(ctx, e, H, W)) return rc;

@@ -304,6 +304,8 @@ int avc_timing_read_cycles(avc_ctx *ctx, int which, double *avg_cycles_out, int6
  *                  same summation order, same bits
  *   "enc_ksplit"   1 (default: a convolution that would run on fewer than half the CUs splits its input channels over several workgroups per
  *                  tile, whose partial sums the last to arrive adds in a fixed order) | 0 -- deterministic either way; the two differ by fp32 rounding
+ *   "enc_defer"    1 (default: the GroupNorm partials of a tensor of <= 32 tiles are folded by its consumers, sparing the producers the ticket and
+ *                  the fold) | 0 always by the producers -- same summation order, same bits
  *   "enc_fork"     1 (default: the hourglass' upper branches run on a second stream -- parallel branches of the hipGraph -- beside the lower ones) |
  *                  0 one stream -- same kernels, same bits */
 int avc_set_option(avc_ctx *ctx, const char *name, int value);
