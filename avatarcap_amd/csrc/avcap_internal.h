@@ -57,9 +57,7 @@ struct Options {
     int knn_search = 0;       // 0 automatic, 1 per-lane grid search, 2 cooperative grid search, 3 exhaustive scan (AVC_KNN_PATH=lane|wave, AVC_KNN_BRUTE=1)
     int fusion_graph = 1;     // normal-fusion iterations replayed as a hipGraph (AVC_FUSION_NO_GRAPH=1 -> 0)
     int enc_graph = 1;        // the image encoder's launches replayed as a hipGraph
-    int enc_lastwg = 1;       // GroupNorm statistics folded by the last workgroup of the producing launch (0: by a launch of their own)
     int enc_ksplit = 1;       // convolutions with few workgroups split K over several (partial sums in HBM, added in a fixed order by the last to arrive)
-    int enc_defer = 1;        // tensors of <= 32 tiles: the consumers fold the GroupNorm partials (0: the producers' last workgroup / finalise launch does)
     int enc_fork = 1;         // the hourglass' upper branches (b1_k) run on a second stream beside the lower ones
 };
 

@@ -59,22 +59,24 @@ constexpr int PIXB = 144;                       // bytes per staged pixel: 32 ch
 constexpr int RING_SLOT = 16384;                // one slot of the weight ring: a group of 4 / CT taps
 constexpr int MAX_CIN = 256;
 
-// Group statistics a launch contributes to (torch.nn.GroupNorm: mean and biased variance over (C/G, H, W)).
+// GroupNorm statistics (torch.nn.GroupNorm: mean and biased variance over (C / G, H, W)) travel from the launch that produces a tensor to the
+// launches that consume it as a table of at most 32 partial (sum, sum of squares) pairs per group, in double: [group][bucket].  A bucket is
+// one tile of the producing launch, or -- launches of more than 32 tiles -- `bsize` consecutive tiles: every workgroup leaves its fp32 tile
+// partial in a level-1 table, takes a ticket on its bucket's counter, and the bucket's last arrival adds the bucket's tiles in tile order.
+// No launch-wide ticket (512 same-address atomics were 15 - 25 us at the end of every launch), no launch-wide fold by one workgroup, no
+// floating-point atomics: bitwise deterministic.  The CONSUMER folds the <= 32 buckets of a group (fold_group) when it builds its affine map.
 struct StatOut {
-    float *part;         // [groups][ntiles] (sum, sum of squares) per workgroup tile; null = no statistics of this kind
-    float *stats;        // [groups] (mean, rstd), the launch's first group first
+    float *part;         // level 1 [rows][ntiles] (sum, sum of squares) per tile, fp32; unused when bsize == 1
+    double *part2;       // level 2 [rows][nb] per bucket; the launch's first row first.  null = the launch leaves no statistics of this kind
     int cpg;             // channels per group
-    int groups;          // groups this launch covers (all of its Cout)
-    float inv_n;         // 1 / (cpg * H * W)
-    float eps;
+    int nb, bsize;       // buckets (<= 32), tiles per bucket
 };
 
 struct ConvArgs {
     const float *x;              // input (H, W, Cin) channel-last
     int H, W, Cin;
-    const float *in_stats;       // (mean, rstd) per group of x  (NORM launches), or
-    const float *in_part;        // ... the producers' per-tile partials [group][in_tiles](sum, sum of squares), folded here (in_tiles in 1..32)
-    int in_tiles; float in_inv_n, in_eps;
+    const double *in_part2;      // the producers' [group][in_nb] partials of x (NORM launches)
+    int in_nb; float in_inv_n, in_eps;           // 1 / (cpg H W), the GroupNorm's eps
     const float *gamma, *beta;   // the consumer's GroupNorm affine
     int in_cpg;
     float in_scale;              // power of two folded into (a, b): keeps small activations' lo halves normal
@@ -88,7 +90,7 @@ struct ConvArgs {
     const float *res;            // (H, W, yC)
     int yC, ycoff;
     StatOut st_raw, st_y;
-    unsigned *counter;           // ticket of the last-workgroup reduction (self-resetting); null = a finalise launch follows
+    unsigned *counter;           // [bucket][slice] tickets (self-resetting); used when bsize > 1
     int tiles_x, tiles_y;
     int ksplit;                  // workgroups per (tile, slice): each walks Cin / 32 / ksplit chunks of K (1: no split)
     float *kpart;                // split-K: [tile x slice][ksplit][accumulator registers][256 threads] raw sums
@@ -115,86 +117,74 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigne
 // D-tile register r (0..15) of lane-half h -> row of the 32x32 tile (CDNA4 C/D map; mlp_layout.h d_row)
 __device__ __forceinline__ constexpr int d_row0(int r) { return (r & 3) + 8 * (r >> 2); }      // + 4 h
 
-// ---- statistics: fold the per-tile partials of `groups` groups into (mean, rstd); one workgroup, fixed order, double ------------
-// Partials are written and read with device-scope (sc1) accesses: they cross XCDs, whose L2s are not coherent with each other.
+// ---- statistics ------------------------------------------------------------------------------------------------------------------
+// Level-1 partials are written and read with device-scope (sc1) accesses: they cross XCDs, whose L2s are not coherent with each other.
 __device__ __forceinline__ void store_partial(float *part, size_t index, float s, float q)
 {
     const unsigned long long v = (unsigned long long)__builtin_bit_cast(unsigned, s) | ((unsigned long long)__builtin_bit_cast(unsigned, q) << 32);
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(part) + index, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Both kinds of a launch (its raw output's groups, its slice of the block output's groups) are folded in ONE pass: wave w takes the groups
-// w, w + 4, ... of the concatenated list, every load of the pass is in flight before the first add (a device-scope load is a ~1-2 us round trip;
-// three dependent passes of them were 6 of the 9 us this tail cost a small convolution).
-__device__ __forceinline__ void finalize_stats(const StatOut &a, const StatOut &b, int ntiles, int tid)
+// The consumer's side: (mean, rstd) of one group from its <= 32 bucket partials -- a butterfly in double (a fixed tree, whatever nb is)
+__device__ __forceinline__ f32x2 fold_group(const double *row, int nb, float inv_n, float eps)
 {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int na = (a.part && a.stats) ? a.groups : 0, nb = (b.part && b.stats) ? b.groups : 0, total = na + nb;
-    constexpr int U = 16;                                  // groups per wave and pass: 64 groups cover every launch of the encoder
-    for (int base = 0; base < total; base += 4 * U) {
-        double s[U], q[U];
+    double sv[32], qv[32];
 #pragma unroll
-        for (int u = 0; u < U; ++u) s[u] = q[u] = 0.0;
-        for (int t0 = 0; t0 < ntiles; t0 += 256) {
-            unsigned long long v[U][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int g = base + wave + 4 * u;
-                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(g < na ? a.part : b.part) + (size_t)(g < na ? g : g - na) * ntiles;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int t = t0 + 64 * k + lane;
-                    v[u][k] = (g < total && t < ntiles) ? __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    s[u] += (double)__builtin_bit_cast(float, (unsigned)v[u][k]);
-                    q[u] += (double)__builtin_bit_cast(float, (unsigned)(v[u][k] >> 32));
-                }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int g = base + wave + 4 * u;
-            if (g >= total) continue;                      // wave-uniform
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { s[u] += __shfl_xor(s[u], o); q[u] += __shfl_xor(q[u], o); }
-            if (lane == 0) {
-                const StatOut &st = g < na ? a : b;
-                const int gl = g < na ? g : g - na;
-                const double mean = s[u] * (double)st.inv_n, var = fmax(q[u] * (double)st.inv_n - mean * mean, 0.0);
-                st.stats[2 * gl] = (float)mean;
-                st.stats[2 * gl + 1] = (float)(1.0 / sqrt(var + (double)st.eps));
-            }
-        }
+    for (int t = 0; t < 32; ++t) {
+        sv[t] = t < nb ? row[2 * t] : 0.0;
+        qv[t] = t < nb ? row[2 * t + 1] : 0.0;
     }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+        for (int l = 0; l < o; ++l) { sv[l] += sv[l + o]; qv[l] += qv[l + o]; }
+    const double m = sv[0] * (double)inv_n, var = fmax(qv[0] * (double)inv_n - m * m, 0.0);
+    return f32x2{(float)m, (float)(1.0 / sqrt(var + (double)eps))};
 }
 
-// The tail every statistics-producing kernel shares: this workgroup's partials are out (sc1 stores, acknowledged: vmcnt(0)), take a ticket, the
-// last workgroup folds.  No __threadfence(): at device scope it is an L2 write-back + invalidate per workgroup, with 4 MB of freshly written
-// activations dirty in every XCD's L2 -- measured +18 us per convolution, 1 ms per frame.  The partials are the only data that crosses
-// workgroups inside a launch, and every access to them is a device-scope one.
-__device__ __forceinline__ void stats_tail(const StatOut &a, const StatOut &b, unsigned *counter, int ntiles, unsigned total_wgs, int tid, char *smem_flag)
+// The producer's side.  Thread tid < nrows holds (s, q) of row row0 + tid of the launch's table for this workgroup's tile (two kinds at most:
+// a convolution's raw output and its slice of the block output share the tile grid, hence the ticket).  `counter` is this workgroup's
+// bucket's ticket (one per bucket and row block).
+struct StatRows { int row0, nrows; float s, q; };
+__device__ __forceinline__ void stats_commit(const StatOut &a, const StatRows &ra, const StatOut &b, const StatRows &rb, unsigned *counter, int tile, int ntiles,
+                                             int tid, char *smem_flag)
 {
-    if (!counter) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const StatOut &any = a.part2 ? a : b;
+    if (!any.part2) return;
+    if (any.bsize == 1) {                                  // the tile is the bucket
+        if (a.part2 && tid < ra.nrows) { double *d = a.part2 + ((size_t)(ra.row0 + tid) * a.nb + tile) * 2; d[0] = (double)ra.s; d[1] = (double)ra.q; }
+        if (b.part2 && tid < rb.nrows) { double *d = b.part2 + ((size_t)(rb.row0 + tid) * b.nb + tile) * 2; d[0] = (double)rb.s; d[1] = (double)rb.q; }
+        return;
+    }
+    if (a.part2 && tid < ra.nrows) store_partial(a.part, (size_t)(ra.row0 + tid) * ntiles + tile, ra.s, ra.q);
+    if (b.part2 && tid < rb.nrows) store_partial(b.part, (size_t)(rb.row0 + tid) * ntiles + tile, rb.s, rb.q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the sc1 stores are acknowledged
     __syncthreads();
+    const int bucket = tile / any.bsize, t0 = bucket * any.bsize, nin = min(any.bsize, ntiles - t0);
     if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *reinterpret_cast<volatile unsigned *>(smem_flag) = (t == total_wgs - 1) ? 1u : 0u;
+        const bool last = t == (unsigned)nin - 1;
+        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<volatile unsigned *>(smem_flag) = last ? 1u : 0u;
     }
     __syncthreads();
-    if (*reinterpret_cast<volatile unsigned *>(smem_flag)) {
-        finalize_stats(a, b, ntiles, tid);
-        if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-__global__ __launch_bounds__(256) void stats_finalize_kernel(StatOut a, StatOut b, int ntiles)
-{
-    finalize_stats(a, b, ntiles, threadIdx.x);
+    if (!*reinterpret_cast<volatile unsigned *>(smem_flag)) return;
+    auto fold = [&](const StatOut &st, const StatRows &r) {
+        if (!st.part2 || tid >= r.nrows) return;
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(st.part) + (size_t)(r.row0 + tid) * ntiles + t0;
+        double S = 0.0, Q = 0.0;
+        for (int k0 = 0; k0 < nin; k0 += 16) {
+            unsigned long long v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = k0 + k < nin ? __hip_atomic_load(src + k0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { S += (double)__builtin_bit_cast(float, (unsigned)v[k]); Q += (double)__builtin_bit_cast(float, (unsigned)(v[k] >> 32)); }
+        }
+        double *d = st.part2 + ((size_t)(r.row0 + tid) * st.nb + bucket) * 2;
+        d[0] = S; d[1] = Q;
+    };
+    fold(a, ra);
+    fold(b, rb);
 }
 
 // ---- the convolution ---------------------------------------------------------------------------------------------------
@@ -213,9 +203,9 @@ struct ConvGeo {
     static constexpr int RP = TAPS == 1 ? TWC : (TWC == 32 ? HC : 32);       // LDS row pitch in pixels (32 for the 16-wide tiles: bank note in DESIGN.md)
     static constexpr int NPIX = HR * RP;
     static constexpr int ACTB = (NPIX * PIXB + 1023) & ~1023;
-    static constexpr int RS_FIT = (163840 - 2048 - 64 - 2 * ACTB) / RING_SLOT;
+    static constexpr int RS_FIT = (163840 - 2048 - 64 - 256 - 2 * ACTB) / RING_SLOT;
     static constexpr int RS = RS_FIT > 6 ? 6 : RS_FIT;            // ring slots; RS - 1 groups of weights are in flight
-    static constexpr int L_ACT0 = 0, L_ACT1 = ACTB, L_RING = 2 * ACTB, L_AB = L_RING + RS * RING_SLOT, L_FLAG = L_AB + 2048, L_TOTAL = L_FLAG + 64;
+    static constexpr int L_ACT0 = 0, L_ACT1 = ACTB, L_RING = 2 * ACTB, L_AB = L_RING + RS * RING_SLOT, L_FLAG = L_AB + 2048, L_TOTAL = L_FLAG + 64 + 256;     // (flag, then (mean, rstd) of the input's 32 groups)
     static_assert(RS >= 3, "no room for the weight ring");
 };
 
@@ -240,32 +230,17 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
     const int cpk = (p.Cin >> 5) / p.ksplit, c0 = ks * cpk, c1 = c0 + cpk;
 
     // ---- the prologue's affine map per input channel: relu(a x + b), a = gamma rstd, b = beta - mean a (both times in_scale)
+    if constexpr (NORM) {
+        if (tid < p.Cin / p.in_cpg)
+            *reinterpret_cast<f32x2 *>(smem + LDS_FLAG + 64 + tid * 8) = fold_group(p.in_part2 + (size_t)tid * p.in_nb * 2, p.in_nb, p.in_inv_n, p.in_eps);
+        __syncthreads();
+    }
     if (tid < p.Cin) {
         float a = p.in_scale, b = 0.0f;
         if constexpr (NORM) {
-            const int g = tid / p.in_cpg;
-            float mean, rstd;
-            if (p.in_tiles > 0) {
-                // The producers of a small tensor (<= 32 tiles) leave their partials unfolded: every consumer folds them itself, in the order of
-                // finalize_stats (a butterfly over the tiles, in double), and the producers are spared the ticket and the fold -- two device-scope
-                // round trips at the end of launches that are nothing but latency.
-                double sv[32], qv[32];
-#pragma unroll
-                for (int t = 0; t < 32; ++t) {
-                    const f32x2 v = t < p.in_tiles ? *reinterpret_cast<const f32x2 *>(p.in_part + ((size_t)g * p.in_tiles + t) * 2) : f32x2{0.0f, 0.0f};
-                    sv[t] = (double)v[0]; qv[t] = (double)v[1];
-                }
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1)
-#pragma unroll
-                    for (int l = 0; l < o; ++l) { sv[l] += sv[l + o]; qv[l] += qv[l + o]; }
-                const double m = sv[0] * (double)p.in_inv_n, var = fmax(qv[0] * (double)p.in_inv_n - m * m, 0.0);
-                mean = (float)m; rstd = (float)(1.0 / sqrt(var + (double)p.in_eps));
-            } else {
-                mean = p.in_stats[2 * g]; rstd = p.in_stats[2 * g + 1];
-            }
-            a = p.gamma[tid] * rstd;
-            b = (p.beta[tid] - mean * a) * p.in_scale;
+            const f32x2 mr = *reinterpret_cast<const f32x2 *>(smem + LDS_FLAG + 64 + (tid / p.in_cpg) * 8);
+            a = p.gamma[tid] * mr[1];
+            b = (p.beta[tid] - mr[0] * a) * p.in_scale;
             a *= p.in_scale;
         }
         *reinterpret_cast<f32x2 *>(smem + LDS_AB + tid * 8) = f32x2{a, b};
@@ -446,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
 
     // ---- split-K: every k slice leaves its raw accumulators in HBM; the last one to arrive (ticket) adds all of them in slice order -- its
     // own included, re-read, so that the sum does not depend on who is last -- and goes on to the epilogue.  Device-scope accesses, no fences
-    // (see stats_tail).
+    // (see stats_commit).
     if (p.ksplit > 1) {
         constexpr int NV = PT * CT * 8;                        // 8-byte pieces per thread (device-scope accesses are at most 64 bits wide)
         typedef unsigned long long u64;
@@ -532,10 +507,10 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
     if (full) emit(std::false_type{}); else emit(std::true_type{});
 
     // ---- statistics: the two pixel halves, then the cpg adjacent channel lanes, then the four waves through LDS
-    if (p.st_raw.part || p.st_y.part) {
+    if (p.st_raw.part2 || p.st_y.part2) {
         float *red = reinterpret_cast<float *>(smem + LDS_ACT0);          // [kind][wave][32 CT groups max](s, q); the staged tiles are dead
         auto reduce = [&](const StatOut &st, float *s, float *q, int kind) {
-            if (!st.part) return;
+            if (!st.part2) return;
 #pragma unroll
             for (int m = 0; m < CT; ++m) {
                 s[m] += __shfl_xor(s[m], 32); q[m] += __shfl_xor(q[m], 32);
@@ -549,23 +524,22 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         reduce(p.st_raw, sr, qr, 0);
         reduce(p.st_y, sy, qy, 1);
         __syncthreads();
-        const int ntiles = p.tiles_x * p.tiles_y;
-        auto publish = [&](const StatOut &st, int kind) {
-            if (!st.part) return;
-            const int gps = 32 * CT / st.cpg;                              // groups of this workgroup's slice
-            if (tid < gps) {
-                float s = 0.0f, q = 0.0f;
+        auto rows = [&](const StatOut &st, int kind) {
+            StatRows r{0, 0, 0.0f, 0.0f};
+            if (!st.part2) return r;
+            r.nrows = 32 * CT / st.cpg;                                    // groups of this workgroup's slice
+            r.row0 = slice * r.nrows;
+            if (tid < r.nrows)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const f32x2 v = *reinterpret_cast<const f32x2 *>(red + ((kind * 4 + w) * 32 * CT + tid) * 2);
-                    s += v[0]; q += v[1];
+                    r.s += v[0]; r.q += v[1];
                 }
-                store_partial(st.part, (size_t)(slice * gps + tid) * ntiles + tile, s, q);
-            }
+            return r;
         };
-        publish(p.st_raw, 0);
-        publish(p.st_y, 1);
-        stats_tail(p.st_raw, p.st_y, p.counter, ntiles, gridDim.x / p.ksplit, tid, smem + LDS_FLAG);
+        const StatRows ra = rows(p.st_raw, 0), rb = rows(p.st_y, 1);
+        const int ntiles = p.tiles_x * p.tiles_y, bs = p.st_raw.part2 ? p.st_raw.bsize : p.st_y.bsize;
+        stats_commit(p.st_raw, ra, p.st_y, rb, p.counter + (size_t)(tile / bs) * slices + slice, tile, ntiles, tid, smem + LDS_FLAG);
     }
 }
 
@@ -600,9 +574,9 @@ struct EltArgs {
     float *out;
     int H, W, C;                 // OUTPUT size
     StatOut st;
-    unsigned *counter;
+    unsigned *counter;           // [bucket] (elt_body) / [bucket][chunk] (tiled upsample) tickets
     int Hb, Wb;                  // size of the other tensor (pool: the input; upsample-add: low3)
-    const float *in_stats, *gamma, *beta; int in_cpg;     // norm-relu: GroupNorm of a
+    const double *in_part2; const float *gamma, *beta; int in_cpg, in_nb; float in_inv_n, in_eps;     // norm-relu: GroupNorm of a
     int ppw;                     // output pixels per workgroup
     int ntiles;
 };
@@ -623,19 +597,18 @@ __device__ __forceinline__ void elt_body(const EltArgs &p, F &&value)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
     }
-    if (!p.st.part) return;
+    if (!p.st.part2) return;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { red[tid * 8 + 2 * e] = s[e]; red[tid * 8 + 2 * e + 1] = q[e]; }
     __syncthreads();
     // group g = channels [g cpg, (g + 1) cpg): cpg in {1, 2, 4, 8}
-    if (tid < p.st.groups) {
-        float ss = 0.0f, qq = 0.0f;
+    const int groups = p.C / p.st.cpg;
+    StatRows r{0, groups, 0.0f, 0.0f};
+    if (tid < groups)
         for (int c = tid * p.st.cpg; c < (tid + 1) * p.st.cpg; ++c)
-            for (int k = 0; k < nsub; ++k) { const float *r = red + ((k * c4n + (c >> 2)) * 8 + 2 * (c & 3)); ss += r[0]; qq += r[1]; }
-        store_partial(p.st.part, (size_t)tid * p.ntiles + blockIdx.x, ss, qq);
-    }
+            for (int k = 0; k < nsub; ++k) { const float *rr = red + ((k * c4n + (c >> 2)) * 8 + 2 * (c & 3)); r.s += rr[0]; r.q += rr[1]; }
     StatOut none{};
-    stats_tail(p.st, none, p.counter, p.ntiles, gridDim.x, tid, reinterpret_cast<char *>(flag));
+    stats_commit(p.st, r, none, StatRows{0, 0, 0.0f, 0.0f}, p.counter + blockIdx.x / p.st.bsize, blockIdx.x, p.ntiles, tid, reinterpret_cast<char *>(flag));
 }
 
 __global__ __launch_bounds__(256) void avgpool_kernel(const EltArgs p)
@@ -751,33 +724,34 @@ __global__ __launch_bounds__(256) void upadd_tiled_kernel(const UpTiledArgs a)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
     }
-    if (!p.st.part) return;
+    if (!p.st.part2) return;
     __syncthreads();
     float *red = src;                                              // [16 pixel lanes][64 channels](s, q)
 #pragma unroll
     for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x2 *>(red + (((tid >> 4) * UT_C) + quad * 4 + e) * 2) = f32x2{s[e], q[e]};
     __syncthreads();
-    const int gpc = UT_C / p.st.cpg;                               // groups of this workgroup's 64 channels
-    if (tid < gpc) {
-        float ss = 0.0f, qq = 0.0f;
+    const int gpc = UT_C / p.st.cpg, nchunks = p.C / UT_C;         // groups of this workgroup's 64 channels
+    StatRows r{chunk * gpc, gpc, 0.0f, 0.0f};
+    if (tid < gpc)
         for (int c = tid * p.st.cpg; c < (tid + 1) * p.st.cpg; ++c)
-            for (int k = 0; k < 16; ++k) { const f32x2 v = *reinterpret_cast<const f32x2 *>(red + (k * UT_C + c) * 2); ss += v[0]; qq += v[1]; }
-        store_partial(p.st.part, (size_t)(chunk * gpc + tid) * nt + tile, ss, qq);
-    }
+            for (int k = 0; k < 16; ++k) { const f32x2 v = *reinterpret_cast<const f32x2 *>(red + (k * UT_C + c) * 2); r.s += v[0]; r.q += v[1]; }
     StatOut none{};
-    stats_tail(p.st, none, p.counter, nt, gridDim.x, tid, reinterpret_cast<char *>(flag));
+    stats_commit(p.st, r, none, StatRows{0, 0, 0.0f, 0.0f}, p.counter + (size_t)(tile / p.st.bsize) * nchunks + chunk, tile, nt, tid, reinterpret_cast<char *>(flag));
 }
 
 // relu(GroupNorm(a)) materialised (HGFilters.py:178: the block that follows normalises THIS tensor again and needs its statistics)
 __global__ __launch_bounds__(256) void normrelu_kernel(const EltArgs p)
 {
+    __shared__ f32x2 mr[32];
+    if (threadIdx.x < p.C / p.in_cpg) mr[threadIdx.x] = fold_group(p.in_part2 + (size_t)threadIdx.x * p.in_nb * 2, p.in_nb, p.in_inv_n, p.in_eps);
+    __syncthreads();
     const int c4 = threadIdx.x % (p.C >> 2);
     float a[4], b[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int c = 4 * c4 + e, g = c / p.in_cpg;
-        a[e] = p.gamma[c] * p.in_stats[2 * g + 1];
-        b[e] = p.beta[c] - p.in_stats[2 * g] * a[e];
+        a[e] = p.gamma[c] * mr[g][1];
+        b[e] = p.beta[c] - mr[g][0] * a[e];
     }
     elt_body(p, [&](int oy, int ox, int c4_) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(p.a + ((size_t)oy * p.W + ox) * p.C + 4 * c4_);
@@ -816,16 +790,15 @@ struct DevConv {            // a packed convolution
 struct DevNorm { float *gamma = nullptr, *beta = nullptr; int C = 0, groups = 32; float eps = 1e-5f; };
 struct DevBlock { DevConv conv[3], ds; bool has_ds = false; DevNorm bn[4]; int cin = 0, cout = 0; };
 
-struct Tensor { float *data = nullptr; int H = 0, W = 0, C = 0; float *stats = nullptr;       // stats: (mean, rstd) x 32 groups, or (small tensors)
-                float *part = nullptr; int part_tiles = 0; bool stats_used = false; };                                  // the producers' partials [group][part_tiles], folded by the consumers
+struct Tensor { float *data = nullptr; int H = 0, W = 0, C = 0;
+                double *part2 = nullptr; int nb = 0; };      // GroupNorm partials [32 groups][nb buckets] its producers leave, its consumers fold
 
-enum LaunchKind { L_S2D, L_CONV, L_POOL, L_UPADD, L_UPADD_TILED, L_NORMRELU, L_FINAL, L_FORK, L_JOIN };
+enum LaunchKind { L_S2D, L_CONV, L_POOL, L_UPADD, L_UPADD_TILED, L_NORMRELU, L_FORK, L_JOIN };
 struct Launch {
     LaunchKind kind;
     ConvArgs conv; int CT = 0, PT = 0, TAPS = 0, TWC = 0; bool norm = false;
     S2dArgs s2d;
     EltArgs elt; int ut_x = 0, ut_y = 0;     // (L_UPADD_TILED: the tile grid)
-    StatOut fa, fb; int fn = 0;      // L_FINAL
     unsigned grid = 0;
     int side = 0;                    // 1: the launch goes to the side stream (the hourglass' upper branches run beside the lower ones)
     int event = -1;                  // L_FORK: the side stream waits for the main stream here; L_JOIN: the main stream waits for the side stream
@@ -840,7 +813,7 @@ struct Encoder {
     int depth = 0;
     std::vector<void *> weight_allocs;
     // the plan of one input size
-    int Hin = 0, Win = 0, lastwg = -1;
+    int Hin = 0, Win = 0;
     std::vector<Launch> plan;
     std::vector<void *> plan_allocs;
     float *in_buf = nullptr;
@@ -848,7 +821,7 @@ struct Encoder {
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr, side_stream = nullptr;
     std::vector<hipEvent_t> events;
-    int fork = -1, ksplit = -1, defer = -1;
+    int fork = -1, ksplit = -1;
 };
 
 static void free_plan(Encoder *e)
@@ -1033,9 +1006,9 @@ int pack_encoder(avc_ctx *ctx, const avc_hgfilter *net)
 
 // ---- launch plan -----------------------------------------------------------------------------------------------------
 struct Planner {
-    avc_ctx *ctx; Encoder *e; std::vector<void *> allocs; bool lastwg; int rc = AVC_OK;
+    avc_ctx *ctx; Encoder *e; std::vector<void *> allocs; int rc = AVC_OK;
     float gn_eps = 1e-5f; int gn_groups = 32;
-    int side = 0; bool fork = false, defer = true;
+    int side = 0; bool fork = false;
 
     void push(Launch L) { L.side = side; e->plan.push_back(L); }
     void sync(LaunchKind kind)
@@ -1061,39 +1034,30 @@ struct Planner {
     {
         Tensor t; t.H = H; t.W = W; t.C = C;
         t.data = static_cast<float *>(alloc(sizeof(float) * (size_t)H * W * C));
-        t.stats = static_cast<float *>(alloc(sizeof(float) * 2 * 256, true));
         return t;
     }
-    StatOut stat(Tensor &t, int first_channel, int channels, int ntiles)
+    // the statistics a launch of `ntiles` tiles leaves for channels [first_channel, + channels) of t; row_blocks = the launch's workgroups per tile
+    // (channel slices / chunks), each with its own ticket per bucket
+    StatOut stat(Tensor &t, int first_channel, int channels, int ntiles, int row_blocks, unsigned **counter)
     {
         StatOut s{};
         s.cpg = t.C / gn_groups;
-        s.groups = channels / s.cpg;
-        if (defer && ntiles <= 32 && (t.part_tiles == 0 || t.part_tiles == ntiles) && !(t.part_tiles == 0 && t.stats_used)) {
-            // a small tensor: its producers (one, or the three convolutions of a block, same tile grid) write into ONE table the consumers fold
-            if (!t.part) { t.part = static_cast<float *>(alloc(sizeof(float) * 2 * (size_t)gn_groups * ntiles, true)); t.part_tiles = ntiles; }
-            s.part = t.part + 2 * (size_t)(first_channel / s.cpg) * ntiles;
-            s.stats = nullptr;                         // no fold on the producer's side
-        } else {
-            if (t.part_tiles) { set_error("avc_hgfilter_forward: internal: mixed statistics modes on one tensor"); rc = AVC_ERR_STATE; }
-            t.stats_used = true;
-            s.part = static_cast<float *>(alloc(sizeof(float) * 2 * (size_t)s.groups * ntiles));
-            s.stats = t.stats + 2 * (first_channel / s.cpg);
+        s.bsize = (ntiles + 31) / 32;
+        s.nb = (ntiles + s.bsize - 1) / s.bsize;
+        if (!t.part2) { t.part2 = static_cast<double *>(alloc(sizeof(double) * 2 * (size_t)gn_groups * s.nb, true)); t.nb = s.nb; }
+        if (t.nb != s.nb && !rc) { set_error("avc_hgfilter_forward: internal: the producers of one tensor disagree on its tile grid (%d vs %d buckets)", t.nb, s.nb); rc = AVC_ERR_STATE; }
+        s.part2 = t.part2 + 2 * (size_t)(first_channel / s.cpg) * s.nb;
+        if (s.bsize > 1) {
+            s.part = static_cast<float *>(alloc(sizeof(float) * 2 * (size_t)(channels / s.cpg) * ntiles));
+            if (!*counter) *counter = static_cast<unsigned *>(alloc(sizeof(unsigned) * (size_t)s.nb * row_blocks, true));
         }
-        s.inv_n = 1.0f / ((float)s.cpg * (float)t.H * (float)t.W);
-        s.eps = gn_eps;
         return s;
-    }
-    unsigned *counter() { return lastwg ? static_cast<unsigned *>(alloc(sizeof(unsigned), true)) : nullptr; }
-    void finish(const StatOut &a, const StatOut &b, int ntiles)
-    {
-        if (lastwg || (!a.stats && !b.stats)) return;
-        Launch f{}; f.kind = L_FINAL; f.fa = a; f.fb = b; f.fn = ntiles; f.grid = 1;
-        push(f);
     }
 
     // conv: x (through gn + ReLU when gn != null) -> raw (with statistics when raw_stats) and / or y[:, ycoff ...] = conv + res
-    void conv(const DevConv &w, const Tensor &x, const DevNorm *gn, Tensor *raw, bool raw_stats, Tensor *y, const Tensor *res, int ycoff, float raw_in_scale = 1.0f)
+    // (force_pt: the three convolutions of a block write their slices of ONE statistics table and must agree on the tile grid)
+    void conv(const DevConv &w, const Tensor &x, const DevNorm *gn, Tensor *raw, bool raw_stats, Tensor *y, const Tensor *res, int ycoff, float raw_in_scale = 1.0f,
+              int force_pt = 0)
     {
         if (rc) return;
         Launch L{}; L.kind = L_CONV;
@@ -1101,16 +1065,18 @@ struct Planner {
         L.TWC = x.W >= 32 ? 32 : 16;
         L.CT = conv_ct(w.cout); L.PT = (L.TWC == 32 && w.taps != 16) ? 2 : 1;
         auto wgs = [&](int CT, int PT) { const int rows = 4 * PT * (32 / L.TWC); return ((x.H + rows - 1) / rows) * ((x.W + L.TWC - 1) / L.TWC) * (w.cout / (32 * CT)); };
+        if (force_pt) L.PT = force_pt;
         while (wgs(L.CT, L.PT) < ctx->num_cus) {
-            if (L.PT == 2) L.PT = 1;
+            if (L.PT == 2 && !force_pt) L.PT = 1;
             else if (L.CT > 1 && w.taps != 16) L.CT /= 2;
             else break;
         }
         const int rows = 4 * L.PT * (32 / L.TWC);
         ConvArgs &a = L.conv;
         a.x = x.data; a.H = x.H; a.W = x.W; a.Cin = x.C;
-        a.in_stats = x.stats; a.in_part = x.part; a.in_tiles = gn ? x.part_tiles : 0; a.in_eps = gn_eps;
+        a.in_part2 = gn ? x.part2 : nullptr; a.in_nb = x.nb; a.in_eps = gn_eps;
         a.in_inv_n = gn ? 1.0f / ((float)(x.C / gn->groups) * (float)x.H * (float)x.W) : 0.0f;
+        if (gn && !x.part2 && !rc) { set_error("avc_hgfilter_forward: internal: a normalised input without statistics"); rc = AVC_ERR_STATE; }
         a.gamma = gn ? gn->gamma : nullptr; a.beta = gn ? gn->beta : nullptr; a.in_cpg = gn ? x.C / gn->groups : 1;
         a.in_scale = gn ? 16.0f : raw_in_scale;
         const int v = L.CT == 4 ? 2 : (L.CT == 2 ? 1 : 0);
@@ -1121,9 +1087,9 @@ struct Planner {
         a.y = y ? y->data : nullptr; a.res = res ? res->data : nullptr; a.yC = y ? y->C : 0; a.ycoff = ycoff;
         a.tiles_x = (x.W + L.TWC - 1) / L.TWC; a.tiles_y = (x.H + rows - 1) / rows;
         const int ntiles = a.tiles_x * a.tiles_y;
-        if (raw && raw_stats) a.st_raw = stat(*raw, 0, w.cout, ntiles);
-        if (y) a.st_y = stat(*y, ycoff, w.cout, ntiles);
-        a.counter = (a.st_raw.stats || a.st_y.stats) ? counter() : nullptr;
+        const int slices = w.cout / (32 * L.CT);
+        if (raw && raw_stats) a.st_raw = stat(*raw, 0, w.cout, ntiles, slices, &a.counter);
+        if (y) a.st_y = stat(*y, ycoff, w.cout, ntiles, slices, &a.counter);
         // few workgroups, each streaming its whole K serially, are bound by the latency of their weight stream: split K over more of them
         const int wg = ntiles * (w.cout / (32 * L.CT)), nchunk = x.C / 32;
         a.ksplit = 1;
@@ -1135,7 +1101,6 @@ struct Planner {
         }
         L.grid = (unsigned)(wg * a.ksplit);
         push(L);
-        finish(a.st_raw, a.st_y, ntiles);
     }
 
     Tensor block(const DevBlock &b, const Tensor &x)
@@ -1143,9 +1108,13 @@ struct Planner {
         Tensor y = tensor(x.H, x.W, b.cout), o1 = tensor(x.H, x.W, b.cout / 2), o2 = tensor(x.H, x.W, b.cout / 4), r;
         const Tensor *res = &x;
         if (b.has_ds) { r = tensor(x.H, x.W, b.cout); conv(b.ds, x, &b.bn[3], &r, false, nullptr, nullptr, 0); res = &r; }
-        conv(b.conv[0], x, &b.bn[0], &o1, true, &y, res, 0);
-        conv(b.conv[1], o1, &b.bn[1], &o2, true, &y, res, b.cout / 2);
-        conv(b.conv[2], o2, &b.bn[2], nullptr, false, &y, res, b.cout / 2 + b.cout / 4);
+        // the tile height of the block: what its narrowest convolution (cout / 4 channels) would pick on its own
+        const int twc = x.W >= 32 ? 32 : 16;
+        int pt = twc == 32 ? 2 : 1;
+        if (pt == 2 && ((x.H + 7) / 8) * ((x.W + 31) / 32) * std::max(1, b.cout / 4 / 32) < ctx->num_cus) pt = 1;
+        conv(b.conv[0], x, &b.bn[0], &o1, true, &y, res, 0, 1.0f, pt);
+        conv(b.conv[1], o1, &b.bn[1], &o2, true, &y, res, b.cout / 2, 1.0f, pt);
+        conv(b.conv[2], o2, &b.bn[2], nullptr, false, &y, res, b.cout / 2 + b.cout / 4, 1.0f, pt);
         return y;
     }
 
@@ -1157,27 +1126,25 @@ struct Planner {
         EltArgs &g = L.elt;
         g.a = a.data; g.b = b ? b->data : nullptr; g.out = out.data; g.H = H; g.W = W; g.C = a.C;
         g.Hb = b ? b->H : a.H; g.Wb = b ? b->W : a.W;
-        if (gn && a.part_tiles) { set_error("avc_hgfilter_forward: internal: the norm + ReLU launch takes folded statistics"); rc = AVC_ERR_STATE; }
-        if (gn) { g.in_stats = a.stats; g.gamma = gn->gamma; g.beta = gn->beta; g.in_cpg = a.C / gn->groups; }
+        if (gn) {
+            g.in_part2 = a.part2; g.in_nb = a.nb; g.gamma = gn->gamma; g.beta = gn->beta; g.in_cpg = a.C / gn->groups;
+            g.in_inv_n = 1.0f / ((float)g.in_cpg * (float)a.H * (float)a.W); g.in_eps = gn_eps;
+        }
         const int npix = H * W;
         if (kind == L_UPADD && a.C % UT_C == 0 && H >= 2 * UT_H && W >= UT_W) {       // the tiled form (every level of the 512^2 path but the lowest)
             L.kind = L_UPADD_TILED;
             L.ut_x = (W + UT_W - 1) / UT_W; L.ut_y = (H + UT_H - 1) / UT_H;
             g.ntiles = L.ut_x * L.ut_y;
             g.ppw = UT_H * UT_W;
-            g.st = stat(out, 0, a.C, g.ntiles);
-            g.counter = g.st.stats ? counter() : nullptr;
+            g.st = stat(out, 0, a.C, g.ntiles, a.C / UT_C, &g.counter);
             L.grid = (unsigned)(g.ntiles * (a.C / UT_C));
         } else {
-            g.ppw = npix <= 1024 ? std::max(16, (npix + 31) / 32) : std::max(16, (npix + 511) / 512);      // small tensors: <= 32 tiles (their consumers fold them)
+            g.ppw = npix <= 1024 ? std::max(16, (npix + 31) / 32) : std::max(16, (npix + 511) / 512);      // small tensors: <= 32 tiles, no tickets
             g.ntiles = (npix + g.ppw - 1) / g.ppw;
-            g.st = stat(out, 0, a.C, g.ntiles);
-            g.counter = g.st.stats ? counter() : nullptr;
+            g.st = stat(out, 0, a.C, g.ntiles, 1, &g.counter);
             L.grid = (unsigned)g.ntiles;
         }
         push(L);
-        StatOut none{};
-        finish(g.st, none, g.ntiles);
         return out;
     }
 
@@ -1245,7 +1212,6 @@ static int run_plan(Encoder *e, hipStream_t main_stream)
         case L_UPADD: hipLaunchKernelGGL(upadd_kernel, dim3(L.grid), dim3(256), 0, s, L.elt); break;
         case L_UPADD_TILED: { UpTiledArgs u{L.elt, L.ut_x, L.ut_y}; hipLaunchKernelGGL(upadd_tiled_kernel, dim3(L.grid), dim3(256), 0, s, u); break; }
         case L_NORMRELU: hipLaunchKernelGGL(normrelu_kernel, dim3(L.grid), dim3(256), 0, s, L.elt); break;
-        case L_FINAL: hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(256), 0, s, L.fa, L.fb, L.fn); break;
         }
     }
     AVC_HIP(hipGetLastError());
@@ -1259,15 +1225,13 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
     AVC_REQUIRE(H1 % (1 << e->depth) == 0 && W1 % (1 << e->depth) == 0, AVC_ERR_ARG,
                 "avc_hgfilter_forward: a %d x %d image gives %d x %d features, which the depth-%d hourglass cannot halve %d times and add back "
                 "(up1 + up2, HGFilters.py:118: the reference raises a size mismatch)", Hin, Win, H1, W1, e->depth, e->depth);
-    Planner P{ctx, e, {}, ctx->opt.enc_lastwg != 0};
+    Planner P{ctx, e, {}};
     P.gn_eps = e->bn1.eps; P.gn_groups = e->bn1.groups;
     P.fork = ctx->opt.enc_fork != 0;
-    P.defer = ctx->opt.enc_defer != 0;
     if (P.fork && !e->side_stream) AVC_HIP(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
     e->in_buf = static_cast<float *>(P.alloc(sizeof(float) * 6 * (size_t)Hin * Win));
     // conv1 (space-to-depth, then 4x4 taps on the matrix pipe) + statistics of bn1
     Tensor sd = P.tensor(H1, W1, 32), t0 = P.tensor(H1, W1, 64);
-    t0.stats_used = true;                                  // its consumer is the norm + ReLU launch, which takes folded statistics
     if (!P.rc) {
         Launch L{}; L.kind = L_S2D;
         L.s2d = S2dArgs{e->in_buf, Hin, Win, H1, W1, sd.data};
@@ -1288,7 +1252,7 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
     e->out = out;
     e->plan_allocs = P.allocs;
     if (P.rc) { free_plan(e); return P.rc; }
-    e->Hin = Hin; e->Win = Win; e->lastwg = ctx->opt.enc_lastwg; e->fork = ctx->opt.enc_fork; e->ksplit = ctx->opt.enc_ksplit; e->defer = ctx->opt.enc_defer;
+    e->Hin = Hin; e->Win = Win; e->fork = ctx->opt.enc_fork; e->ksplit = ctx->opt.enc_ksplit;
     // record the launches once as a hipGraph (replayed with one hipGraphLaunch per frame)
     if (ctx->opt.enc_graph) {
         if (!e->cap_stream) AVC_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
@@ -1312,7 +1276,7 @@ int encoder_forward(avc_ctx *ctx, const float *image, int H, int W, float *feat_
     Encoder *e = static_cast<Encoder *>(ctx->encoder);
     AVC_REQUIRE(e && e->packed, AVC_ERR_STATE, "avc_hgfilter_forward: no encoder weights (call avc_hgfilter_pack first)");
     AVC_REQUIRE(image && H >= 2 && W >= 2 && (int64_t)H * W <= (1 << 22), AVC_ERR_ARG, "avc_hgfilter_forward: NULL image or unsupported size %d x %d", H, W);
-    if (e->Hin != H || e->Win != W || e->lastwg != ctx->opt.enc_lastwg || e->fork != ctx->opt.enc_fork || e->ksplit != ctx->opt.enc_ksplit || e->defer != ctx->opt.enc_defer || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
+    if (e->Hin != H || e->Win != W || e->fork != ctx->opt.enc_fork || e->ksplit != ctx->opt.enc_ksplit || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
         // (re)building frees buffers a replay in flight may still use
         AVC_HIP(hipDeviceSynchronize());
         if (int rc = build_plan(ctx, e, H, W)) return rc;

@@ -300,12 +300,8 @@ int avc_timing_read_cycles(avc_ctx *ctx, int which, double *avg_cycles_out, int6
  *   "knn_search"   0 (default: per wave) | 1 per-lane grid search | 2 cooperative grid search | 3 exhaustive scan -- all four return the same bits
  *   "fusion_graph" 1 (default: the fusion iterations replay a hipGraph) | 0 plain launches
  *   "enc_graph"    1 (default: avc_hgfilter_forward replays a hipGraph) | 0 plain launches -- same kernels, same bits
- *   "enc_lastwg"   1 (default: a convolution's last workgroup folds the GroupNorm partials it and its peers wrote) | 0 a launch of its own does --
- *                  same summation order, same bits
  *   "enc_ksplit"   1 (default: a convolution that would run on fewer than half the CUs splits its input channels over several workgroups per
  *                  tile, whose partial sums the last to arrive adds in a fixed order) | 0 -- deterministic either way; the two differ by fp32 rounding
- *   "enc_defer"    1 (default: the GroupNorm partials of a tensor of <= 32 tiles are folded by its consumers, sparing the producers the ticket and
- *                  the fold) | 0 always by the producers -- same summation order, same bits
  *   "enc_fork"     1 (default: the hourglass' upper branches run on a second stream -- parallel branches of the hipGraph -- beside the lower ones) |
  *                  0 one stream -- same kernels, same bits */
 int avc_set_option(avc_ctx *ctx, const char *name, int value);

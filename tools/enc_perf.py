@@ -1,5 +1,5 @@
-"""Timing of the HIP image encoder (csrc/conv_enc.hip) at the reference's 512^2 input: hipGraph replay vs plain launches, statistics folded by the
-last workgroup vs by a launch of their own.  `python tools/enc_perf.py [--iters N] [--once]` on the GPU box (--once: one forward per setting, for rocprofv3)."""
+"""Timing of the HIP image encoder (csrc/conv_enc.hip) at the reference's 512^2 input: hipGraph replay vs plain launches, split-K and the
+second stream on / off.  `python tools/enc_perf.py [--iters N] [--once]` on the GPU box (--once: one forward per setting, for rocprofv3)."""
 import argparse
 import os
 import sys
@@ -22,11 +22,11 @@ def main():
     hg = HGFilter(1, 4, 6, 32, 'group', 'no_down', False).to('cuda').eval()
     syn.load_synth(hg, gi.SEED_NET)
     x = torch.from_numpy(gi.normal_maps(a.res)[None]).cuda()
-    settings = [(1, 1, 1)] if a.once else [(1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0), (1, 0, 0)]
+    settings = [(1, 1, 1)] if a.once else [(1, 1, 1), (0, 1, 1), (1, 1, 0), (1, 0, 1)]
     with torch.no_grad():
-        for graph, lastwg, fork in settings:
+        for graph, ksplit, fork in settings:
             _lib.set_option('enc_graph', graph)
-            _lib.set_option('enc_lastwg', lastwg)
+            _lib.set_option('enc_ksplit', ksplit)
             _lib.set_option('enc_fork', fork)
             for _ in range(1 if a.once else 3):
                 hg.encode(x, want_feat=False, bind=True)
@@ -39,7 +39,7 @@ def main():
                 hg.encode(x, want_feat=False, bind=True)
             e1.record()
             torch.cuda.synchronize()
-            print(f'encoder {a.res}^2  graph={graph} lastwg={lastwg} fork={fork}: {e0.elapsed_time(e1) / a.iters:.3f} ms per frame', flush=True)
+            print(f'encoder {a.res}^2  graph={graph} ksplit={ksplit} fork={fork}: {e0.elapsed_time(e1) / a.iters:.3f} ms per frame', flush=True)
 
 
 if __name__ == '__main__':
