@@ -93,8 +93,8 @@ class HGFilter(nn.Module):
         from .. import _lib
         if not x.is_cuda:
             raise RuntimeError('HGFilter runs on the HIP device only (csrc/conv_enc.hip); there is no CPU path')
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise RuntimeError('HGFilter: inference only -- call under torch.no_grad() (training is out of scope, SURVEY.md section 2)')
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise RuntimeError('HGFilter: inference only -- no gradient flows through the HIP encoder (training is out of scope, SURVEY.md section 2)')
         if bind and x.shape[0] != 1:
             raise ValueError('HGFilter.encode(bind=True): one frame at a time (B == 1)')
         x = x.contiguous().float()

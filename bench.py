@@ -392,7 +392,7 @@ def other_configs(device, frames=3):
     it['front_normal'], it['back_normal'] = fm[0], fm[1]
     t_re, r = stage_ms(lambda: pipe.recon_frame(it), 3)
     imgs = torch.cat([it['front_normal'], it['back_normal']], dim=1)
-    t_hg, _ = stage_ms(lambda: rn.get_feat_maps(imgs)[-1], 3)
+    t_hg, _ = stage_ms(lambda: rn.bind_feat_map(imgs), 3)          # the encoder as recon_frame runs it: its channel-last output bound as the decoder's map
     out['configs[2]'] = {'workload': 'AvatarCap full (main.py:357-453): avatar query + marching cubes + LBS, canonical normal fusion (100 iterations), HGFilter, '
                                      'reconstruction query + marching cubes + LBS; 256^3 grid, the reference\'s valid band', 'frames': frames,
                          'valid_points': int(ds.infer_pts.shape[0]), 'ms_per_frame': full_ms, 'frames_per_s': 1e3 / full_ms,

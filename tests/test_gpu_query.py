@@ -90,7 +90,7 @@ def test_recon_decoder_matches_reference_golden(golden):
     y = rn.decode(_t(pts[None]), _t(gi.img_feat_map()[None]), _t(gi.center()[None]))
     assert y.shape == (1, 2048)                                     # the reference's return shape (arch_recon.py:73-76), used as output[0] (main.py:442)
     assert maxabs(y[0].cpu().numpy(), golden['G6_decoder']) < TOL
-    # whole infer(): HGFilter on MIOpen + fused decoder
+    # whole infer(): HGFilter on the HIP encoder + fused decoder
     nm = gi.normal_maps(64)
     items = {'cano_pts': _t(pts[None]), 'cano_smpl_center': _t(gi.center()[None]),
              'front_normal': _t(nm[None, :3]), 'back_normal': _t(nm[None, 3:])}
@@ -98,7 +98,7 @@ def test_recon_decoder_matches_reference_golden(golden):
     assert y2.shape == golden['G6_recon'].shape
     err = maxabs(y2.cpu().numpy(), golden['G6_recon'])
     print(f'infer() vs G6_recon: {err:.3e}')
-    assert err < 1e-4   # measured 8e-7 (MIOpen's fp32 conv stack + the fused GroupNorm vs the reference on the CPU): north_star's bar holds end to end
+    assert err < 1e-4   # measured 8e-7 (the split-fp16 MFMA encoder vs the reference on the CPU): north_star's bar holds end to end
 
 
 @pytest.mark.parametrize('n', [1, 33, 4097])
