@@ -33,6 +33,8 @@ check_range = False
 # not in the reference: the HGFilter encoder (csrc/conv_enc.hip) replays its ~70 launches as one hipGraph per frame (avc_set_option "enc_graph");
 # False launches the same kernels one by one -- same bits
 hg_graph = True
+# ... and the warping field's U-Net (MIOpen) replays its ~70 launches as one hipGraph per frame; False: eager launches -- same kernels, same bits
+unet_graph = True
 
 
 def load_config(path):

@@ -81,8 +81,52 @@ class UnetNoCond7DS(nn.Module):
         self.upconvC7 = _Up(2 * nf, output_nc, 'upsample', bn=False, bias=True)
 
     def forward(self, x):
+        """On the HIP device the ~70 MIOpen launches of one pass (0.7 ms of kernels that the host needs ~1.4 ms to enqueue -- more when eight ranks share a
+        host) are recorded ONCE per input shape and set of weights as a hipGraph and replayed with one launch per frame (`config.unet_graph`): the same
+        kernels on the same arguments, bit for bit the eager pass (tests/test_gpu_producers.py).  The result is a fresh tensor, not the graph's buffer."""
+        from .. import config
+        if x.is_cuda and getattr(config, 'unet_graph', True) and not (torch.is_grad_enabled() and x.requires_grad):
+            y = self._graph_forward(x)
+            if y is not None:
+                return y
         with deterministic_convs():
             return self._forward(x)
+
+    def __getstate__(self):                    # a captured graph belongs to this process and these buffers: never pickled / deep-copied
+        d = dict(self.__dict__)
+        d.pop('_graph', None); d.pop('_graph_failed', None)
+        return d
+
+    def _graph_forward(self, x):
+        key = (tuple(x.shape), x.dtype, x.device, tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()),
+               tuple(b._version for b in self.buffers()))
+        g = self.__dict__.get('_graph')
+        if g is None or g['key'] != key:
+            if self.__dict__.get('_graph_failed') == key:
+                return None
+            try:
+                with torch.no_grad():
+                    static_in = x.detach().clone()
+                    side = torch.cuda.Stream(device=x.device)
+                    side.wait_stream(torch.cuda.current_stream(x.device))
+                    with torch.cuda.stream(side), deterministic_convs():
+                        for _ in range(2):          # MIOpen's solution search and workspaces settle before the capture
+                            self._forward(static_in)
+                    torch.cuda.current_stream(x.device).wait_stream(side)
+                    graph = torch.cuda.CUDAGraph()
+                    with deterministic_convs(), torch.cuda.graph(graph):
+                        out = self._forward(static_in)
+                g = {'key': key, 'graph': graph, 'in': static_in, 'out': out}
+                self.__dict__['_graph'] = g
+            except Exception as e:              # noqa: BLE001 -- a capture the runtime refuses: the eager launches of the same kernels, and say so once
+                import warnings
+                warnings.warn(f'UNet7DS: hipGraph capture failed ({type(e).__name__}: {e}); launching eagerly')
+                self.__dict__['_graph_failed'] = key
+                self.__dict__.pop('_graph', None)
+                return None
+        g['in'].copy_(x)
+        g['graph'].replay()
+        return g['out'].clone()
 
     def _forward(self, x):
         d = [x]

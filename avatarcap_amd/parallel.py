@@ -3,11 +3,16 @@
 The reference has no multi-GPU code; its frame loop (main.py:348) carries no state between frames, so
 frames shard embarrassingly: frame f runs on rank f mod world_size, one process per GPU, weights /
 grid / SMPL tables replicated.  The only exchange is an all-gather(v) of the finished meshes
-(torch.distributed; backend 'nccl' = RCCL over xGMI on the GPU box, 'gloo' in the CPU tests):
-  1. all_gather of the per-frame (V, F) counts,
-  2. one all_gather of the [verts | normals] float buffers and one of the int32 faces, padded to the
-     largest rank (xGMI moves the ~1 GB of a 64-frame batch in well under one frame time, so a single
-     large collective per batch beats per-frame ones).
+(torch.distributed; backend 'nccl' = RCCL over xGMI on the GPU box, 'gloo' in the CPU tests), exact-size
+and overlapped with the frames that follow (MeshExchange):
+  step k = the frames k * world .. k * world + world - 1, one per rank;
+  1. submit(mesh) starts an asynchronous all-gather of the step's (V, F) counts (16 bytes per rank) and returns;
+  2. one step later the counts are on the host: the step's meshes travel as `world` asynchronous broadcasts of EXACTLY
+     6 V + 3 F 32-bit words each ([verts | normals] and the faces in one buffer), issued on the communication stream while
+     the next frame's kernels run -- RCCL moves them over xGMI / SDMA; no padding to the largest rank, and nothing of the
+     exchange sits behind the last frame except that frame's own mesh;
+  3. finish() waits for what is still in flight and returns all meshes in frame order on every rank.
+all_gather_meshes(meshes, n_frames) is the same exchange for meshes that already exist.
 """
 from __future__ import annotations
 
@@ -42,15 +47,6 @@ def all_gather_slabs(local: torch.Tensor, n: int, group=None, force: bool = Fals
     return flat[:n]
 
 
-def _pack(meshes, device):
-    counts = torch.tensor([[m['v'].shape[0], m['f'].shape[0]] for m in meshes], dtype=torch.int64, device=device).reshape(-1, 2)
-    vn = [torch.cat([m['v'].reshape(-1, 3), m['vn'].reshape(-1, 3)], 1).reshape(-1) for m in meshes]
-    fs = [m['f'].reshape(-1).to(torch.int32) for m in meshes]
-    vbuf = torch.cat(vn) if vn else torch.empty(0, dtype=torch.float32, device=device)
-    fbuf = torch.cat(fs) if fs else torch.empty(0, dtype=torch.int32, device=device)
-    return counts, vbuf.to(torch.float32), fbuf
-
-
 def _collective_device(meshes, group, device):
     """Device of the send / receive buffers: the meshes' own, else the caller's, else -- for a rank that owns no frame (fewer frames
     than ranks) -- the current HIP device under the nccl (= RCCL) backend, which cannot move host tensors, and the host under gloo."""
@@ -63,9 +59,89 @@ def _collective_device(meshes, group, device):
     return torch.device('cpu')
 
 
+class MeshExchange:
+    """Exact-size, overlapped all-gather(v) of a batch's per-frame meshes (module docstring).  Every rank calls submit() once per step, in step
+    order, with its frame of that step ({'v' (V,3) f32, 'vn' (V,3) f32, 'f' (F,3) i32}) or None when it owns none (the last step of a batch whose
+    size is not a multiple of the world size), then finish().  `force` runs the collectives even with one rank (the single-GPU RCCL test)."""
+
+    def __init__(self, n_frames: int, group=None, device=None, force: bool = False):
+        self.n_frames, self.group, self.force = int(n_frames), group, force
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.active = self.world > 1 or force
+        self.device = device
+        self.steps = (self.n_frames + self.world - 1) // self.world
+        self.out = [None] * self.n_frames
+        self._k = 0                    # steps submitted
+        self._sent = 0                 # steps whose payload broadcasts have been issued
+        self._counts, self._mine, self._works = [], [], []
+        self.bytes_received = 0
+
+    def _src(self, r):                 # global rank of group rank r (broadcast takes global ranks)
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def submit(self, mesh):
+        k = self._k
+        if k >= self.steps:
+            raise ValueError(f'MeshExchange: {self.steps} steps for {self.n_frames} frames on {self.world} ranks, submit() called again')
+        f = k * self.world + self.rank
+        if (mesh is None) != (f >= self.n_frames):
+            raise ValueError(f'MeshExchange: rank {self.rank} step {k}: frame {f} of {self.n_frames} ' + ('is missing' if mesh is None else 'does not exist'))
+        self._k += 1
+        if not self.active:
+            self.out[f] = {'v': mesh['v'], 'vn': mesh['vn'], 'f': mesh['f']}
+            return
+        if self.device is None:
+            self.device = _collective_device([mesh] if mesh is not None else [], self.group, None)
+        dev = self.device
+        if mesh is None:
+            buf, V, F = torch.empty(0, dtype=torch.int32, device=dev), 0, 0
+        else:
+            V, F = int(mesh['v'].shape[0]), int(mesh['f'].shape[0])
+            vn = torch.cat([mesh['v'].reshape(-1, 3), mesh['vn'].reshape(-1, 3)], 1).to(torch.float32).contiguous()
+            buf = torch.cat([vn.reshape(-1).view(torch.int32), mesh['f'].reshape(-1).to(torch.int32)])       # 6 V + 3 F words, exactly
+        counts = torch.tensor([V, F], dtype=torch.int64, device=dev)
+        allc = torch.empty(2 * self.world, dtype=torch.int64, device=dev)
+        w = dist.all_gather_into_tensor(allc, counts, group=self.group, async_op=True)
+        self._counts.append((allc, w))
+        self._mine.append(buf)
+        if k >= 1:
+            self._send(k - 1)          # its counts were requested a whole frame ago
+
+    def _send(self, j):
+        """Step j's payload: `world` broadcasts of exact size (asynchronous; the receive buffers are the output meshes' storage)."""
+        allc, w = self._counts[j]
+        w.wait()
+        c = allc.cpu().reshape(self.world, 2)
+        for r in range(self.world):
+            f = j * self.world + r
+            if f >= self.n_frames:
+                continue
+            V, F = int(c[r, 0]), int(c[r, 1])
+            buf = self._mine[j] if r == self.rank else torch.empty(6 * V + 3 * F, dtype=torch.int32, device=self.device)
+            if r != self.rank:
+                self.bytes_received += 4 * buf.numel()
+            if buf.numel():
+                self._works.append(dist.broadcast(buf, src=self._src(r), group=self.group, async_op=True))
+            vn = buf[:6 * V].view(torch.float32).reshape(V, 6)
+            self.out[f] = {'v': vn[:, :3], 'vn': vn[:, 3:], 'f': buf[6 * V:].reshape(F, 3)}
+        self._sent = j + 1
+
+    def finish(self) -> list:
+        if self._k != self.steps:
+            raise ValueError(f'MeshExchange.finish: {self._k} of {self.steps} steps were submitted')
+        if self.active:
+            for j in range(self._sent, self.steps):
+                self._send(j)
+            for w in self._works:
+                w.wait()
+            self._works.clear()
+        return self.out
+
+
 def all_gather_meshes(meshes: list[dict], n_frames: int, group=None, force: bool = False, device=None) -> list[dict]:
     """meshes: this rank's frames -- exactly shard_frames(n_frames, rank, world), in that (ascending) order -- each
-    {'v' (V,3) f32, 'vn' (V,3) f32, 'f' (F,3) i32}.  Returns, on every rank, all n_frames meshes in frame order."""
+    {'v' (V,3) f32, 'vn' (V,3) f32, 'f' (F,3) i32}.  Returns, on every rank, all n_frames meshes in frame order (MeshExchange, all steps at once)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1 and not force:      # `force` runs the collectives even with one rank (RCCL smoke test)
@@ -73,33 +149,10 @@ def all_gather_meshes(meshes: list[dict], n_frames: int, group=None, force: bool
     mine = len(shard_frames(n_frames, rank, world))
     if len(meshes) != mine:
         raise ValueError(f'all_gather_meshes: rank {rank} of {world} owns {mine} of {n_frames} frames but was given {len(meshes)} meshes')
-    device = _collective_device(meshes, group, device)
-    kmax = (n_frames + world - 1) // world
-    counts, vbuf, fbuf = _pack(meshes, device)
-    cpad = torch.zeros((kmax, 2), dtype=torch.int64, device=device)
-    cpad[:counts.shape[0]] = counts
-    all_counts = [torch.empty_like(cpad) for _ in range(world)]
-    dist.all_gather(all_counts, cpad, group=group)
-    all_counts = torch.stack(all_counts).cpu()                       # (world, kmax, 2)
-    vmax = int(all_counts[:, :, 0].sum(1).max()) * 6
-    fmax = int(all_counts[:, :, 1].sum(1).max()) * 3
-    vpad = torch.zeros(max(vmax, 1), dtype=torch.float32, device=device); vpad[:vbuf.numel()] = vbuf
-    fpad = torch.zeros(max(fmax, 1), dtype=torch.int32, device=device); fpad[:fbuf.numel()] = fbuf
-    # one flat receive buffer per collective (no per-rank staging copies); the per-rank pieces below are views of it
-    flat_v = torch.empty(world * vpad.numel(), dtype=vpad.dtype, device=device)
-    flat_f = torch.empty(world * fpad.numel(), dtype=fpad.dtype, device=device)
-    dist.all_gather_into_tensor(flat_v, vpad, group=group)
-    dist.all_gather_into_tensor(flat_f, fpad, group=group)
-    all_v, all_f = flat_v.reshape(world, -1), flat_f.reshape(world, -1)
-    out = [None] * n_frames
-    for r in range(world):
-        vo = fo = 0
-        for k, f in enumerate(shard_frames(n_frames, r, world)):
-            V, Fn = int(all_counts[r, k, 0]), int(all_counts[r, k, 1])
-            vn = all_v[r][vo:vo + 6 * V].reshape(V, 6)
-            out[f] = {'v': vn[:, :3], 'vn': vn[:, 3:], 'f': all_f[r][fo:fo + 3 * Fn].reshape(Fn, 3)}
-            vo += 6 * V; fo += 3 * Fn
-    return out
+    ex = MeshExchange(n_frames, group, _collective_device(meshes, group, device), force)
+    for k in range(ex.steps):
+        ex.submit(meshes[k] if k < len(meshes) else None)
+    return ex.finish()
 
 
 # ---- the sharded frame loop of `-m test` and the process plumbing around it -------------------------------------------------------------
@@ -124,9 +177,12 @@ def self_launch(script: str, argv: list[str], n_ranks: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def init_process_group(backend: str, rank: int, world: int, device=None, timeout_s: float = 120.0):
-    """torch.distributed.init_process_group with a BOUNDED rendezvous and bounded collectives: a rank that never shows up (a GPU that failed to
-    come up, a wrong WORLD_SIZE) ends the job with a message and a non-zero status after `timeout_s` instead of hanging it."""
+def init_process_group(backend: str, rank: int, world: int, device=None, timeout_s: float = 120.0, collective_timeout_s: float | None = None):
+    """torch.distributed.init_process_group with a BOUNDED rendezvous: a rank that never shows up (a GPU that failed to come up, a wrong WORLD_SIZE)
+    ends the job with a message and a non-zero status after `timeout_s` instead of hanging it.  The collectives that follow get their OWN bound,
+    `collective_timeout_s` (default 10 x the rendezvous bound, at least 30 min): in `main.py -m test` the first collective after the rendezvous is reached
+    only when a rank has finished its whole shard, and ranks legitimately drift apart by minutes on a long sequence (I/O, a slower GPU, frames that fail
+    fast) -- one timeout for both would either let a dead rendezvous hang for half an hour or kill a healthy job."""
     import datetime
     import os
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -140,6 +196,67 @@ def init_process_group(backend: str, rank: int, world: int, device=None, timeout
     got = dist.get_world_size()
     if got != world:
         raise SystemExit(f'rank {rank}: the process group has {got} ranks, {world} were asked for')
+    # every rank is here: from now on the (longer) collective bound applies
+    barrier_or_die('rendezvous', rank, timeout_s)
+    if collective_timeout_s is None:
+        collective_timeout_s = max(10.0 * timeout_s, 1800.0)
+    try:
+        from torch.distributed.distributed_c10d import _set_pg_timeout
+        _set_pg_timeout(datetime.timedelta(seconds=collective_timeout_s))
+    except Exception as e:      # noqa: BLE001 -- a torch without the hook: one bound governs both (say so once)
+        if rank == 0:
+            print(f'# parallel: could not raise the collective timeout ({type(e).__name__}: {e}); rendezvous and collectives share {timeout_s:.0f} s', flush=True)
+
+
+def pin_to_gpu_numa(device_index: int, local_world: int = 1, log=None) -> dict:
+    """CPU affinity of this rank := the cores of its GPU's NUMA node (/sys/bus/pci/devices/<bdf>/numa_node), split evenly among the ranks that share
+    the node, and OMP / MKL threads to match: eight Python ranks on one host otherwise migrate across sockets and oversubscribe each other (bench.py's
+    --gpus 8 run is host-paced between launches).  Best effort: returns what it did, {} when the topology is not readable (containers, no sysfs)."""
+    import os
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = f'{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0'
+        node = int(open(f'/sys/bus/pci/devices/{bdf}/numa_node').read())
+        if node < 0:
+            return {}
+        cpus = _parse_cpulist(open(f'/sys/devices/system/node/node{node}/cpulist').read())
+        allowed = sorted(set(cpus) & os.sched_getaffinity(0))
+        if not allowed:
+            return {}
+        # ranks whose GPUs sit on the same node share its cores: give each an equal, disjoint slice
+        same = []
+        for d in range(torch.cuda.device_count()):
+            p = torch.cuda.get_device_properties(d)
+            b = f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0'
+            try:
+                if int(open(f'/sys/bus/pci/devices/{b}/numa_node').read()) == node:
+                    same.append(d)
+            except OSError:
+                pass
+        same = [d for d in same if d < max(local_world, 1)] or [device_index]
+        share = max(1, len(allowed) // len(same))
+        k = same.index(device_index) if device_index in same else 0
+        mine = allowed[k * share:(k + 1) * share] or allowed
+        os.sched_setaffinity(0, mine)
+        threads = max(1, min(len(mine), 16))
+        torch.set_num_threads(threads)
+        os.environ['OMP_NUM_THREADS'] = str(threads)
+        info = {'numa_node': node, 'cpus': len(mine), 'first_cpu': mine[0], 'threads': threads}
+        if log:
+            log(f'# rank on GPU {device_index} ({bdf}): NUMA node {node}, pinned to {len(mine)} cores from {mine[0]}, {threads} threads')
+        return info
+    except Exception:           # noqa: BLE001 -- never fatal
+        return {}
+
+
+def _parse_cpulist(text: str) -> list[int]:
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
 
 
 def barrier_or_die(what: str, rank: int, timeout_s: float = 120.0, group=None):
@@ -151,24 +268,46 @@ def barrier_or_die(what: str, rank: int, timeout_s: float = 120.0, group=None):
         raise SystemExit(f'rank {rank}: barrier "{what}" failed ({type(e).__name__}: {e}) -- a peer rank is gone or stuck')
 
 
-def run_sharded(frames: list, process, rank: int = 0, world: int = 1, log=print) -> dict:
+def _fatal(e: BaseException) -> bool:
+    """Errors after which the device or the process is not worth another frame: out of memory, a HIP runtime fault (sticky: every later call fails too)."""
+    if isinstance(e, (MemoryError, torch.cuda.OutOfMemoryError)):
+        return True
+    msg = str(e)
+    return 'HIP error' in msg or 'hipError' in msg or 'AVC_ERR_HIP' in msg or '(status -3)' in msg
+
+
+def run_sharded(frames: list, process, rank: int = 0, world: int = 1, log=print, max_consecutive_failures: int = 3) -> dict:
     """The frame loop of main.py:348, sharded (SURVEY.md 8(e)): this rank runs frames[rank::world] in order.  `process(k, frame, next_frame)` does one
     frame (next_frame: the one this rank runs after it, or None -- FramePipeline's look-ahead).  A frame that raises is logged and SKIPPED: the
     loop carries no state between frames (main.py:348), so one bad frame -- a missing .exr, an empty surface -- does not take the others down.
-    Returns {'done': [frames], 'failed': [(frame, 'Type: message')], 'results': {frame: what process returned}}."""
+    What is NOT contained: an out-of-memory or HIP runtime error (the device state is gone: the remaining frames are reported as failed without being
+    tried), and `max_consecutive_failures` failures in a row (something systematic: same treatment).
+    Returns {'done': [frames], 'failed': [(frame, 'Type: message')], 'results': {frame: what process returned}, 'aborted': reason or None}."""
     import traceback
     mine = [frames[i] for i in shard_frames(len(frames), rank, world)]
     done, failed, results = [], [], {}
+    streak, aborted = 0, None
     for k, fr in enumerate(mine):
+        if aborted:
+            failed.append((fr, f'not attempted: {aborted}'))
+            continue
         nxt = mine[k + 1] if k + 1 < len(mine) else None
         try:
             results[fr] = process(k, fr, nxt)
             done.append(fr)
+            streak = 0
         except Exception as e:      # noqa: BLE001 -- per-frame containment is the point
             failed.append((fr, f'{type(e).__name__}: {e}'))
             log(f'# rank {rank}: frame {fr} FAILED and is skipped -- {type(e).__name__}: {e}')
             log(''.join(traceback.format_exception(type(e), e, e.__traceback__)).rstrip())
-    return {'done': done, 'failed': failed, 'results': results}
+            streak += 1
+            if _fatal(e):
+                aborted = f'frame {fr} hit a fatal device error ({type(e).__name__})'
+            elif streak >= max_consecutive_failures:
+                aborted = f'{streak} frames in a row failed'
+            if aborted:
+                log(f'# rank {rank}: {aborted} -- the remaining {len(mine) - k - 1} frame(s) of this rank are not attempted')
+    return {'done': done, 'failed': failed, 'results': results, 'aborted': aborted}
 
 
 def gather_summaries(summary: dict, group=None) -> list[dict]:

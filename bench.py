@@ -56,10 +56,9 @@ PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA (MI355X_MICROA
 SUSTAINED_F16_TFLOPS = 1505.0      # what this part sustains at its power cap on split-fp16 MFMAs of FULL-ENTROPY operands fed from LDS, nothing else in
                                     # the instruction stream (1.47 GHz): tools/ubench/mfma_order.hip, profiles/r03_power_wall.md -- information only
                                     # (round 1's 1673 was measured on low-entropy operands)
-HBM_TRAFFIC_BYTES_256 = 0.510e9     # per dense 256^3 launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc (profiles/r03_pmc_avatar.md: 356 + 154 MB):
-                                    # 67.1 MB of occupancy written (exact), the feature map per XCD, what share of the weight stream left L2, and the
-                                    # per-column table of the column-folded launch (131 MB written by the column pass, read back 2 KB per tile);
-                                    # round 1's 1.98e9 also read 201 MB of points and wrote 201 MB of offsets nobody reads
+# (roofline.traffic -- HBM bytes per launch -- comes from PMC counters, which only a separate `rocprofv3 --pmc` pass can collect: it is null on the line
+#  and reported under profiles/ (r03_pmc_avatar.md: 0.51 GB per dense 256^3 launch against 0.087 GB algorithmic: the 131 MB per-column table written by the
+#  column pass and read back 2 KB per tile, the feature map per XCD, the share of the weight stream that leaves L2))
 
 
 class _stdout_to_stderr:
@@ -241,7 +240,9 @@ def main():
 
     from avatarcap_amd import _lib
     from avatarcap_amd.dataset import to_cuda
-    from avatarcap_amd.parallel import all_gather_meshes
+    from avatarcap_amd.parallel import MeshExchange, all_gather_meshes, pin_to_gpu_numa
+    if world > 1:
+        pin_to_gpu_numa(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))       # each rank on the cores of its GPU's NUMA node
     K, W, res = args.steps, args.warmup, args.res
     n_frames = world * (K + W)
     pipe, sd = build_pipeline(res, 'dense', n_frames, device)
@@ -267,28 +268,32 @@ def main():
     barrier('start of the timed region')
     _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
     t0 = time.perf_counter()
-    meshes = []
+    # the batch's meshes are exchanged step by step WHILE the following frames compute (parallel.MeshExchange: exact sizes, asynchronous
+    # broadcasts on RCCL's stream); what is left behind the last frame is that frame's own mesh
+    ex = MeshExchange(world * K, force=force_dist) if (world > 1 or force_dist) else None
     for s in range(W, W + K):
         out = pipe.avatar_frame(my[s], next_items=my[s + 1] if s + 1 < W + K else None)
-        meshes.append({'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']})
+        if ex is not None:
+            ex.submit({'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']})
     torch.cuda.synchronize()
-    t_frames = time.perf_counter() - t0            # this rank's K frames, before the exchange
-    t_gather = 0.0
-    if world > 1 or force_dist:
+    t_frames = time.perf_counter() - t0            # this rank's K frames (the exchange of the earlier steps ran beside them)
+    t_gather, rx_bytes = 0.0, 0
+    if ex is not None:
         tg = time.perf_counter()
-        gathered = all_gather_meshes(meshes, world * K, force=force_dist)
+        gathered = ex.finish()
         torch.cuda.synchronize()
-        t_gather = time.perf_counter() - tg        # includes waiting for the slowest rank's frames
-        assert len(gathered) == world * K
+        t_gather = time.perf_counter() - tg        # what of the exchange was still outstanding, incl. waiting for the slowest rank's last frame
+        rx_bytes = ex.bytes_received
+        assert len(gathered) == world * K and all(m is not None for m in gathered)
     barrier('end of the timed region')
     dt = time.perf_counter() - t0
     _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
-    per_rank = [[dt, t_frames, t_gather]]
+    per_rank = [[dt, t_frames, t_gather, float(rx_bytes)]]
     if world > 1:
-        mine_t = torch.tensor([dt, t_frames, t_gather], dtype=torch.float64, device=device)
-        all_t = torch.empty(world * 3, dtype=torch.float64, device=device)
+        mine_t = torch.tensor([dt, t_frames, t_gather, float(rx_bytes)], dtype=torch.float64, device=device)
+        all_t = torch.empty(world * 4, dtype=torch.float64, device=device)
         dist.all_gather_into_tensor(all_t, mine_t)
-        per_rank = all_t.reshape(world, 3).cpu().tolist()
+        per_rank = all_t.reshape(world, 4).cpu().tolist()
         dt = max(r[0] for r in per_rank)           # MAX over ranks
 
     import ctypes as C
@@ -304,6 +309,7 @@ def main():
             'value': world * K / dt, 'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': K, 'warmup': W,
             'ms_per_step': dt / K * 1e3,
             'ms_per_step_per_rank': [r[1] / K * 1e3 for r in per_rank], 'all_gather_ms_per_rank': [r[2] * 1e3 for r in per_rank],
+            'all_gather_rx_mb_per_rank': [r[3] / 1e6 for r in per_rank],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (products as 3 split-fp16 MFMA passes, fp32 accumulate)', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: AvatarNet occupancy-only, {res}^3 grid dense ({N} points/frame), random SMPL pose, '
@@ -311,10 +317,15 @@ def main():
                        'grid': [res] * 3, 'points_per_frame': N, 'vertices_last_frame': int(out['cano_v'].shape[0]),
                        'faces_last_frame': int(out['f'].shape[0]), 'parallelism': f'frame-sharded x{world}',
                        'frames_in_batch': world * K, 'meshes_all_gathered': bool(world > 1 or force_dist),
+                       'mesh_exchange': 'exact-size broadcasts per step, overlapped with the following frames (parallel.MeshExchange)',
+                       'semantics': '`value` is the DENSE stress variant BASELINE configs[1] names (every one of the 256^3 grid points evaluated); the reference itself '
+                                    'evaluates only the valid band around the canonical SMPL and fills the rest (main.py:362-363): that is `masked` and the '
+                                    '`configs` legs below',
                        'dense_points': 'generated from the grid index (avc_avatar_query_grid), offsets not written'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_TFLOPS,
-                         'traffic': HBM_TRAFFIC_BYTES_256 if res == 256 else None, 'traffic_source': 'profiles/r03_pmc_avatar.md (FETCH_SIZE x2 + WRITE_SIZE; collected by rocprofv3 --pmc, not in this run)',
+                         'traffic': None, 'traffic_note': 'HBM bytes are PMC counters of a separate rocprofv3 --pmc pass (profiles/r04_pmc_avatar.md: 0.51 GB per launch, '
+                                                           '0.087 GB algorithmic); not measurable from inside this process, hence null here',
                          'kernel': 'avc::avatar_kernel<true,false,1> (+ its column_terms_kernel pass, timed together)', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
                          'shader_cycles_per_launch': avg_cyc.value, 'clock_mhz': (avg_cyc.value / (avg_ms.value * 1e3)) if avg_ms.value > 0 else 0.0,
                          'cycles_per_mfma': avg_cyc.value / (4728 * (N / 128 / min(N // 128, torch.cuda.get_device_properties(device).multi_processor_count))) if avg_cyc.value > 0 else 0.0,
@@ -325,6 +336,38 @@ def main():
                          'sustained_mfma_tflops_measured': SUSTAINED_F16_TFLOPS,
                          'mfma_issued_vs_sustained': (N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 / SUSTAINED_F16_TFLOPS) if avg_ms.value > 0 else 0.0},
         }
+        if world == 1:
+            # the HBM-bound kernels of the same frame, timed on its own volume and mesh (algorithmic bytes of SURVEY.md 8(d) / time / 8 TB/s)
+            try:
+                from avatarcap_amd import config as cfg_
+                from avatarcap_amd.utils import recon_util, smpl_util
+                vol, V, Fc = out['occ_volume'], int(out['cano_v'].shape[0]), int(out['f'].shape[0])
+
+                def timed(fn, reps=5):
+                    fn(); torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for _ in range(reps):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t) / reps
+
+                t_mc = timed(lambda: recon_util.recon_mesh_device(vol, pipe.vol_res, pipe.ds.cano_bounds, iso_value=cfg_.iso_value))
+                v1, n1, jm = out['cano_v'][None], out['cano_vn'][None], my[-1]['cano2live_jnt_mats']
+
+                def lbs_all():
+                    w = smpl_util.calculate_lbs(v1)
+                    smpl_util.skinning(v1, w, jm, True)
+                    smpl_util.skinning_normal(n1, w, jm)
+                t_lbs = timed(lbs_all)
+                mc_bytes, lbs_bytes = 4 * N + 24 * V + 12 * Fc, V * (12 + 96 + 24 + 12 + 12 + 64) + 83_000
+                line['roofline_secondary'] = {
+                    'marching cubes + normals (mesh.hip, 5 launches + one host sync)': {'bound': 'hbm', 'ms': t_mc * 1e3, 'algorithmic_bytes': mc_bytes,
+                                                                                       'achieved': mc_bytes / t_mc / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': mc_bytes / t_mc / 8e12},
+                    'KNN-4 LBS + skinning of points and normals (knn_lbs.hip)': {'bound': 'hbm', 'ms': t_lbs * 1e3, 'algorithmic_bytes': lbs_bytes,
+                                                                                'achieved': lbs_bytes / t_lbs / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': lbs_bytes / t_lbs / 8e12,
+                                                                                'note': 'the search is VALU-bound (DESIGN.md section 3): the HBM fraction is reported for completeness'}}
+            except Exception as e:       # informational only
+                line['roofline_secondary'] = {'error': repr(e)}
         if world == 1 and not args.no_masked:
             try:
                 line['masked'] = masked_run(res, device, K, W)
@@ -333,7 +376,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(pipe, sd, out, res)
         if world == 1 and not args.no_configs:
-            del pipe, my, meshes
+            del pipe, my
             torch.cuda.empty_cache()
             try:
                 line['configs'] = other_configs(device)
@@ -345,7 +388,7 @@ def main():
 
 
 def other_configs(device, frames=3):
-    """BASELINE configs[2] and configs[3] on the driver-timed line (VERDICT round 2, next #5), N = 1, a few frames each; never `value`."""
+    """BASELINE configs[2], the reference's own example.yaml grid and configs[3] on the driver-timed line, N = 1, a few frames each; never `value`."""
     from avatarcap_amd import config, synthetic as syn, _lib
     from avatarcap_amd.dataset import SyntheticTestDataset, to_cuda, synthetic_camera, synthetic_observed_normals
     from avatarcap_amd.network.arch_avatar import GeoTexAvatar
@@ -367,41 +410,59 @@ def other_configs(device, frames=3):
     with contextlib.redirect_stdout(sys.stderr):
         net = GeoTexAvatar(base_weight_volume=np.zeros((2, 2, 2, 24), np.float32)).to(device).eval(); syn.load_synth(net, syn.SEED)
         rn = ReconNetwork().to(device).eval(); syn.load_synth(rn, syn.SEED)
-    # ---- configs[2]: AvatarCap full, 256^3, the reference's valid band
-    config.cfg['testing']['vol_res'] = [256] * 3
-    ds = SyntheticTestDataset([256] * 3, valid='band', n_frames=frames + 1, device=device)
-    pipe = FramePipeline(net, ds, rn)
-    items = [to_cuda(ds[i], add_batch=True) for i in range(frames + 1)]
-    w2c, cam = synthetic_camera()
-    a = pipe.avatar_frame(items[0])
-    obs = synthetic_observed_normals(a['live_v'], a['live_vn'], a['f'], w2c, cam, seed=0)       # the image-observed normal map of step 2, synthesised once
-    pipe.avatarcap_frame(items[0], obs, w2c, cam); torch.cuda.synchronize()
-    _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
-    t = time.perf_counter()
-    for i in range(1, frames + 1):
-        a, r = pipe.avatarcap_frame(items[i], obs, w2c, cam, next_items=items[i + 1] if i < frames else None)
-    torch.cuda.synchronize()
-    full_ms = (time.perf_counter() - t) / frames * 1e3
-    q = [(C.c_double(), C.c_int64()) for _ in range(2)]
-    for w in range(2):
-        _lib.check(_lib.lib().avc_timing_read(ctx, w, C.byref(q[w][0]), C.byref(q[w][1]), 1))
-    _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
-    it = dict(items[1])
-    t_av, a = stage_ms(lambda: pipe.avatar_frame(items[1]), 3)
-    t_fu, fm = stage_ms(lambda: pipe.fuse_normals(a, obs, w2c, cam), 3)
-    it['front_normal'], it['back_normal'] = fm[0], fm[1]
-    t_re, r = stage_ms(lambda: pipe.recon_frame(it), 3)
-    imgs = torch.cat([it['front_normal'], it['back_normal']], dim=1)
-    t_hg, _ = stage_ms(lambda: rn.bind_feat_map(imgs), 3)          # the encoder as recon_frame runs it: its channel-last output bound as the decoder's map
-    out['configs[2]'] = {'workload': 'AvatarCap full (main.py:357-453): avatar query + marching cubes + LBS, canonical normal fusion (100 iterations), HGFilter, '
-                                     'reconstruction query + marching cubes + LBS; 256^3 grid, the reference\'s valid band', 'frames': frames,
-                         'valid_points': int(ds.infer_pts.shape[0]), 'ms_per_frame': full_ms, 'frames_per_s': 1e3 / full_ms,
-                         'stage_ms': {'avatar_frame (unet + band query + mc + lbs)': t_av, 'normal maps + fusion': t_fu,
-                                      'recon_frame (hgfilter + band query + mc + lbs)': t_re, 'of which hgfilter': t_hg},
-                         'kernel_ms': {'avatar query (band, column-folded)': q[0][0].value, 'recon query (band, point by point on generated coordinates)': q[1][0].value},
-                         'avatar_vertices': int(a['cano_v'].shape[0]), 'recon_vertices': int(r['cano_v'].shape[0])}
-    del ds, pipe, items, a, r, obs, fm, it, imgs
-    torch.cuda.empty_cache()
+    # ---- configs[2]: AvatarCap full on the reference's valid band -- at 256^3 and at the reference's own vol_res (configs/example.yaml:14-17)
+    def full_leg(res, what):
+        config.cfg['testing']['vol_res'] = list(res)
+        ds = SyntheticTestDataset(list(res), valid='band', n_frames=frames + 1, device=device)
+        pipe = FramePipeline(net, ds, rn)
+        items = [to_cuda(ds[i], add_batch=True) for i in range(frames + 1)]
+        w2c, cam = synthetic_camera()
+        a = pipe.avatar_frame(items[0])
+        obs = synthetic_observed_normals(a['live_v'], a['live_vn'], a['f'], w2c, cam, seed=0)       # the image-observed normal map of step 2, synthesised once
+        pipe.avatarcap_frame(items[0], obs, w2c, cam); torch.cuda.synchronize()
+        _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
+        t = time.perf_counter()
+        for i in range(1, frames + 1):
+            a, r = pipe.avatarcap_frame(items[i], obs, w2c, cam, next_items=items[i + 1] if i < frames else None)
+        torch.cuda.synchronize()
+        full_ms = (time.perf_counter() - t) / frames * 1e3
+        q = [(C.c_double(), C.c_int64()) for _ in range(2)]
+        for w in range(2):
+            _lib.check(_lib.lib().avc_timing_read(ctx, w, C.byref(q[w][0]), C.byref(q[w][1]), 1))
+        _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
+        it = dict(items[1])
+        t_av, a = stage_ms(lambda: pipe.avatar_frame(items[1]), 3)
+        t_fu, fm = stage_ms(lambda: pipe.fuse_normals(a, obs, w2c, cam), 3)
+        it['front_normal'], it['back_normal'] = fm[0], fm[1]
+        t_re, r = stage_ms(lambda: pipe.recon_frame(it), 3)
+        imgs = torch.cat([it['front_normal'], it['back_normal']], dim=1)
+        t_hg, _ = stage_ms(lambda: rn.bind_feat_map(imgs), 3)          # the encoder as recon_frame runs it: its channel-last output bound as the decoder's map
+        leg = {'workload': 'AvatarCap full (main.py:357-453): avatar query + marching cubes + LBS, canonical normal fusion (100 iterations), HGFilter '
+                           '(hand-written HIP encoder), reconstruction query + marching cubes + LBS; ' + what, 'vol_res': list(res), 'frames': frames,
+               'valid_points': int(ds.infer_pts.shape[0]), 'valid_fraction': float(ds.infer_pts.shape[0]) / float(np.prod(res)),
+               'ms_per_frame': full_ms, 'frames_per_s': 1e3 / full_ms,
+               'stage_ms': {'avatar_frame (unet + band query + mc + lbs)': t_av, 'normal maps + fusion': t_fu,
+                            'recon_frame (hgfilter + band query + mc + lbs)': t_re, 'of which hgfilter': t_hg},
+               'kernel_ms': {'avatar query (band, column-folded)': q[0][0].value, 'recon query (band, point by point on generated coordinates)': q[1][0].value},
+               'avatar_vertices': int(a['cano_v'].shape[0]), 'recon_vertices': int(r['cano_v'].shape[0])}
+        del ds, pipe, items, a, r, obs, fm, it, imgs
+        torch.cuda.empty_cache()
+        return leg
+
+    out['configs[2]'] = full_leg([256] * 3, "256^3 grid, the reference's valid band")
+    # secondary roofline fractions of the other kernels of the path, from the legs' own timings (algorithmic work of SURVEY.md 8(d) / time / peak)
+    c2 = out['configs[2]']
+    nb = c2['valid_points']
+    out['secondary_rooflines'] = {
+        'avatar band query (avatar_kernel, column-folded band)': {'bound': 'mfma', 'achieved_tflops': nb * FLOP_PER_POINT / (c2['kernel_ms']['avatar query (band, column-folded)'] * 1e-3) / 1e12},
+        'recon band query (recon_kernel)': {'bound': 'mfma', 'achieved_tflops': nb * 387072 / (c2['kernel_ms']['recon query (band, point by point on generated coordinates)'] * 1e-3) / 1e12},
+        'HGFilter encoder (conv_enc.hip, ~70 launches incl. their gaps)': {'bound': 'mfma', 'achieved_tflops': 232.3e9 / (c2['stage_ms']['of which hgfilter'] * 1e-3) / 1e12},
+    }
+    for v in out['secondary_rooflines'].values():
+        v['peak_tflops'] = PEAK_F16_TFLOPS
+        v['frac'] = v['achieved_tflops'] / PEAK_F16_TFLOPS
+    out['example.yaml'] = full_leg([384, 384, 128], "the reference's own configuration: vol_res 384 x 384 x 128 (configs/example.yaml:14-17), valid band "
+                                                    "(dataset/avatarcap_dataset.py:111-125) -- what `main.py -c configs/example.yaml -m test` computes per frame")
     # ---- configs[3]: 512^3 dense + marching cubes + colour head on the vertices (HBM-bound stress)
     config.cfg['testing']['vol_res'] = [512] * 3
     ds = SyntheticTestDataset([512] * 3, valid='dense', n_frames=2, device=device)

@@ -61,7 +61,7 @@ class _StandInPipeline:
 
 
 def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w_nerf=False, frame_idx=None, view_idx=0, interval=1,
-                  synthetic=False, n_frames=2, valid='band', integrate_manner='merge', rank=0, world=1, gather_meshes=False,
+                  synthetic=False, n_frames=2, valid='band', integrate_manner='merge', rank=0, world=1, gather_meshes=False, gather_batch=8,
                   dry_run=False, dry_fail=()):
     from avatarcap_amd import config, parallel
     cfg = config.cfg
@@ -179,22 +179,54 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
             return {'v': a['live_v'], 'vn': a['live_vn'], 'f': a['f']}
         return None
 
-    summary = parallel.run_sharded(frames, process, rank, world, log)
+    # --gather-meshes: the one collective of the throughput mode: every rank's finished avatar meshes, exchanged step by step
+    # WHILE the following frames compute (parallel.MeshExchange: exact sizes, asynchronous), in batches of `gather_batch` steps so that a long
+    # sequence does not pile every mesh of every rank up in HBM: after a batch rank 0 moves it to host memory and the device copies are dropped.
+    # A failed or unattempted frame travels as an empty mesh, so the ranks' steps stay aligned.
+    dev = None if dry_run else config.device
+    gathered = {}                                            # rank 0: frame -> {'v', 'vn', 'f'} numpy
+    gather = {'ex': None, 'step': 0}
+    steps = (len(frames) + world - 1) // world
+
+    def empty_mesh():
+        return {'v': torch.zeros((0, 3), device=dev), 'vn': torch.zeros((0, 3), device=dev), 'f': torch.zeros((0, 3), dtype=torch.int32, device=dev)}
+
+    def submit_step(mesh):
+        k = gather['step']
+        b0 = (k // gather_batch) * gather_batch               # first step of this batch
+        if gather['ex'] is None:
+            lo, hi = b0 * world, min(len(frames), (b0 + gather_batch) * world)
+            gather['ex'] = (parallel.MeshExchange(hi - lo, device=dev), lo, hi)
+        ex, lo, hi = gather['ex']
+        has_frame = k * world + rank < len(frames)
+        ex.submit((mesh or empty_mesh()) if has_frame else None)
+        gather['step'] = k + 1
+        if k + 1 == min(steps, b0 + gather_batch):            # the batch is complete: collect it, keep nothing on the device
+            for fr, m in zip(frames[lo:hi], ex.finish()):
+                if rank == 0:
+                    gathered[fr] = {key: m[key].cpu().numpy() for key in ('v', 'vn', 'f')}
+            gather['ex'] = None
+
+    def process_and_submit(k, fr, nxt):
+        mesh = None
+        try:
+            mesh = process(k, fr, nxt)
+            return mesh
+        finally:
+            if gather_meshes:
+                submit_step(mesh)
+
+    summary = parallel.run_sharded(frames, process_and_submit, rank, world, log)
+    if gather_meshes:
+        while gather['step'] < steps:                          # frames this rank never attempted (abort) or does not own (last, partial step)
+            submit_step(None)
+    summary['results'] = {}                                    # the meshes have been handed over: nothing of the batch stays on the device
     everyone = parallel.gather_summaries(summary)
     n_failed = sum(len(s_['failed']) for s_ in everyone)
-    if gather_meshes:
-        # the one collective of the throughput mode: every rank's finished avatar meshes, all-gathered once per batch.  A failed
-        # frame travels as an empty mesh, so the ranks' counts stay what shard_frames says they are.
-        dev = None if dry_run else config.device
-        empty = lambda: {'v': torch.zeros((0, 3), device=dev), 'vn': torch.zeros((0, 3), device=dev),                  # noqa: E731
-                         'f': torch.zeros((0, 3), dtype=torch.int32, device=dev)}
-        mine = [frames[k] for k in parallel.shard_frames(len(frames), rank, world)]
-        meshes = [summary['results'].get(fr) or empty() for fr in mine]
-        allm = parallel.all_gather_meshes(meshes, len(frames), device=dev)
-        if rank == 0:
-            np.savez(os.path.join(out_dir, 'all_avatar_meshes.npz'), frames=np.asarray(frames, np.int64),
-                     **{'%s_%04d' % (key, fr): m[key].cpu().numpy() for fr, m in zip(frames, allm) for key in ('v', 'vn', 'f')})
-            log('# gathered %d meshes (%d vertices) over %d rank(s)' % (len(allm), sum(int(m['v'].shape[0]) for m in allm), world))
+    if gather_meshes and rank == 0:
+        np.savez(os.path.join(out_dir, 'all_avatar_meshes.npz'), frames=np.asarray(frames, np.int64),
+                 **{'%s_%04d' % (key, fr): gathered[fr][key] for fr in frames for key in ('v', 'vn', 'f')})
+        log('# gathered %d meshes (%d vertices) over %d rank(s)' % (len(gathered), sum(int(m['v'].shape[0]) for m in gathered.values()), world))
     if rank == 0:
         log('# %d of %d frames done on %d rank(s)%s' % (sum(len(s_['done']) for s_ in everyone), len(frames), world,
             '' if not n_failed else '; FAILED: ' + ', '.join('%s (%s)' % (fr, why) for s_ in everyone for fr, why in s_['failed'])))
@@ -216,6 +248,10 @@ def main(argv=None):
     arg_parser.add_argument('--integrate', type=str, default='merge', choices=['merge', 'cover'], help='normal fusion manner (main.py:281)')
     arg_parser.add_argument('--gpus', type=int, default=0, help='shard the frames over this many GPUs of the node (one process each); 0: whatever launched us')
     arg_parser.add_argument('--gather-meshes', action='store_true', help='all-gather the live avatar meshes of the batch (RCCL) and write them on rank 0')
+    arg_parser.add_argument('--gather-batch', type=int, default=8, help='--gather-meshes: steps (frames per rank) exchanged and moved to the host at a time')
+    arg_parser.add_argument('--dist-timeout', type=float, default=180.0, help='seconds a rank may take to show up at the rendezvous')
+    arg_parser.add_argument('--collective-timeout', type=float, default=None,
+                            help='seconds a collective may wait for the slowest rank AFTER the rendezvous (default: 10 x --dist-timeout, at least 1800)')
     arg_parser.add_argument('--output-dir', type=str, default=None, help='overrides testing.output_dir of the yaml')
     arg_parser.add_argument('--dry-run', action='store_true', help='no GPU: stand-in meshes on gloo (launcher, sharding, error containment, gather)')
     arg_parser.add_argument('--dry-fail', type=int, nargs='*', default=[], help='--dry-run: frames whose processing raises')
@@ -240,11 +276,15 @@ def main(argv=None):
         torch.cuda.set_device(local_rank)
         config.device = torch.device('cuda', local_rank)
     if world > 1:
-        parallel.init_process_group('gloo' if args.dry_run else 'nccl', rank, world, None if args.dry_run else config.device)
+        parallel.init_process_group('gloo' if args.dry_run else 'nccl', rank, world, None if args.dry_run else config.device,
+                                    timeout_s=args.dist_timeout, collective_timeout_s=args.collective_timeout)
+        if not args.dry_run:
+            parallel.pin_to_gpu_numa(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)), log=print if rank == 0 else None)
     try:
         n_failed = run_avatarcap(w_recon=True, save_avatar_mesh=args.save_ply, save_final_mesh=args.save_ply, w_nerf=args.nerf,
                                  synthetic=args.synthetic, n_frames=args.frames, valid=args.valid, integrate_manner=args.integrate,
-                                 rank=rank, world=world, gather_meshes=args.gather_meshes, dry_run=args.dry_run, dry_fail=args.dry_fail)
+                                 rank=rank, world=world, gather_meshes=args.gather_meshes, gather_batch=max(1, args.gather_batch), dry_run=args.dry_run,
+                                 dry_fail=args.dry_fail)
     finally:
         if world > 1:
             import torch.distributed as dist

@@ -100,9 +100,12 @@ def test_lbs_at_full_vertex_count(frame, monkeypatch):
     assert torch.equal(out['live_v'], smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'])[0])
 
 
-def test_full_avatarcap_frame_at_256_band():
-    """BASELINE configs[2] at its full size: steps 1-3 chained on a band-masked 256^3 grid.  Sampled oracle parity of the
-    reconstruction decoder on the fused maps' image features, untouched fill values outside the band, a closed manifold mesh."""
+@pytest.mark.parametrize('res', [[256, 256, 256], [384, 384, 128]], ids=['256x256x256', 'example.yaml 384x384x128'])
+def test_full_avatarcap_frame_on_the_band(res):
+    """BASELINE configs[2] at its full size, and the reference's OWN configuration (configs/example.yaml:14-17: vol_res 384 x 384 x 128, only the
+    points within 0.1 m of the canonical SMPL evaluated, dataset/avatarcap_dataset.py:111-125): steps 1-3 chained on the band-masked grid.
+    Sampled oracle parity of BOTH volumes -- the avatar's occupancy on the pose feature map of this frame and the reconstruction decoder's on the
+    fused maps' image features --, untouched fill values outside the band, a manifold mesh that is open only where the body leaves the volume."""
     from avatarcap_amd.dataset import SyntheticTestDataset, to_cuda, synthetic_camera, synthetic_observed_normals
     from avatarcap_amd.network.arch_avatar import GeoTexAvatar
     from avatarcap_amd.network.arch_recon import ReconNetwork
@@ -110,9 +113,9 @@ def test_full_avatarcap_frame_at_256_band():
     from common import recon_sd
     from oracle import avatarcap_oracle as orc
     config.cfg = config.default_cfg()
-    config.cfg['testing']['vol_res'] = RES
+    config.cfg['testing']['vol_res'] = res
     config.device = torch.device('cuda')
-    ds = SyntheticTestDataset(RES, valid='band', n_frames=1)
+    ds = SyntheticTestDataset(res, valid='band', n_frames=1)
     net = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume()).to('cuda').eval()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in geotex_sd().items()})
     rn = ReconNetwork().to('cuda').eval()
@@ -120,30 +123,42 @@ def test_full_avatarcap_frame_at_256_band():
     pipe = FramePipeline(net, ds, rn)
     items = to_cuda(ds[0], add_batch=True)
     a = pipe.avatar_frame(items)
+    flag = ds.infer_pts_flag
+    assert 0.1 < float(flag.float().mean()) < 0.3
+    rs = np.random.RandomState(2)
+    sel = np.sort(rs.choice(ds.infer_pts.shape[0], 1500, replace=False))
+    selc = torch.from_numpy(sel).cuda()
+    pts = ds.infer_pts[selc].cpu().numpy()
+    # 1. the avatar's band volume (main.py:360-364): avatar_kernel<warp, geometry only, column-folded band> on this frame's pose feature map
+    assert torch.equal(a['occ_volume'][~flag], ds.invalid_pts_ov)                     # main.py:363
+    fmap = net.warping_field.pose_feat_map[0].cpu().numpy()
+    ref_a = orc.occupancy_query(pts, fmap, ds.cano_smpl_center, geotex_sd())['cano_pts_ov'][:, 0]
+    err_a = maxabs(a['occ_volume'][flag][selc].cpu().numpy(), ref_a)
     w2c, cam = synthetic_camera()
     obs = synthetic_observed_normals(a['live_v'], a['live_vn'], a['f'], w2c, cam, seed=3)
     items['front_normal'], items['back_normal'], _ = pipe.fuse_normals(a, obs, w2c, cam, 'merge', iter_num=100)
     r = pipe.recon_frame(items)
     vol = r['occ_volume']
-    flag = ds.infer_pts_flag
-    assert 0.1 < float(flag.float().mean()) < 0.3
     assert torch.equal(vol[~flag], ds.invalid_pts_ov)                                 # main.py:443
+    # 2. the reconstruction volume (main.py:440-443)
     with torch.no_grad():
         imap = rn.get_feat_maps(torch.cat([items['front_normal'], items['back_normal']], 1))[-1][0].cpu().numpy()
-    rs = np.random.RandomState(2)
-    sel = np.sort(rs.choice(ds.infer_pts.shape[0], 1500, replace=False))
-    ref = orc.recon_infer(ds.infer_pts[torch.from_numpy(sel).cuda()].cpu().numpy(), imap, ds.cano_smpl_center, recon_sd())
-    assert maxabs(vol[flag][torch.from_numpy(sel).cuda()].cpu().numpy(), ref) < 1e-4
-    v, f = r['cano_v'], r['f'].long()
-    assert v.shape[0] > 10000
-    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
-    key = torch.minimum(e[:, 0], e[:, 1]) * v.shape[0] + torch.maximum(e[:, 0], e[:, 1])
-    uniq, cnt = torch.unique(key, return_counts=True)
-    hist = {int(c): int((cnt == c).sum()) for c in torch.unique(cnt)}
-    assert int(cnt.max()) == 2, hist                                                  # manifold: no edge shared by 3+ faces
+    ref = orc.recon_infer(pts, imap, ds.cano_smpl_center, recon_sd())
+    err_r = maxabs(vol[flag][selc].cpu().numpy(), ref)
+    print(f'vol_res {res}: {int(flag.sum())} band points, avatar occupancy vs oracle {err_a:.2e}, reconstruction occupancy vs oracle {err_r:.2e}, '
+          f'{a["cano_v"].shape[0]} / {r["cano_v"].shape[0]} vertices')
+    assert err_a < 1e-4 and err_r < 1e-4
     b0, b1 = torch.from_numpy(ds.cano_bounds[0]).cuda(), torch.from_numpy(ds.cano_bounds[1]).cuda()
-    voxel = (b1 - b0) / 256
-    border = ((v - b0 < 1.01 * voxel) | (b1 - v < 1.01 * voxel)).any(1)
-    open_e = uniq[cnt == 1]
-    assert bool(border[open_e // v.shape[0]].all() and border[open_e % v.shape[0]].all()), hist   # open only where the body leaves the volume
-    assert r['live_v'].shape == v.shape and bool(torch.isfinite(r['live_v']).all())
+    voxel = (b1 - b0) / torch.tensor(res, dtype=torch.float32, device='cuda')
+    for mesh in (a, r):
+        v, f = mesh['cano_v'], mesh['f'].long()
+        assert v.shape[0] > 10000
+        e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        key = torch.minimum(e[:, 0], e[:, 1]) * v.shape[0] + torch.maximum(e[:, 0], e[:, 1])
+        uniq, cnt = torch.unique(key, return_counts=True)
+        hist = {int(c): int((cnt == c).sum()) for c in torch.unique(cnt)}
+        assert int(cnt.max()) == 2, hist                                              # manifold: no edge shared by 3+ faces
+        border = ((v - b0 < 1.01 * voxel) | (b1 - v < 1.01 * voxel)).any(1)
+        open_e = uniq[cnt == 1]
+        assert bool(border[open_e // v.shape[0]].all() and border[open_e % v.shape[0]].all()), hist   # open only where the body leaves the volume
+        assert mesh['live_v'].shape == v.shape and bool(torch.isfinite(mesh['live_v']).all())

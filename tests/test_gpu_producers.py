@@ -43,6 +43,31 @@ def test_unet7ds_on_miopen_matches_reference(golden):
         assert torch.equal(first, again), float((first - again).abs().max())  # first call == later calls, bit for bit
 
 
+def test_unet_graph_replay_equals_eager_launches():
+    """UnetNoCond7DS.forward replays a hipGraph (config.unet_graph): bit for bit the eager pass, fresh output tensors, a second input through the same
+    graph, new weights picked up; the module still deep-copies and pickles."""
+    import copy
+    import pickle
+    from avatarcap_amd.network.unets import UnetNoCond7DS
+    un = UnetNoCond7DS(input_nc=6, output_nc=64, nf=32).to('cuda').eval()
+    syn.load_synth(un, gi.SEED_NET)
+    a, b = _t(gi.pos_map(256, seed=77)[None]), _t(gi.pos_map(256, seed=78)[None])
+    with torch.no_grad():
+        config.unet_graph = False
+        try:
+            ea, eb = un(a).clone(), un(b).clone()
+        finally:
+            config.unet_graph = True
+        ga = un(a)
+        assert un.__dict__.get('_graph') is not None and un.__dict__.get('_graph_failed') is None       # captured, not fallen back
+        gb = un(b)
+        assert torch.equal(ga, ea) and torch.equal(gb, eb) and ga.data_ptr() != gb.data_ptr()
+        un2 = pickle.loads(pickle.dumps(copy.deepcopy(un)))
+        assert '_graph' not in un2.__dict__ and torch.equal(un2(a), ea)
+        syn.load_synth(un, gi.SEED_NET + 5)
+        assert not torch.equal(un(a), ea)
+
+
 def _hg():
     from avatarcap_amd.network.HGFilters import HGFilter
     hg = HGFilter(1, 4, 6, 32, 'group', 'no_down', False).to('cuda').eval()

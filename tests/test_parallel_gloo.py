@@ -155,7 +155,7 @@ def test_main_shards_frames_and_contains_a_failing_frame(tmp_path):
     env = dict(os.environ); env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
     ok = tmp_path / 'ok'
     r = subprocess.run([sys.executable, os.path.join(root, 'main.py'), '-m', 'test', '--dry-run', '--frames', '7', '--gpus', '2', '--gather-meshes',
-                        '--output-dir', str(ok)], capture_output=True, text=True, env=env, timeout=600)
+                        '--gather-batch', '2', '--output-dir', str(ok)], capture_output=True, text=True, env=env, timeout=600)       # 4 steps in batches of 2
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert sorted(p.name for p in ok.glob('*_mesh.npz')) == ['%04d_mesh.npz' % f for f in range(7)]
     lines = r.stdout.splitlines()
@@ -196,3 +196,90 @@ def test_run_sharded_and_bounded_rendezvous():
             "parallel.init_process_group('gloo', 0, 2, timeout_s=3.0)" % root)                # rank 1 never comes
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and 'rendezvous of 2 ranks' in r.stderr and 'failed within 3 s' in r.stderr
+
+
+def _exchange_worker(rank, world, port, n_frames, q):
+    """The overlapped, exact-size exchange as bench.py / main.py drive it: one submit() per step, work between the steps, finish() at the end."""
+    from avatarcap_amd.parallel import MeshExchange
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ex = MeshExchange(n_frames)
+        for k in range(ex.steps):
+            f = k * world + rank
+            ex.submit(_mesh(f) if f < n_frames else None)
+            torch.randn(64, 64) @ torch.randn(64, 64)                 # "the next frame" between two steps
+        out = ex.finish()
+        ok = len(out) == n_frames
+        for f, m in enumerate(out):
+            ref = _mesh(f)
+            ok = ok and all(torch.equal(m[key], ref[key]) and m[key].dtype == ref[key].dtype for key in ('v', 'vn', 'f'))
+        # exact sizes: what this rank received is the other ranks' meshes, word for word -- no padding to the largest
+        want = sum(4 * (6 * _mesh(f)['v'].shape[0] + 3 * _mesh(f)['f'].shape[0]) for f in range(n_frames) if f % world != rank)
+        q.put((rank, bool(ok), ex.bytes_received == want))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_frames', [(2, 7), (4, 10), (4, 3), (2, 1)])
+def test_mesh_exchange_overlapped_exact_size(world, n_frames):
+    """MeshExchange on gloo, world 2 and 4: frames that do not fill the last step (a rank submits None), fewer frames than ranks, meshes of different
+    sizes (incl. F == 0): every rank ends with every mesh, bit for bit, and has received exactly the bytes of the others' meshes."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True, True) for r in range(world)]
+
+
+def test_mesh_exchange_validates_its_steps():
+    from avatarcap_amd.parallel import MeshExchange
+    ex = MeshExchange(2)                                               # no process group: one rank, nothing travels
+    with pytest.raises(ValueError, match='is missing'):
+        ex.submit(None)
+    ex = MeshExchange(2)
+    ex.submit(_mesh(0))
+    with pytest.raises(ValueError, match='1 of 2 steps'):
+        ex.finish()
+    ex.submit(_mesh(1))
+    out = ex.finish()
+    assert torch.equal(out[1]['v'], _mesh(1)['v'])
+    with pytest.raises(ValueError, match='submit\\(\\) called again'):
+        ex.submit(_mesh(2))
+
+
+def test_run_sharded_stops_on_fatal_errors_and_failure_streaks():
+    """A HIP fault or an out-of-memory error is sticky: the remaining frames are reported as failed WITHOUT being tried (each would fail the same way, with
+    a traceback each); so are the frames behind three failures in a row.  A single bad frame is still contained."""
+    from avatarcap_amd.parallel import run_sharded, _parse_cpulist, pin_to_gpu_numa
+    tried = []
+
+    def oom(k, fr, nxt):
+        tried.append(fr)
+        if fr == 2:
+            raise torch.cuda.OutOfMemoryError('HIP out of memory')
+        return fr
+    s = run_sharded(list(range(6)), oom, log=lambda m: None)
+    assert tried == [0, 1, 2] and s['done'] == [0, 1] and [f for f, _ in s['failed']] == [2, 3, 4, 5] and 'fatal device error' in s['aborted']
+    assert s['failed'][1][1].startswith('not attempted')
+    tried.clear()
+
+    def flaky(k, fr, nxt):
+        tried.append(fr)
+        if fr in (1, 3, 4, 5):
+            raise ValueError('bad frame')
+        return fr
+    s = run_sharded(list(range(8)), flaky, log=lambda m: None)
+    assert tried == [0, 1, 2, 3, 4, 5] and s['done'] == [0, 2] and '3 frames in a row' in s['aborted'] and len(s['failed']) == 6
+    tried.clear()
+    s = run_sharded(list(range(4)), lambda k, fr, nxt: (_ for _ in ()).throw(RuntimeError('libavcap_hip: hipLaunch failed: HIP error (status -3)')), log=lambda m: None)
+    assert len(s['done']) == 0 and s['failed'][1][1].startswith('not attempted')
+    assert _parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11] and _parse_cpulist('') == []
+    assert pin_to_gpu_numa(0) == {} or 'numa_node' in pin_to_gpu_numa(0)         # no GPU / no sysfs topology: a no-op, never an error
