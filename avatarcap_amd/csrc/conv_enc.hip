@@ -95,6 +95,7 @@ struct ConvArgs {
     int ksplit;                  // workgroups per (tile, slice): each walks Cin / 32 / ksplit chunks of K (1: no split)
     float *kpart;                // split-K: [tile x slice][ksplit][accumulator registers][256 threads] raw sums
     unsigned *kcounter;          // split-K: one ticket per (tile, slice)
+    unsigned *range_flag;        // set to 1 when a staged value exceeds the fp16 range of the split (avc_set_range_check reads it)
 };
 
 __device__ __forceinline__ float relu_bits(float x)
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         xrs[2] = p.H * p.W * p.Cin * 4; xrs[3] = 0x00027000;
     }
     f32x4 stage[NPIECE];
+    float amax = 0.0f;                                     // largest magnitude that went through the fp16 split
     auto load_acts = [&](int c) {
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) stage[i] = raw_buffer_load_f32x4(xrs, goff[i], c * 128, 0);
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
             float v0 = ab0[0] * stage[i][0] + ab0[1], v1 = ab0[2] * stage[i][1] + ab0[3];
             float v2 = ab1[0] * stage[i][2] + ab1[1], v3 = ab1[2] * stage[i][3] + ab1[3];
             if constexpr (NORM) { v0 = relu_bits(v0); v1 = relu_bits(v1); v2 = relu_bits(v2); v3 = relu_bits(v3); }
+            amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)), __builtin_fmaxf(__builtin_fabsf(v2), __builtin_fabsf(v3))));
             unsigned h01, l01, h23, l23;
             split2(v0, v1, h01, l01);
             split2(v2, v3, h23, l23);
@@ -418,6 +421,9 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
             asm volatile("" ::: "memory");
         });
     }
+
+    // a staged value beyond 65504 became +-inf in its `hi` half: the launch's output is not to be trusted (avc_set_range_check reports it)
+    if (!(amax <= 65504.0f) && p.range_flag) atomicOr(p.range_flag, 1u);
 
     // ---- split-K: every k slice leaves its raw accumulators in HBM; the last one to arrive (ticket) adds all of them in slice order -- its
     // own included, re-read, so that the sum does not depend on who is last -- and goes on to the epilogue.  Device-scope accesses, no fences
@@ -817,6 +823,7 @@ struct Encoder {
     std::vector<Launch> plan;
     std::vector<void *> plan_allocs;
     float *in_buf = nullptr;
+    unsigned *range_flag = nullptr;
     Tensor out, normx;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr, side_stream = nullptr;
@@ -831,7 +838,7 @@ static void free_plan(Encoder *e)
     for (void *p : e->plan_allocs) hipFree(p);
     for (hipEvent_t ev : e->events) hipEventDestroy(ev);
     e->events.clear();
-    e->plan_allocs.clear(); e->plan.clear(); e->Hin = e->Win = 0; e->in_buf = nullptr;
+    e->plan_allocs.clear(); e->plan.clear(); e->Hin = e->Win = 0; e->in_buf = nullptr; e->range_flag = nullptr;
 }
 static void free_weights(Encoder *e)
 {
@@ -1092,6 +1099,7 @@ struct Planner {
         if (y) a.st_y = stat(*y, ycoff, w.cout, ntiles, slices, &a.counter);
         // few workgroups, each streaming its whole K serially, are bound by the latency of their weight stream: split K over more of them
         const int wg = ntiles * (w.cout / (32 * L.CT)), nchunk = x.C / 32;
+        a.range_flag = e->range_flag;
         a.ksplit = 1;
         if (ctx->opt.enc_ksplit)
             while (a.ksplit < nchunk && a.ksplit < 8 && 2 * wg * a.ksplit <= ctx->num_cus) a.ksplit *= 2;
@@ -1230,6 +1238,7 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
     P.fork = ctx->opt.enc_fork != 0;
     if (P.fork && !e->side_stream) AVC_HIP(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
     e->in_buf = static_cast<float *>(P.alloc(sizeof(float) * 6 * (size_t)Hin * Win));
+    e->range_flag = static_cast<unsigned *>(P.alloc(sizeof(unsigned), true));
     // conv1 (space-to-depth, then 4x4 taps on the matrix pipe) + statistics of bn1
     Tensor sd = P.tensor(H1, W1, 32), t0 = P.tensor(H1, W1, 64);
     if (!P.rc) {
@@ -1282,8 +1291,16 @@ int encoder_forward(avc_ctx *ctx, const float *image, int H, int W, float *feat_
         if (int rc = build_plan(ctx, e, H, W)) return rc;
     }
     AVC_HIP(hipMemcpyAsync(e->in_buf, image, sizeof(float) * 6 * (size_t)H * W, hipMemcpyDeviceToDevice, s));
+    if (ctx->check_range) AVC_HIP(hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), s));
     if (e->exec) AVC_HIP(hipGraphLaunch(e->exec, s));
     else if (int rc = run_plan(e, s)) return rc;
+    if (ctx->check_range) {                                // avc_set_range_check: synchronous, like the queries'
+        unsigned flag = 0;
+        AVC_HIP(hipMemcpyAsync(&flag, e->range_flag, sizeof flag, hipMemcpyDeviceToHost, s));
+        AVC_HIP(hipStreamSynchronize(s));
+        AVC_REQUIRE(flag == 0, AVC_ERR_RANGE, "avc_hgfilter_forward: a normalised activation exceeded 65504 / 16 in magnitude (or a raw one 65504) -- outside the "
+                    "range of the split-fp16 arithmetic (include/avcap.h, 'numeric range'); the feature map of this call is not valid");
+    }
     const Tensor &o = e->out;
     const int HW = o.H * o.W;
     if (feat_out) hipLaunchKernelGGL(hwc_to_nchw_kernel, dim3((HW + 63) / 64, (o.C + 63) / 64), dim3(256), 0, s, o.data, feat_out, o.C, HW);

@@ -85,6 +85,7 @@ class HGFilter(nn.Module):
             _lib.check(_lib.lib().avc_hgfilter_pack(ctx, w.struct))
             self._packed = ver
             _lib.set_owner(ctx, 'hgfilter', ver)
+        _lib.apply_range_check(ctx)
         return ctx
 
     def encode(self, x, want_feat=True, want_normx=False, bind=False):

@@ -273,6 +273,8 @@ def _fatal(e: BaseException) -> bool:
     if isinstance(e, (MemoryError, torch.cuda.OutOfMemoryError)):
         return True
     msg = str(e)
+    if getattr(e, 'status', None) == -5 or '(status -5)' in msg:       # AVC_ERR_RANGE: these WEIGHTS leave the range of the split-fp16 arithmetic -- every frame would
+        return True
     return 'HIP error' in msg or 'hipError' in msg or 'AVC_ERR_HIP' in msg or '(status -3)' in msg
 
 
@@ -302,7 +304,8 @@ def run_sharded(frames: list, process, rank: int = 0, world: int = 1, log=print,
             log(''.join(traceback.format_exception(type(e), e, e.__traceback__)).rstrip())
             streak += 1
             if _fatal(e):
-                aborted = f'frame {fr} hit a fatal device error ({type(e).__name__})'
+                aborted = (f'frame {fr}: AVC_ERR_RANGE -- the checkpoint drives a feature or activation out of the fp16 range of the fused kernels'
+                           if getattr(e, 'status', None) == -5 or '(status -5)' in str(e) else f'frame {fr} hit a fatal device error ({type(e).__name__})')
             elif streak >= max_consecutive_failures:
                 aborted = f'{streak} frames in a row failed'
             if aborted:

@@ -163,7 +163,11 @@ int avc_avatar_query_grid_subset(avc_ctx *ctx, const float *axis_x_dev, const fl
  * |value| <= 65504 (Softplus layers carry y / ln 2).  The reference's float32 path has no such bound (network/mlp.py:90-110).
  * avc_set_range_check(ctx, 1) switches the queries of this context to a build of the kernels that tracks the largest
  * magnitude entering a split; a query then synchronises its stream and returns AVC_ERR_RANGE when the bound was exceeded
- * (its outputs are not valid).  Off by default: the check costs one VALU instruction per value pair and the synchronisation. */
+ * (its outputs are not valid).  Off by default: the check costs one VALU instruction per value pair and the synchronisation.
+ * The image encoder (avc_hgfilter_forward) uses the same arithmetic: its kernels always track the largest staged value -- normalised
+ * activations are staged times 16, so the bound is 4094 there, 65504 for the one raw input (conv_last0's) -- and with the check on the
+ * call synchronises and returns AVC_ERR_RANGE likewise.
+ * `main.py -m test` on checkpoints read from disk runs the first frame of every rank with the check on; a trip ends the run. */
 int avc_set_range_check(avc_ctx *ctx, int enabled);
 
 /* DoubleTNet.forward alone on given points (pts_space == 'temp', arch_avatar.py:216-219) */

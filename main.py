@@ -128,7 +128,15 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
             loaded[i] = load(i)
         return loaded[i]
 
+    # Weights read from disk have never been through the kernels: the split-fp16 arithmetic of the fused queries is exact only while every feature
+    # and activation stays below 65504 (include/avcap.h, "numeric range"), and an overflow is SILENT (a ReLU swallows the NaN).  The first frame
+    # of every rank therefore runs with the range check on (avc_set_range_check: the checked flavour of the kernels, one synchronisation per
+    # query); a trip is fatal for the whole run (parallel.run_sharded: AVC_ERR_RANGE).  Synthetic weights are generated inside the range.
+    check_first = not (synthetic or dry_run)
+
     def process(k, i, nxt_i):
+        if check_first:
+            config.check_range = (k == 0)
         items = items_of(i)
         nxt = None
         if nxt_i is not None:

@@ -31,7 +31,11 @@ class MesaRenderer:
     """The methods render_cano_mesh / canonicalize_normal_map call on a Renderer (utils/renderer.py:389-451)."""
 
     def __init__(self, img_w, img_h, shader_name='vertex_attribute'):
-        self.img_w, self.img_h, self.shader = img_w, img_h, {'vertex_attribute': 0, 'position': 1}[shader_name]
+        # the GLSL sources are the reference's own, read from its module at run time (utils/renderer.py:10-60, selected as :337-343 does)
+        from utils import renderer as ref_renderer
+        self.img_w, self.img_h = img_w, img_h
+        self.vs = getattr(ref_renderer, 'vs_' + shader_name).strip().encode()
+        self.fs = getattr(ref_renderer, 'fs_' + shader_name).strip().encode()
 
     def set_model(self, vertices, vertex_attributes=None, vertex_attributes_2=None):
         self.v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
@@ -46,7 +50,8 @@ class MesaRenderer:
     def render(self):
         td = tempfile.mkdtemp()
         with open(td + '/in.bin', 'wb') as f:
-            f.write(struct.pack('<4i', self.img_w, self.img_h, self.v.shape[0], self.shader) + self.mvp.tobytes() + self.v.tobytes() + self.a.tobytes())
+            f.write(struct.pack('<5i', self.img_w, self.img_h, self.v.shape[0], len(self.vs), len(self.fs)) + self.mvp.tobytes() + self.v.tobytes() + self.a.tobytes()
+                    + self.vs + self.fs)
         r = subprocess.run([BIN, td + '/in.bin', td + '/out.bin'], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         self.gl_info = r.stderr.strip()

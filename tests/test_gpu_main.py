@@ -65,3 +65,42 @@ def test_main_test_mode_on_a_sequence_directory(tmp_path):
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '-c', str(tmp_path / 'cfg.yaml'), '-m', 'test'],
                         capture_output=True, text=True, env=dict(os.environ, AVC_SMPL_DIR=str(tmp_path / 'nowhere')), timeout=600, cwd=ROOT)
     assert r2.returncode != 0 and 'FileNotFoundError' in r2.stderr
+
+
+def test_main_refuses_a_checkpoint_that_leaves_the_fp16_range(tmp_path):
+    """Weights read from disk have never been through the kernels: `main.py -m test` runs the first frame of every rank with the range
+    check on, and a net.pt whose activations overflow the split-fp16 arithmetic ends the run non-zero with AVC_ERR_RANGE instead of writing meshes
+    of silently wrong values (a ReLU would have swallowed the NaN)."""
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar
+    from avatarcap_amd.network.arch_recon import ReconNetwork
+    data, train, out = tmp_path / 'testing', tmp_path / 'training', tmp_path / 'out'
+    smpl_dir = tmp_path / 'smpl_files'
+    for d in (data, train, smpl_dir):
+        os.makedirs(d)
+    sq.write_smpl_file(str(smpl_dir / 'basicmodel_M_lbs_10_207_0_v1.0.0.pkl'))
+    ids = sq.build_sequence(str(data), lambda p, img: _write_exr(p, img[..., ::-1].copy(), 'RGB', 2, 3), n_frames=3, start=0, data_type='real',
+                            pos_map_res=256, pos_map_src=(192, 384))
+    os.makedirs(data / 'imgs' / 'normal')
+    for idx in ids:
+        nm = syn.smooth_normal_maps(40 + idx, 512)[:3].transpose(1, 2, 0)
+        _write_exr(str(data / 'imgs' / 'normal' / ('normal_%04d.exr' % idx)), np.ascontiguousarray(nm[..., ::-1]), 'RGB', 1, 3)
+    np.save(str(train / 'cano_base_blend_weight_volume.npy'), np.full((4, 4, 4, 24), 1 / 24, np.float32))
+    config.cfg = config.default_cfg()
+    config.cfg['training']['training_data_dir'] = str(train)
+    for name, m, fn in (('avatar', GeoTexAvatar(), 'net.pt'), ('recon', ReconNetwork(), 'recon_net.pt')):
+        os.makedirs(tmp_path / name)
+        sd = syn.synth_state_dict(syn.module_shapes(m), syn.SEED)
+        if name == 'avatar':                                                  # a hidden layer of the template 3000 x too large: its activations pass 65504
+            sd['cano_template.shared_mlp.fc_list.2.0.weight'] = sd['cano_template.shared_mlp.fc_list.2.0.weight'] * 3000.0
+        torch.save({'network': {k: torch.from_numpy(v) for k, v in sd.items()}}, str(tmp_path / name / fn))
+    cfg = {'training': {'training_data_dir': str(train)},
+           'testing': {'vol_res': [40, 96, 36], 'recon_net_ckpt': str(tmp_path / 'recon'), 'net_ckpt': str(tmp_path / 'avatar'),
+                       'net_ckpt_finetuned': None, 'testing_data_dir': str(data), 'output_dir': str(out)},
+           'model': {'cano_template': {'pos_encoding': 10}, 'warping_field': {'pos_encoding': 0}}}
+    with open(tmp_path / 'cfg.yaml', 'w') as fh:
+        yaml.safe_dump(cfg, fh)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '-c', str(tmp_path / 'cfg.yaml'), '-m', 'test'],
+                       capture_output=True, text=True, env=dict(os.environ, AVC_SMPL_DIR=str(smpl_dir)), timeout=900, cwd=ROOT)
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert 'AVC_ERR_RANGE' in r.stdout and 'status -5' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert 'not attempted' in r.stdout and not list(out.glob('*_mesh.npz'))       # nothing was written; frames 1, 2 were not run on weights known to be bad

@@ -197,3 +197,22 @@ def test_recon_infer_end_to_end_at_512(golden):
         assert e < 1e-4
 
 
+
+
+def test_hgfilter_range_check_trips():
+    """config.check_range (avc_set_range_check): an encoder whose normalised activations leave the fp16 range of the split (a GroupNorm gain of 1e5: the
+    staged value is 16 x the activation) returns AVC_ERR_RANGE instead of a feature map of infs the decoder would turn into plausible occupancies."""
+    from avatarcap_amd import _lib
+    hg = _hg()
+    x = _t(gi.normal_maps(64)[None])
+    config.check_range = True
+    try:
+        with torch.no_grad():
+            hg(x)                                                             # in range: no error
+            hg.conv3.bn2.weight.mul_(1e5)
+            with pytest.raises(_lib.AvcapError) as ei:
+                hg(x)
+        assert ei.value.status == _lib.AVC_ERR_RANGE
+    finally:
+        config.check_range = False
+        _lib.apply_range_check(_lib.ctx(x.device))

@@ -6,7 +6,9 @@
  * implementation, which is what pins oracle/raster_oracle.c.
  *
  *   mesa_raster <in.bin> <out.bin>
- *   in : int32 W, H, nverts, shader (0 = vertex_attribute, 1 = position); float mvp[16] (row-major); float vertices[nverts*3]; float attrs[nverts*3]
+ *   in : int32 W, H, nverts, vs_len, fs_len; float mvp[16] (row-major); float vertices[nverts*3]; float attrs[nverts*3]; then the GLSL sources of the
+ *        vertex and the fragment shader (vs_len, fs_len bytes) -- the caller reads them from the reference's utils/renderer.py at run time
+ *        (tests/golden/make_golden_gl.py); no shader text lives in this file
  *   out: float RGBA[H*W*4], rows as glReadPixels returns them (row 0 = bottom)
  * gcc -O1 mesa_raster.c -o mesa_raster -ldl      (needs mesa-common-dev's GL/internal/dri_interface.h and libgl1-mesa-dri) */
 #include <GL/gl.h>
@@ -28,26 +30,19 @@ static const __DRIextension *loader_exts[] = {&swrast_loader.base, NULL};
 static void *(*get_proc)(const char *);
 #define GLF(ret, name, ...) ret (*p_##name)(__VA_ARGS__) = (ret (*)(__VA_ARGS__))get_proc(#name); if (!p_##name) { fprintf(stderr, "no %s\n", #name); return 3; }
 
-static const char *VS[2] = {
-    "#version 330 core\nuniform mat4 mvp;\nlayout (location = 0) in vec3 vertices;\nlayout (location = 1) in vec3 attributes;\nout vec4 vertex_attributes;\n"
-    "void main(){ gl_Position = mvp * vec4(vertices, 1.f); vertex_attributes = vec4(attributes, 1.f); }\n",
-    "#version 330 core\nuniform mat4 mvp;\nlayout (location = 0) in vec3 vertices;\nout vec4 positions;\n"
-    "void main(){ gl_Position = mvp * vec4(vertices, 1.f); positions = vec4(vertices, 1.f); }\n"};
-static const char *FS[2] = {
-    "#version 330 core\nin vec4 vertex_attributes;\nout vec4 frag_color;\nvoid main(){ frag_color = vertex_attributes; }\n",
-    "#version 330 core\nin vec4 positions;\nout vec4 frag_color;\nvoid main(){ frag_color = positions; }\n"};
-
 int main(int argc, char **argv)
 {
     if (argc < 3) { fprintf(stderr, "usage: mesa_raster in.bin out.bin\n"); return 1; }
     FILE *fi = fopen(argv[1], "rb");
     if (!fi) { perror(argv[1]); return 1; }
-    int32_t hdr[4];
+    int32_t hdr[5];
     float mvp[16];
-    if (fread(hdr, 4, 4, fi) != 4 || fread(mvp, 4, 16, fi) != 16) return 1;
-    const int W = hdr[0], H = hdr[1], nv = hdr[2], sh = hdr[3];
+    if (fread(hdr, 4, 5, fi) != 5 || fread(mvp, 4, 16, fi) != 16) return 1;
+    const int W = hdr[0], H = hdr[1], nv = hdr[2], vs_len = hdr[3], fs_len = hdr[4];
     float *verts = malloc(sizeof(float) * 3 * nv), *attrs = malloc(sizeof(float) * 3 * nv);
     if (fread(verts, 4, 3 * (size_t)nv, fi) != 3 * (size_t)nv || fread(attrs, 4, 3 * (size_t)nv, fi) != 3 * (size_t)nv) return 1;
+    char *vs_src = calloc(vs_len + 1, 1), *fs_src = calloc(fs_len + 1, 1);
+    if (fread(vs_src, 1, vs_len, fi) != (size_t)vs_len || fread(fs_src, 1, fs_len, fi) != (size_t)fs_len) return 1;
     fclose(fi);
 
     setenv("LIBGL_ALWAYS_SOFTWARE", "1", 0);
@@ -103,8 +98,9 @@ int main(int argc, char **argv)
 
     /* Renderer.__init__ (renderer.py:337-387) */
     GLuint vs = p_glCreateShader(GL_VERTEX_SHADER), fs = p_glCreateShader(GL_FRAGMENT_SHADER);
-    p_glShaderSource(vs, 1, &VS[sh], NULL); p_glCompileShader(vs);
-    p_glShaderSource(fs, 1, &FS[sh], NULL); p_glCompileShader(fs);
+    const char *vsp = vs_src, *fsp = fs_src;
+    p_glShaderSource(vs, 1, &vsp, NULL); p_glCompileShader(vs);
+    p_glShaderSource(fs, 1, &fsp, NULL); p_glCompileShader(fs);
     GLint ok = 0;
     p_glGetShaderiv(vs, GL_COMPILE_STATUS, &ok);
     if (!ok) { char log[2048]; p_glGetShaderInfoLog(vs, 2048, NULL, log); fprintf(stderr, "vs: %s\n", log); return 4; }

@@ -113,7 +113,7 @@ int main(int argc, char **argv)
         const int ntiles = a.tiles_x * a.tiles_y, wg = ntiles * (Cout / (32 * CT));
         if (stats >= 1) a.st_raw = make_stat(Cout, 0, Cout, ntiles, Cout / (32 * CT), &a.counter);
         if (stats >= 2) a.st_y = make_stat(yC, 0, Cout, ntiles, Cout / (32 * CT), &a.counter);
-        a.ksplit = ksplit;
+        a.ksplit = ksplit; a.range_flag = nullptr;
         if (ksplit > 1) {
             a.kpart = dev_zero((size_t)wg * ksplit * 256 * PT * CT * 16);
             CK(hipMalloc(&a.kcounter, sizeof(unsigned) * wg)); CK(hipMemset(a.kcounter, 0, sizeof(unsigned) * wg));
