@@ -89,6 +89,7 @@ struct avc_ctx {
     int fusion_graph_H = 0, fusion_graph_W = 0, fusion_graph_iters = 0;
     void *encoder = nullptr;                                       // enc::Encoder: packed HGFilter weights + the launch plan of the last input size (conv_enc.hip)
     void *gn_scratch = nullptr; size_t gn_scratch_bytes = 0;       // GroupNorm slice sums
+    std::vector<void *> retired_scratch;                           // outgrown blocks that a captured graph may still name: freed with the context
     void *scatter_scratch = nullptr; size_t scatter_scratch_bytes = 0;   // block counts of avc_scatter_volume
     void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
     void *col_scratch = nullptr; size_t col_scratch_bytes = 0;     // per-column terms of a column-folded dense query (512 floats per column)

@@ -58,6 +58,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->col_scratch) hipFree(ctx->col_scratch);
     if (ctx->rcol_scratch) hipFree(ctx->rcol_scratch);
     if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
+    for (void *p : ctx->retired_scratch) hipFree(p);
     enc::release_encoder(ctx);
     release_fusion_graph(ctx);
     if (ctx->fusion_scratch) hipFree(ctx->fusion_scratch);

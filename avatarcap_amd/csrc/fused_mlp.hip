@@ -1570,6 +1570,26 @@ static int set_lds(K kernel)
     return AVC_OK;
 }
 
+// every kernel of this flavour gets its dynamic-LDS attribute once, BEFORE a launch function starts its timing events: a failure then returns without
+// leaking them
+static int set_all_lds()
+{
+    static bool done = false;
+    if (done) return AVC_OK;
+    if (int rc = set_lds(avatar_kernel<false, true, 0>)) return rc;
+    if (int rc = set_lds(avatar_kernel<false, false, 0>)) return rc;
+    if (int rc = set_lds(avatar_kernel<true, true, 0>)) return rc;
+    if (int rc = set_lds(avatar_kernel<true, false, 0>)) return rc;
+#if !AVC_CHECK_RANGE
+    if (int rc = set_lds(avatar_kernel<true, false, 1>)) return rc;
+    if (int rc = set_lds(avatar_kernel<true, false, 2>)) return rc;
+    if (int rc = set_lds(recon_fold_kernel<1>)) return rc;
+#endif
+    if (int rc = set_lds(recon_kernel)) return rc;
+    done = true;
+    return AVC_OK;
+}
+
 static unsigned bytes_until(const PackedNet &net, size_t nchunks)
 {
     unsigned b = 0;
@@ -1648,13 +1668,14 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
     if (fold) {
         const size_t ncol = (size_t)grid->res[0] * grid->res[1], bytes = (ncol * 512 + 64) * sizeof(float);
         if (ctx->col_scratch_bytes < bytes) {
-            if (ctx->col_scratch) AVC_HIP(hipFree(ctx->col_scratch));
+            if (ctx->col_scratch) { AVC_HIP(hipDeviceSynchronize()); AVC_HIP(hipFree(ctx->col_scratch)); }        // an earlier launch (any stream) may still read it
             ctx->col_scratch = nullptr; ctx->col_scratch_bytes = 0;
             AVC_HIP(hipMalloc(&ctx->col_scratch, bytes));
             ctx->col_scratch_bytes = bytes;
         }
         p.colterms = static_cast<const float *>(ctx->col_scratch);
     }
+    if (int rc0 = set_all_lds()) return rc0;
     hipEvent_t e0, e1;
     timing_begin(ctx, 0, s, e0, e1, p);        // (a folded launch is timed with its column pass)
 #define LAUNCH(W_, C_, F_)                                                                              \
@@ -1708,13 +1729,14 @@ int launch_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n
         const size_t ncol = (size_t)grid->res[0] * grid->res[1], bytes = (ncol * RCOL + 64) * sizeof(float);
         AVC_REQUIRE(ncol * RCOL * sizeof(float) < ((size_t)1 << 32) - 4096, AVC_ERR_ARG, "recon query: %zu columns exceed the 4 GiB column table of a folded launch", ncol);
         if (ctx->rcol_scratch_bytes < bytes) {
-            if (ctx->rcol_scratch) AVC_HIP(hipFree(ctx->rcol_scratch));
+            if (ctx->rcol_scratch) { AVC_HIP(hipDeviceSynchronize()); AVC_HIP(hipFree(ctx->rcol_scratch)); }      // an earlier launch (any stream) may still read it
             ctx->rcol_scratch = nullptr; ctx->rcol_scratch_bytes = 0;
             AVC_HIP(hipMalloc(&ctx->rcol_scratch, bytes));
             ctx->rcol_scratch_bytes = bytes;
         }
         p.colterms = static_cast<const float *>(ctx->rcol_scratch);
     }
+    if (int rc0 = set_all_lds()) return rc0;
     hipEvent_t e0, e1;
     timing_begin(ctx, 1, s, e0, e1, p);        // (a folded launch is timed with its column pass)
 #if !AVC_CHECK_RANGE

@@ -187,7 +187,9 @@ int launch_group_norm(avc_ctx *ctx, const float *x, int N, int C, int64_t HW, in
     const int S = (int)std::max<int64_t>(1, std::min<int64_t>(GN_MAX_SPLIT, std::min<int64_t>(2048 / ((int64_t)N * G) + 1, L / 4096 + 1)));
     const size_t bytes = sizeof(double) * 2 * (size_t)N * G * S;
     if (ctx->gn_scratch_bytes < bytes) {
-        if (ctx->gn_scratch) AVC_HIP(hipFree(ctx->gn_scratch));
+        // never freed while the context lives: a caller may have captured launches that carry the old pointer into a hipGraph;
+        // outgrown blocks are parked and released by avc_ctx_destroy
+        if (ctx->gn_scratch) ctx->retired_scratch.push_back(ctx->gn_scratch);
         ctx->gn_scratch = nullptr; ctx->gn_scratch_bytes = 0;
         AVC_HIP(hipMalloc(&ctx->gn_scratch, bytes));
         ctx->gn_scratch_bytes = bytes;

@@ -340,7 +340,8 @@ def main():
             # the HBM-bound kernels of the same frame, timed on its own volume and mesh (algorithmic bytes of SURVEY.md 8(d) / time / 8 TB/s)
             try:
                 from avatarcap_amd import config as cfg_
-                from avatarcap_amd.utils import recon_util, smpl_util
+                from avatarcap_amd.utils import recon_util
+                from avatarcap_amd.utils.smpl_util import smpl_util
                 vol, V, Fc = out['occ_volume'], int(out['cano_v'].shape[0]), int(out['f'].shape[0])
 
                 def timed(fn, reps=5):

@@ -13,7 +13,10 @@
  *     thread-local description of the last failure.
  *   - `stream` is a hipStream_t (NULL = default stream).  Calls are asynchronous w.r.t. the host
  *     unless stated otherwise.  No ownership is transferred.  One context per device; a context
- *     is thread-compatible (use it from one thread at a time).
+ *     is thread-compatible (use it from one thread at a time) and serves ONE stream at a time: its
+ *     bound feature maps, per-column tables and mesh scratch are shared by the calls made on it,
+ *     so two queries of one context must not overlap on different streams (use one context per
+ *     concurrent stream, or order the streams with events).
  *   - all arithmetic is float32 in / float32 out; indices are int32 (faces) / int64 (KNN).
  */
 #ifndef AVCAP_H

@@ -90,8 +90,8 @@ def test_main_refuses_a_checkpoint_that_leaves_the_fp16_range(tmp_path):
     for name, m, fn in (('avatar', GeoTexAvatar(), 'net.pt'), ('recon', ReconNetwork(), 'recon_net.pt')):
         os.makedirs(tmp_path / name)
         sd = syn.synth_state_dict(syn.module_shapes(m), syn.SEED)
-        if name == 'avatar':                                                  # a hidden layer of the template 3000 x too large: its activations pass 65504
-            sd['cano_template.shared_mlp.fc_list.2.0.weight'] = sd['cano_template.shared_mlp.fc_list.2.0.weight'] * 3000.0
+        if name == 'avatar':                                                  # a hidden layer of the template 1e5 x too large (weights ~1.5e4: the packer takes them): its activations pass 65504
+            sd['cano_template.shared_mlp.fc_list.2.0.weight'] = sd['cano_template.shared_mlp.fc_list.2.0.weight'] * 1.0e5
         torch.save({'network': {k: torch.from_numpy(v) for k, v in sd.items()}}, str(tmp_path / name / fn))
     cfg = {'training': {'training_data_dir': str(train)},
            'testing': {'vol_res': [40, 96, 36], 'recon_net_ckpt': str(tmp_path / 'recon'), 'net_ckpt': str(tmp_path / 'avatar'),
