@@ -482,35 +482,63 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
     float sr[CT], qr[CT], sy[CT], qy[CT];
 #pragma unroll
     for (int m = 0; m < CT; ++m) sr[m] = qr[m] = sy[m] = qy[m] = 0.0f;
-    auto emit = [&](auto masked) {
-        constexpr bool MASK = decltype(masked)::value;
+    // per output tile m: first ALL residual values of the tile (one batch of loads in flight -- written element by element the compiler
+    // serialises every load behind the previous store: it cannot know that res, raw and y do not alias, and a store is in vmcnt too), then the
+    // stores.  32-bit element offsets from uniform bases (every tensor of the encoder is below 2^32 bytes).
+    const float *__restrict__ resp = p.res;
+    float *__restrict__ rawp = p.raw;
+    float *__restrict__ yp = p.y;
+    // MODE 0: partial tile (any outputs, run-time checks per element -- rare: every level of the 512^2 path tiles exactly); 1: raw + y; 2: y only;
+    // 3: raw only.  The full-tile forms are straight-line code: a run-time `if (raw)` per element ends the basic block and the compiler then
+    // drains vmcnt at every join.
+    auto emit = [&](auto mode) {
+        constexpr int MODE = decltype(mode)::value;
+        constexpr bool MASK = MODE == 0;
 #pragma unroll
         for (int m = 0; m < CT; ++m) {
-            const int co = (slice * CT + m) * 32 + j;
+            const unsigned co = (slice * CT + m) * 32 + j;
             const float bias = p.bias ? p.bias[co] : 0.0f;
+            float rv[PT][16];
+            bool ok[PT][16];
+            unsigned ybase[PT], rbase[PT];
+            const bool has_raw = MODE == 0 ? rawp != nullptr : (MODE == 1 || MODE == 3), has_y = MODE == 0 ? yp != nullptr : (MODE == 1 || MODE == 2);
+            // element offset of register r = lane base (this lane's first pixel and channel) + dpix(r) * channels, dpix(r) wave-uniform:
+            // one VALU add per element instead of a multiply-add chain and a 64-bit address each
 #pragma unroll
             for (int n = 0; n < PT; ++n) {
                 const int q = wave * PT + n;
+                const unsigned pix0 = (unsigned)((y0 + q * PTR) * p.W + x0 + 4 * h);
+                ybase[n] = pix0 * (unsigned)p.yC + (unsigned)p.ycoff + co;
+                rbase[n] = pix0 * (unsigned)p.Cout + co;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int pl = d_row0(r) + 4 * h;
-                    const int iy = y0 + q * PTR + (TWC == 32 ? 0 : (r >> 3)), ix = x0 + (TWC == 32 ? pl : (pl & 15));
-                    if (MASK && (iy >= p.H || ix >= p.W)) continue;
-                    const int pix = iy * p.W + ix;
+                    const int iy = y0 + q * PTR + (TWC == 32 ? 0 : (r >> 3)), ix = x0 + 4 * h + (TWC == 32 ? d_row0(r) : (d_row0(r) & 15));
+                    ok[n][r] = !MASK || (iy < p.H && ix < p.W);
+                    const unsigned dpix = TWC == 32 ? (unsigned)d_row0(r) : (unsigned)((r >> 3) * p.W + (d_row0(r) & 15));
+                    rv[n][r] = (has_y && ok[n][r]) ? resp[ybase[n] + dpix * (unsigned)p.yC] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < PT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (MASK && !ok[n][r]) continue;
+                    const unsigned dpix = TWC == 32 ? (unsigned)d_row0(r) : (unsigned)((r >> 3) * p.W + (d_row0(r) & 15));
                     const float v = acc[n][m][r] * p.out_scale + bias;
-                    if (p.raw) p.raw[(size_t)pix * p.Cout + co] = v;
+                    if (has_raw) rawp[rbase[n] + dpix * (unsigned)p.Cout] = v;
                     sr[m] += v; qr[m] += v * v;
-                    if (p.y) {
-                        const size_t o = (size_t)pix * p.yC + p.ycoff + co;
-                        const float w = v + p.res[o];
-                        p.y[o] = w;
+                    if (has_y) {
+                        const float w = v + rv[n][r];
+                        yp[ybase[n] + dpix * (unsigned)p.yC] = w;
                         sy[m] += w; qy[m] += w * w;
                     }
                 }
-            }
         }
     };
-    if (full) emit(std::false_type{}); else emit(std::true_type{});
+    if (!full) emit(std::integral_constant<int, 0>{});
+    else if (rawp && yp) emit(std::integral_constant<int, 1>{});
+    else if (yp) emit(std::integral_constant<int, 2>{});
+    else emit(std::integral_constant<int, 3>{});
 
     // ---- statistics: the two pixel halves, then the cpg adjacent channel lanes, then the four waves through LDS
     if (p.st_raw.part2 || p.st_y.part2) {
