@@ -344,7 +344,9 @@ int avc_calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *ca
 int avc_skinning(avc_ctx *ctx, const float *pts, const float *nrm, int64_t n, const float *lbs, const float *jm,
                  float *po, float *no, float *mo, avc_stream stream)
 {
-    AVC_REQUIRE(ctx && n >= 0 && lbs && jm && (pts || nrm), AVC_ERR_ARG, "avc_skinning: NULL argument");
+    AVC_REQUIRE(ctx && n >= 0 && jm, AVC_ERR_ARG, "avc_skinning: NULL argument");
+    if (n == 0) return AVC_OK;                                   // an empty mesh: nothing to skin (the pointers may be NULL)
+    AVC_REQUIRE(lbs && (pts || nrm), AVC_ERR_ARG, "avc_skinning: NULL argument");
     AVC_REQUIRE((!pts || po) && (!nrm || no), AVC_ERR_ARG, "avc_skinning: output missing for a given input");
     AVC_HIP(hipSetDevice(ctx->device));
     return skinning(pts, nrm, n, lbs, jm, po, no, mo, (hipStream_t)stream);
