@@ -44,6 +44,15 @@ class avc_hgfilter(C.Structure):
                 ('conv_last', avc_conv2d), ('bn_end', avc_groupnorm), ('l', avc_conv2d)]
 
 
+class avc_bn2d(C.Structure):
+    _fields_ = [('mean', C.c_void_p), ('var', C.c_void_p), ('eps', C.c_float)]
+
+
+class avc_unet7ds(C.Structure):
+    _fields_ = [('down', avc_conv2d * 7), ('down_bn', avc_bn2d * 7), ('up', avc_conv2d * 3), ('up_bn', avc_bn2d * 3),
+                ('upc', avc_conv2d * 3), ('upc_bn', avc_bn2d * 3)]
+
+
 _SIGNATURES = {
     'avc_last_error': (C.c_char_p, []),
     'avc_version': (C.c_int, []),
@@ -67,6 +76,8 @@ _SIGNATURES = {
                                               C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
     'avc_hgfilter_pack': (C.c_int, [C.c_void_p, C.POINTER(avc_hgfilter)]),
     'avc_hgfilter_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'avc_unet_pack': (C.c_int, [C.c_void_p, C.POINTER(avc_unet7ds)]),
+    'avc_unet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'avc_hgfilter_debug_tensor': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             C.c_void_p]),
     'avc_group_norm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
@@ -221,6 +232,51 @@ class BnList:
             arr[i].gamma, arr[i].beta, arr[i].mean, arr[i].var = (h.ctypes.data for h in hs)
             arr[i].eps = float(e['eps'])
         self.arr = arr
+
+
+class UNetWeights:
+    """avc_unet7ds for a module tree shaped like the reference's UnetNoCond7DS (network/unets.py:169-199); keeps the host arrays alive.
+    `upconv4` exists in checkpoints and is never applied (unets.py:213-214): it is not marshalled."""
+
+    def __init__(self, m):
+        self.keep = []
+        u = avc_unet7ds()
+        for i in range(7):
+            blk = getattr(m, f'conv{i + 1}')
+            self._conv(u.down[i], blk.conv.weight, None, transposed=False)
+            self._bn(u.down_bn[i], getattr(blk, 'bn', None))
+        for i in range(3):
+            blk = getattr(m, f'upconv{i + 1}')
+            if blk.up.bias is not None:
+                raise NotImplementedError('UnetNoCond7DS: the transposed convolutions carry no bias (unets.py:45)')
+            self._conv(u.up[i], blk.up.weight, None, transposed=True)
+            self._bn(u.up_bn[i], getattr(blk, 'bn', None))
+        for i, n in enumerate(('upconvC5', 'upconvC6', 'upconvC7')):
+            blk = getattr(m, n)
+            self._conv(u.upc[i], blk.up[1].weight, blk.up[1].bias, transposed=False)
+            self._bn(u.upc_bn[i], getattr(blk, 'bn', None))
+        self.struct = u
+
+    def _arr(self, t):
+        a = _host(t)
+        self.keep.append(a)
+        return a.ctypes.data
+
+    def _conv(self, dst, w, b, transposed):
+        dst.w = self._arr(w)
+        dst.b = self._arr(b) if b is not None else None
+        o, i, kh, kw = (int(v) for v in w.shape)
+        dst.cout, dst.cin = (i, o) if transposed else (o, i)          # ConvTranspose2d stores (in, out, kh, kw)
+        dst.kh, dst.kw = kh, kw
+
+    def _bn(self, dst, bn):
+        if bn is None:
+            dst.mean = dst.var = None
+            dst.eps = 0.0
+            return
+        if bn.affine or bn.running_mean is None:
+            raise NotImplementedError('UnetNoCond7DS: BatchNorm2d(affine=False) with running statistics (unets.py:26, :58)')
+        dst.mean, dst.var, dst.eps = self._arr(bn.running_mean), self._arr(bn.running_var), float(bn.eps)
 
 
 class HGFilterWeights:

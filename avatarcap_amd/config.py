@@ -30,11 +30,9 @@ cfg = dict()           # configurations from the yaml file (config.py:25)
 # 'numeric range'); a query then synchronises and raises AvcapError (AVC_ERR_RANGE) instead of returning silently wrong values
 check_range = False
 
-# not in the reference: the HGFilter encoder (csrc/conv_enc.hip) replays its ~70 launches as one hipGraph per frame (avc_set_option "enc_graph");
-# False launches the same kernels one by one -- same bits
+# not in the reference: the HGFilter encoder and the warping field's U-Net (csrc/conv_enc.hip) replay their ~70 / 18 launches as one hipGraph each per
+# frame (avc_set_option "enc_graph"); False launches the same kernels one by one -- same bits
 hg_graph = True
-# ... and the warping field's U-Net (MIOpen) replays its ~70 launches as one hipGraph per frame; False: eager launches -- same kernels, same bits
-unet_graph = True
 
 
 def load_config(path):

@@ -87,6 +87,7 @@ struct avc_ctx {
     void *fusion_scratch = nullptr; size_t fusion_scratch_bytes = 0;   // normal-fusion work buffers
     void *fusion_graph = nullptr, *fusion_graph_exec = nullptr;        // hipGraph_t / hipGraphExec_t of the fusion iterations
     int fusion_graph_H = 0, fusion_graph_W = 0, fusion_graph_iters = 0;
+    void *unet = nullptr;                                          // enc::Encoder holding the warping field's U-Net
     void *encoder = nullptr;                                       // enc::Encoder: packed HGFilter weights + the launch plan of the last input size (conv_enc.hip)
     void *gn_scratch = nullptr; size_t gn_scratch_bytes = 0;       // GroupNorm slice sums
     std::vector<void *> retired_scratch;                           // outgrown blocks that a captured graph may still name: freed with the context
@@ -143,6 +144,9 @@ int pack_encoder(avc_ctx *ctx, const avc_hgfilter *net);
 int encoder_forward(avc_ctx *ctx, const float *image, int H, int W, float *feat_out, float *normx_out, int bind, hipStream_t s);
 int encoder_debug_tensor(avc_ctx *ctx, int launch, int which, float *out, int *C, int *H, int *W, hipStream_t s);
 void release_encoder(avc_ctx *ctx);
+int pack_unet(avc_ctx *ctx, const avc_unet7ds *net);
+int unet_forward(avc_ctx *ctx, const float *pos_map, int H, int W, float *out_nchw, int bind, hipStream_t s);
+void release_unet(avc_ctx *ctx);
 }
 // knn_lbs.hip
 int knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, hipStream_t s);

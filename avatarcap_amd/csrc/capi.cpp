@@ -60,6 +60,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
     for (void *p : ctx->retired_scratch) hipFree(p);
     enc::release_encoder(ctx);
+    enc::release_unet(ctx);
     release_fusion_graph(ctx);
     if (ctx->fusion_scratch) hipFree(ctx->fusion_scratch);
     for (int w = 0; w < 2; ++w) {
@@ -364,6 +365,20 @@ int avc_hgfilter_forward(avc_ctx *ctx, const float *image, int H, int W, float *
     AVC_REQUIRE(ctx, AVC_ERR_ARG, "avc_hgfilter_forward: NULL ctx");
     AVC_HIP(hipSetDevice(ctx->device));
     return enc::encoder_forward(ctx, image, H, W, feat_out, normx_out, bind_img_feat_map, (hipStream_t)stream);
+}
+
+int avc_unet_pack(avc_ctx *ctx, const avc_unet7ds *net)
+{
+    AVC_REQUIRE(ctx && net, AVC_ERR_ARG, "avc_unet_pack: NULL argument");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return enc::pack_unet(ctx, net);
+}
+
+int avc_unet_forward(avc_ctx *ctx, const float *pos_map, int H, int W, float *out_nchw, int bind_pose_feat_map, avc_stream stream)
+{
+    AVC_REQUIRE(ctx, AVC_ERR_ARG, "avc_unet_forward: NULL ctx");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return enc::unet_forward(ctx, pos_map, H, W, out_nchw, bind_pose_feat_map, (hipStream_t)stream);
 }
 
 int avc_hgfilter_debug_tensor(avc_ctx *ctx, int launch, int which, float *out_nchw_dev, int32_t *C, int32_t *H, int32_t *W, avc_stream stream)

@@ -57,7 +57,7 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_in
 // ---- LDS map of conv_mfma_kernel ---------------------------------------------------------------------------------------
 constexpr int PIXB = 144;                       // bytes per staged pixel: 32 channels x (hi, lo) halves + 16 pad (odd multiple of 16: conflict-free b128 reads)
 constexpr int RING_SLOT = 16384;                // one slot of the weight ring: a group of 4 / CT taps
-constexpr int MAX_CIN = 256;
+constexpr int MAX_CIN = 1024;               // input channels of one convolution (the U-Net's space-to-depth layers reach 1024)
 
 // GroupNorm statistics (torch.nn.GroupNorm: mean and biased variance over (C / G, H, W)) travel from the launch that produces a tensor to the
 // launches that consume it as a table of at most 32 partial (sum, sum of squares) pairs per group, in double: [group][bucket].  A bucket is
@@ -72,6 +72,14 @@ struct StatOut {
     int nb, bsize;       // buckets (<= 32), tiles per bucket
 };
 
+// A destination of a convolution's output in one of the layouts the U-Net's layers hand to each other (all channel-last):
+//   OUT_NORMAL  pixel (y, x), channel coff + co of a (H, W, C) tensor -- a slice of the tensor a torch.cat would have built
+//   OUT_S2D     the space-to-depth form the next stride-2 convolution reads: pixel (y / 2, x / 2), channel ((y & 1) 2 + (x & 1)) Cout + co of (H/2, W/2, 4 Cout)
+//   OUT_D2S     a transposed convolution computed as a 3x3 convolution with 4 Cq parity-major output channels: output channel par Cq + c of pixel (y, x) is
+//               channel coff + c of pixel (2 y + par / 2, 2 x + par % 2) of a (2 H, 2 W, C) tensor
+enum { OUT_NONE = 0, OUT_NORMAL = 1, OUT_S2D = 2, OUT_D2S = 3 };
+struct OutSpec { float *ptr; int layout, C, coff; };
+
 struct ConvArgs {
     const float *x;              // input (H, W, Cin) channel-last
     int H, W, Cin;
@@ -80,6 +88,7 @@ struct ConvArgs {
     const float *gamma, *beta;   // the consumer's GroupNorm affine
     int in_cpg;
     float in_scale;              // power of two folded into (a, b): keeps small activations' lo halves normal
+    float in_slope;              // raw inputs (NORM == false): x <- max(x, in_slope x) while staging: 1 none, 0 ReLU, 0.2 LeakyReLU(0.2) (the U-Net's pre-activations)
     const char *wstream;         // packed weights: slices of 32 CT output channels, each [chunk][tap][k-step][tile][hi 1 KiB | lo 1 KiB]
     unsigned wbytes, slice_bytes;
     const float *bias;           // (Cout) or null
@@ -96,6 +105,7 @@ struct ConvArgs {
     float *kpart;                // split-K: [tile x slice][ksplit][accumulator registers][256 threads] raw sums
     unsigned *kcounter;          // split-K: one ticket per (tile, slice)
     unsigned *range_flag;        // set to 1 when a staged value exceeds the fp16 range of the split (avc_set_range_check reads it)
+    OutSpec oa, ob;              // generic outputs (the U-Net's layouts); when oa.ptr != null they replace raw / y and no statistics are produced
 };
 
 __device__ __forceinline__ float relu_bits(float x)
@@ -204,9 +214,9 @@ struct ConvGeo {
     static constexpr int RP = TAPS == 1 ? TWC : (TWC == 32 ? HC : 32);       // LDS row pitch in pixels (32 for the 16-wide tiles: bank note in DESIGN.md)
     static constexpr int NPIX = HR * RP;
     static constexpr int ACTB = (NPIX * PIXB + 1023) & ~1023;
-    static constexpr int RS_FIT = (163840 - 2048 - 64 - 256 - 2 * ACTB) / RING_SLOT;
+    static constexpr int RS_FIT = (163840 - 8 * MAX_CIN - 64 - 256 - 2 * ACTB) / RING_SLOT;
     static constexpr int RS = RS_FIT > 6 ? 6 : RS_FIT;            // ring slots; RS - 1 groups of weights are in flight
-    static constexpr int L_ACT0 = 0, L_ACT1 = ACTB, L_RING = 2 * ACTB, L_AB = L_RING + RS * RING_SLOT, L_FLAG = L_AB + 2048, L_TOTAL = L_FLAG + 64 + 256;     // (flag, then (mean, rstd) of the input's 32 groups)
+    static constexpr int L_ACT0 = 0, L_ACT1 = ACTB, L_RING = 2 * ACTB, L_AB = L_RING + RS * RING_SLOT, L_FLAG = L_AB + 8 * MAX_CIN, L_TOTAL = L_FLAG + 64 + 256;     // (flag, then (mean, rstd) of the input's 32 groups)
     static_assert(RS >= 3, "no room for the weight ring");
 };
 
@@ -236,15 +246,15 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
             *reinterpret_cast<f32x2 *>(smem + LDS_FLAG + 64 + tid * 8) = fold_group(p.in_part2 + (size_t)tid * p.in_nb * 2, p.in_nb, p.in_inv_n, p.in_eps);
         __syncthreads();
     }
-    if (tid < p.Cin) {
+    for (int c = tid; c < p.Cin; c += 256) {
         float a = p.in_scale, b = 0.0f;
         if constexpr (NORM) {
-            const f32x2 mr = *reinterpret_cast<const f32x2 *>(smem + LDS_FLAG + 64 + (tid / p.in_cpg) * 8);
-            a = p.gamma[tid] * mr[1];
-            b = (p.beta[tid] - mr[0] * a) * p.in_scale;
+            const f32x2 mr = *reinterpret_cast<const f32x2 *>(smem + LDS_FLAG + 64 + (c / p.in_cpg) * 8);
+            a = p.gamma[c] * mr[1];
+            b = (p.beta[c] - mr[0] * a) * p.in_scale;
             a *= p.in_scale;
         }
-        *reinterpret_cast<f32x2 *>(smem + LDS_AB + tid * 8) = f32x2{a, b};
+        *reinterpret_cast<f32x2 *>(smem + LDS_AB + c * 8) = f32x2{a, b};
     }
 
     // ---- staging geometry of this thread: piece i = 4 channels `sub` of staged pixel sp = tid / 8 + 32 i
@@ -286,6 +296,10 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
             float v0 = ab0[0] * stage[i][0] + ab0[1], v1 = ab0[2] * stage[i][1] + ab0[3];
             float v2 = ab1[0] * stage[i][2] + ab1[1], v3 = ab1[2] * stage[i][3] + ab1[3];
             if constexpr (NORM) { v0 = relu_bits(v0); v1 = relu_bits(v1); v2 = relu_bits(v2); v3 = relu_bits(v3); }
+            else {
+                v0 = __builtin_fmaxf(v0, p.in_slope * v0); v1 = __builtin_fmaxf(v1, p.in_slope * v1);
+                v2 = __builtin_fmaxf(v2, p.in_slope * v2); v3 = __builtin_fmaxf(v3, p.in_slope * v3);
+            }
             amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)), __builtin_fmaxf(__builtin_fabsf(v2), __builtin_fabsf(v3))));
             unsigned h01, l01, h23, l23;
             split2(v0, v1, h01, l01);
@@ -535,6 +549,35 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
                 }
         }
     };
+    // the U-Net's outputs: any layout, no residual, no statistics; these launches are small (the whole U-Net is 10 GFLOP), the addressing is per element
+    if (p.oa.ptr) {
+        auto put = [&](const OutSpec &o, int iy, int ix, unsigned co, float v) {
+            if (o.layout == OUT_NORMAL) o.ptr[((size_t)iy * p.W + ix) * o.C + o.coff + co] = v;
+            else if (o.layout == OUT_S2D) o.ptr[((size_t)(iy >> 1) * (p.W >> 1) + (ix >> 1)) * o.C + (((iy & 1) * 2 + (ix & 1)) * (o.C >> 2)) + o.coff + co] = v;
+            else if (o.layout == OUT_D2S) {
+                const unsigned cq = (unsigned)p.Cout >> 2, par = co / cq, c = co - par * cq;
+                o.ptr[((size_t)(2 * iy + (par >> 1)) * (2 * p.W) + 2 * ix + (par & 1)) * o.C + o.coff + c] = v;
+            }
+        };
+#pragma unroll
+        for (int m = 0; m < CT; ++m) {
+            const unsigned co = (slice * CT + m) * 32 + j;
+            const float bias = p.bias ? p.bias[co] : 0.0f;
+#pragma unroll
+            for (int n = 0; n < PT; ++n) {
+                const int q = wave * PT + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int iy = y0 + q * PTR + (TWC == 32 ? 0 : (r >> 3)), ix = x0 + 4 * h + (TWC == 32 ? d_row0(r) : (d_row0(r) & 15));
+                    if (iy >= p.H || ix >= p.W) continue;
+                    const float v = acc[n][m][r] * p.out_scale + bias;
+                    put(p.oa, iy, ix, co, v);
+                    if (p.ob.ptr) put(p.ob, iy, ix, co, v);
+                }
+            }
+        }
+        return;
+    }
     if (!full) emit(std::integral_constant<int, 0>{});
     else if (rawp && yp) emit(std::integral_constant<int, 1>{});
     else if (yp) emit(std::integral_constant<int, 2>{});
@@ -811,6 +854,30 @@ __global__ void hwc_to_nchw_kernel(const float *__restrict__ src, float *__restr
 }
 
 
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) of relu(x) (network/unets.py:42-45, the ReLU of :52): out[2 i] = 0.25 x[i - 1] + 0.75 x[i],
+// out[2 i + 1] = 0.75 x[i] + 0.25 x[i + 1], indices clamped -- torch's source index (dst + 0.5) / 2 - 0.5 floored at 0.  x (H, W, C) -> out (2 H, 2 W, C).
+struct Up2Args { const float *x; float *out; int H, W, C; };
+__global__ __launch_bounds__(256) void up2_kernel(const Up2Args p)
+{
+    const int c4n = p.C >> 2;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)4 * p.H * p.W * c4n;
+    if (i >= total) return;
+    const int c4 = (int)(i % c4n);
+    const size_t pix = i / c4n;
+    const int ox = (int)(pix % (2 * p.W)), oy = (int)(pix / (2 * p.W));
+    // torch: real = max((dst + 0.5) * 0.5 - 0.5, 0); i0 = floor(real); lambda1 = real - i0; i1 = min(i0 + 1, size - 1)
+    const float ry = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.0f), rx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.0f);
+    const int y0 = (int)ry, x0 = (int)rx, y1 = min(y0 + 1, p.H - 1), x1 = min(x0 + 1, p.W - 1);
+    const float ly = ry - (float)y0, lx = rx - (float)x0;
+    auto at = [&](int y, int x) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(p.x + ((size_t)y * p.W + x) * p.C + 4 * c4);
+        return f32x4{relu_bits(v[0]), relu_bits(v[1]), relu_bits(v[2]), relu_bits(v[3])};
+    };
+    const f32x4 v00 = at(y0, x0), v01 = at(y0, x1), v10 = at(y1, x0), v11 = at(y1, x1);
+    const float w00 = (1.0f - ly) * (1.0f - lx), w01 = (1.0f - ly) * lx, w10 = ly * (1.0f - lx), w11 = ly * lx;
+    *reinterpret_cast<f32x4 *>(p.out + pix * p.C + 4 * c4) = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+}
+
 // =====================================================================================================================
 // host side: weight packing, the launch plan of one input size, the hipGraph
 // =====================================================================================================================
@@ -827,11 +894,12 @@ struct DevBlock { DevConv conv[3], ds; bool has_ds = false; DevNorm bn[4]; int c
 struct Tensor { float *data = nullptr; int H = 0, W = 0, C = 0;
                 double *part2 = nullptr; int nb = 0; };      // GroupNorm partials [32 groups][nb buckets] its producers leave, its consumers fold
 
-enum LaunchKind { L_S2D, L_CONV, L_POOL, L_UPADD, L_UPADD_TILED, L_NORMRELU, L_FORK, L_JOIN };
+enum LaunchKind { L_S2D, L_CONV, L_POOL, L_UPADD, L_UPADD_TILED, L_NORMRELU, L_UP2, L_FORK, L_JOIN };
 struct Launch {
     LaunchKind kind;
     ConvArgs conv; int CT = 0, PT = 0, TAPS = 0, TWC = 0; bool norm = false;
     S2dArgs s2d;
+    Up2Args up2;
     EltArgs elt; int ut_x = 0, ut_y = 0;     // (L_UPADD_TILED: the tile grid)
     unsigned grid = 0;
     int side = 0;                    // 1: the launch goes to the side stream (the hourglass' upper branches run beside the lower ones)
@@ -845,6 +913,7 @@ struct Encoder {
     DevBlock conv2, conv3, conv4, top_m;
     std::vector<DevBlock> hg;        // b1_d, b2_d, ..., b1_1, b2_1, b2_plus_1, b3_1 .. b3_d
     int depth = 0;
+    DevConv u_down[7], u_up[3], u_upc[3];       // the U-Net's convolutions (a second Encoder object holds them: avc_ctx::unet)
     std::vector<void *> weight_allocs;
     // the plan of one input size
     int Hin = 0, Win = 0;
@@ -903,12 +972,12 @@ constexpr int conv_ct(int cout) { return cout >= 128 ? 4 : (cout >= 64 ? 2 : 1);
 // [slice][chunk][tap][k-step][tile][hi 1 KiB | lo 1 KiB]; element (lane, e) of a fragment: co = 32 (slice CT + tile) + (lane & 31),
 // ci = 32 chunk + 16 kstep + 8 (lane >> 5) + e.  Any CT that divides cout / 32 reads the same stream (a slice of CT tiles is CT
 // consecutive slices of one tile only when the tile index is the outermost axis -- it is not; so the stream is packed per CT).
-static int pack_conv(Encoder *e, const avc_conv2d &c, int taps_expected, DevConv &d, const char *name)
+static int pack_conv(Encoder *e, const avc_conv2d &c, int taps_expected, DevConv &d, const char *name, int ct_mask = 7)
 {
     AVC_REQUIRE(c.w, AVC_ERR_ARG, "avc_hgfilter_pack: %s: NULL weight", name);
     AVC_REQUIRE(c.kh * c.kw == taps_expected && c.kh == c.kw, AVC_ERR_ARG, "avc_hgfilter_pack: %s: kernel %dx%d, expected %d taps", name, c.kh, c.kw, taps_expected);
-    AVC_REQUIRE(c.cin % 32 == 0 && c.cin <= MAX_CIN && c.cout % 32 == 0 && c.cout <= 256, AVC_ERR_ARG,
-                "avc_hgfilter_pack: %s: (%d <- %d) channels; multiples of 32 up to 256 are supported", name, c.cout, c.cin);
+    AVC_REQUIRE(c.cin % 32 == 0 && c.cin <= MAX_CIN && c.cout % 32 == 0 && c.cout <= 1024, AVC_ERR_ARG,
+                "pack: %s: (%d <- %d) channels; multiples of 32 up to 1024 are supported", name, c.cout, c.cin);
     d.cout = c.cout; d.cin = c.cin; d.taps = taps_expected;
     const int taps = taps_expected, nchunk = c.cin / 32;
     double m = 0.0;
@@ -928,7 +997,7 @@ static int pack_conv(Encoder *e, const avc_conv2d &c, int taps_expected, DevConv
     for (int v = 0; v < 3; ++v) {
         const int CT = 1 << v;
         off[v] = (unsigned)stream.size();
-        if (ntile % CT) continue;
+        if (ntile % CT || !(ct_mask & CT)) continue;
         for (int slice = 0; slice < ntile / CT; ++slice)
             for (int ch = 0; ch < nchunk; ++ch)
                 for (int t = 0; t < taps; ++t)
@@ -1114,6 +1183,7 @@ struct Planner {
         if (gn && !x.part2 && !rc) { set_error("avc_hgfilter_forward: internal: a normalised input without statistics"); rc = AVC_ERR_STATE; }
         a.gamma = gn ? gn->gamma : nullptr; a.beta = gn ? gn->beta : nullptr; a.in_cpg = gn ? x.C / gn->groups : 1;
         a.in_scale = gn ? 16.0f : raw_in_scale;
+        a.in_slope = 1.0f;
         const int v = L.CT == 4 ? 2 : (L.CT == 2 ? 1 : 0);
         a.slice_bytes = (unsigned)(x.C / 32) * w.taps * 2 * L.CT * 2048;
         a.wstream = w.wstream + w.off[v]; a.wbytes = a.slice_bytes * (w.cout / (32 * L.CT));
@@ -1130,7 +1200,7 @@ struct Planner {
         a.range_flag = e->range_flag;
         a.ksplit = 1;
         if (ctx->opt.enc_ksplit)
-            while (a.ksplit < nchunk && a.ksplit < 8 && 2 * wg * a.ksplit <= ctx->num_cus) a.ksplit *= 2;
+            while (nchunk % (2 * a.ksplit) == 0 && a.ksplit < 8 && 2 * wg * a.ksplit <= ctx->num_cus) a.ksplit *= 2;       // slices of whole chunks
         if (a.ksplit > 1) {
             a.kpart = static_cast<float *>(alloc(sizeof(float) * (size_t)wg * a.ksplit * 256 * L.PT * L.CT * 16));
             a.kcounter = static_cast<unsigned *>(alloc(sizeof(unsigned) * wg, true));
@@ -1224,6 +1294,7 @@ static int launch_conv(const Launch &L, hipStream_t s)
 #define AVC_ENC_CT(PT_, TAPS_, TWC_, NORM_) AVC_ENC_CASE(1, PT_, TAPS_, TWC_, NORM_) AVC_ENC_CASE(2, PT_, TAPS_, TWC_, NORM_) AVC_ENC_CASE(4, PT_, TAPS_, TWC_, NORM_)
 #define AVC_ENC_GEO(TAPS_, NORM_) AVC_ENC_CT(2, TAPS_, 32, NORM_) AVC_ENC_CT(1, TAPS_, 32, NORM_) AVC_ENC_CT(1, TAPS_, 16, NORM_)
     AVC_ENC_GEO(9, true)
+    AVC_ENC_GEO(9, false)
     AVC_ENC_GEO(1, true)
     AVC_ENC_GEO(1, false)
     AVC_ENC_CASE(2, 1, 16, 32, false)
@@ -1248,6 +1319,7 @@ static int run_plan(Encoder *e, hipStream_t main_stream)
         case L_UPADD: hipLaunchKernelGGL(upadd_kernel, dim3(L.grid), dim3(256), 0, s, L.elt); break;
         case L_UPADD_TILED: { UpTiledArgs u{L.elt, L.ut_x, L.ut_y}; hipLaunchKernelGGL(upadd_tiled_kernel, dim3(L.grid), dim3(256), 0, s, u); break; }
         case L_NORMRELU: hipLaunchKernelGGL(normrelu_kernel, dim3(L.grid), dim3(256), 0, s, L.elt); break;
+        case L_UP2: hipLaunchKernelGGL(up2_kernel, dim3(L.grid), dim3(256), 0, s, L.up2); break;
         }
     }
     AVC_HIP(hipGetLastError());
@@ -1294,6 +1366,7 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
     if (ctx->opt.enc_graph) {
         if (!e->cap_stream) AVC_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
         // first a plain run: hipFuncSetAttribute calls and module loading must not happen inside a capture
+        AVC_HIP(hipDeviceSynchronize());                    // the zero-fills of the plan's counters (null stream) are done: the capture stream does not wait for them
         if (int rc = run_plan(e, e->cap_stream)) { free_plan(e); return rc; }
         AVC_HIP(hipStreamSynchronize(e->cap_stream));
         AVC_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
@@ -1350,17 +1423,284 @@ int encoder_forward(avc_ctx *ctx, const float *image, int H, int W, float *feat_
 // a tensor of the last forward, for tests: index into the launch plan -> the launch's raw / y output as NCHW
 int encoder_debug_tensor(avc_ctx *ctx, int launch, int which, float *out, int *C, int *H, int *W, hipStream_t s)
 {
-    Encoder *e = static_cast<Encoder *>(ctx->encoder);
+    Encoder *e = static_cast<Encoder *>(which == 2 ? ctx->unet : ctx->encoder);
     AVC_REQUIRE(e && launch >= 0 && launch < (int)e->plan.size(), AVC_ERR_ARG, "avc_hgfilter_debug_tensor: launch %d of %d", launch, e ? (int)e->plan.size() : 0);
     const Launch &L = e->plan[launch];
     const float *src = nullptr; int c = 0, h = 0, w = 0;
-    if (L.kind == L_CONV) { src = which ? L.conv.y : L.conv.raw; c = which ? L.conv.yC : L.conv.Cout; h = L.conv.H; w = L.conv.W; }
+    if (L.kind == L_CONV && which == 2) {                  // the U-Net's destination tensor (whole: the caller knows the channel slice the launch wrote)
+        const OutSpec &o = L.conv.oa;
+        const int up = o.layout == OUT_D2S ? 2 : 1;
+        src = o.ptr; c = o.C; h = up * L.conv.H; w = up * L.conv.W;
+    }
+    else if (L.kind == L_CONV) { src = which ? L.conv.y : L.conv.raw; c = which ? L.conv.yC : L.conv.Cout; h = L.conv.H; w = L.conv.W; }
     else if (L.kind == L_POOL || L.kind == L_UPADD || L.kind == L_UPADD_TILED || L.kind == L_NORMRELU) { src = L.elt.out; c = L.elt.C; h = L.elt.H; w = L.elt.W; }
+    else if (L.kind == L_UP2) { src = L.up2.out; c = L.up2.C; h = 2 * L.up2.H; w = 2 * L.up2.W; }
+    else if (L.kind == L_S2D) { src = L.s2d.out; c = 32; h = L.s2d.H; w = L.s2d.W; }
     *C = c; *H = h; *W = w;
     if (L.kind == L_CONV) *C = c | (L.CT << 16) | (L.PT << 20) | (L.TAPS << 24) | ((L.conv.ksplit > 1 ? 1 : 0) << 30);
     if (out && src) hipLaunchKernelGGL(hwc_to_nchw_kernel, dim3((h * w + 63) / 64, (c + 63) / 64), dim3(256), 0, s, src, out, c, h * w);
     AVC_HIP(hipGetLastError());
     return src ? AVC_OK : 1;
+}
+
+
+// =====================================================================================================================
+// The warping field's U-Net (UnetNoCond7DS, network/unets.py:169-229; blocks :10-60) on the same convolution kernel
+// =====================================================================================================================
+// Every layer becomes ONE launch of conv_mfma_kernel<.., TAPS = 9, .., NORM = false> on tensors that are already in the layout the next layer reads:
+//   Conv2DBlock (LeakyReLU(0.2) -> Conv2d k4 s2 p1 -> BatchNorm2d(affine=False)):  a stride-2 4x4 convolution is a 3x3 convolution (pad 1) of the
+//     space-to-depth tensor (4 C channels per pixel: input row 2 o - 1 + k is row o - 1 + ty of parity py with k = 2 ty + py - 1); its producer writes the
+//     s2d form directly (OUT_S2D), plus the plain form into its channel slice of the decoder tensor it will be concatenated into (OUT_NORMAL: torch.cat
+//     costs nothing).  The BatchNorm (eval, running statistics) is folded into weights and bias; the pre-activation is applied while the input is staged.
+//   UpConv2DBlock 'upconv' (ReLU -> ConvTranspose2d k4 s2 p1 -> BN -> cat):  output row 2 i + a takes input rows i - 1 + ty with k = a + 3 - 2 ty: a 3x3
+//     convolution with 4 Cout parity-major output channels, scattered to the double-resolution tensor by the epilogue (OUT_D2S).
+//   UpConv2DBlock 'upsample' (ReLU -> bilinear x2 -> Conv2d 3x3 + bias -> BN -> cat):  up2_kernel, then a plain 3x3 convolution.
+// 18 launches (one space-to-depth of the input, 7 + 4 + 3 convolutions, 3 upsamples) instead of MIOpen's ~70, replayed as a hipGraph; the last
+// convolution's output IS the channel-last pose feature map the avatar query samples.  The reference's quirk is kept: upconv3 runs twice, upconv4 never
+// (unets.py:213-214).
+static int fold_bn(const avc_bn2d &bn, int cout, std::vector<float> &scale, std::vector<float> &shift, const char *name)
+{
+    scale.assign(cout, 1.0f); shift.assign(cout, 0.0f);
+    if (!bn.mean) return AVC_OK;
+    AVC_REQUIRE(bn.var, AVC_ERR_ARG, "avc_unet_pack: %s: running_var is NULL", name);
+    for (int c = 0; c < cout; ++c) {
+        AVC_REQUIRE(bn.var[c] + bn.eps > 0.0f, AVC_ERR_ARG, "avc_unet_pack: %s: running_var[%d] + eps <= 0", name, c);
+        scale[c] = 1.0f / std::sqrt(bn.var[c] + bn.eps);
+        shift[c] = -bn.mean[c] * scale[c];
+    }
+    return AVC_OK;
+}
+
+int pack_unet(avc_ctx *ctx, const avc_unet7ds *net)
+{
+    if (!ctx->unet) ctx->unet = new Encoder();
+    Encoder *e = static_cast<Encoder *>(ctx->unet);
+    free_plan(e);
+    free_weights(e);
+    char nm[48];
+    std::vector<float> sc, sh;
+    // ---- conv1..7: Conv2d(ci, co, 4, 2, 1, bias=False) as 3x3 over the 4 ci (first layer: 24 padded to 32) space-to-depth channels
+    for (int l = 0; l < 7; ++l) {
+        const avc_conv2d &c = net->down[l];
+        snprintf(nm, sizeof nm, "conv%d", l + 1);
+        AVC_REQUIRE(c.w && c.kh == 4 && c.kw == 4 && !c.b && c.cout % 32 == 0, AVC_ERR_ARG, "avc_unet_pack: %s must be Conv2d(k4, s2, p1, bias=False) with cout a multiple of 32", nm);
+        AVC_REQUIRE(l == 0 ? c.cin * 4 <= 32 : (c.cin == net->down[l - 1].cout), AVC_ERR_ARG, "avc_unet_pack: %s: %d input channels", nm, c.cin);
+        if (int rc = fold_bn(net->down_bn[l], c.cout, sc, sh, nm)) return rc;
+        const int ci4 = l == 0 ? 32 : 4 * c.cin;
+        std::vector<float> w((size_t)c.cout * ci4 * 9, 0.0f);
+        for (int co = 0; co < c.cout; ++co)
+            for (int par = 0; par < 4; ++par)
+                for (int ci = 0; ci < c.cin; ++ci)
+                    for (int ty = 0; ty < 3; ++ty)
+                        for (int tx = 0; tx < 3; ++tx) {
+                            const int ky = 2 * ty + (par >> 1) - 1, kx = 2 * tx + (par & 1) - 1;
+                            if (ky < 0 || ky > 3 || kx < 0 || kx > 3) continue;
+                            w[((size_t)co * ci4 + par * c.cin + ci) * 9 + ty * 3 + tx] = c.w[(((size_t)co * c.cin + ci) * 4 + ky) * 4 + kx] * sc[co];
+                        }
+        const avc_conv2d c3{w.data(), sh.data(), c.cout, ci4, 3, 3};
+        if (int rc = pack_conv(e, c3, 9, e->u_down[l], nm, conv_ct(c.cout))) return rc;
+    }
+    // ---- upconv1..3: ConvTranspose2d(ci, co, 4, 2, 1, bias=False), weight (ci, co, 4, 4), as 3x3 with 4 co parity-major outputs
+    for (int l = 0; l < 3; ++l) {
+        const avc_conv2d &c = net->up[l];
+        snprintf(nm, sizeof nm, "upconv%d", l + 1);
+        AVC_REQUIRE(c.w && c.kh == 4 && c.kw == 4 && !c.b && c.cout % 32 == 0 && c.cin % 32 == 0, AVC_ERR_ARG, "avc_unet_pack: %s must be ConvTranspose2d(k4, s2, p1, bias=False)", nm);
+        if (int rc = fold_bn(net->up_bn[l], c.cout, sc, sh, nm)) return rc;
+        std::vector<float> w((size_t)4 * c.cout * c.cin * 9, 0.0f), b((size_t)4 * c.cout);
+        for (int par = 0; par < 4; ++par)
+            for (int co = 0; co < c.cout; ++co) {
+                b[(size_t)par * c.cout + co] = sh[co];
+                for (int ci = 0; ci < c.cin; ++ci)
+                    for (int ty = 0; ty < 3; ++ty)
+                        for (int tx = 0; tx < 3; ++tx) {
+                            const int ky = (par >> 1) + 3 - 2 * ty, kx = (par & 1) + 3 - 2 * tx;
+                            if (ky < 0 || ky > 3 || kx < 0 || kx > 3) continue;
+                            w[(((size_t)par * c.cout + co) * c.cin + ci) * 9 + ty * 3 + tx] = c.w[(((size_t)ci * c.cout + co) * 4 + ky) * 4 + kx] * sc[co];
+                        }
+            }
+        const avc_conv2d c3{w.data(), b.data(), 4 * c.cout, c.cin, 3, 3};
+        if (int rc = pack_conv(e, c3, 9, e->u_up[l], nm, 4)) return rc;
+    }
+    // ---- upconvC5..C7: Conv2d(ci, co, 3, 1, 1, bias=True) behind the bilinear upsample
+    for (int l = 0; l < 3; ++l) {
+        const avc_conv2d &c = net->upc[l];
+        snprintf(nm, sizeof nm, "upconvC%d", l + 5);
+        AVC_REQUIRE(c.w && c.b && c.kh == 3 && c.kw == 3 && c.cout % 32 == 0 && c.cin % 32 == 0, AVC_ERR_ARG, "avc_unet_pack: %s must be Conv2d(3x3, p1) with a bias", nm);
+        if (int rc = fold_bn(net->upc_bn[l], c.cout, sc, sh, nm)) return rc;
+        std::vector<float> w((size_t)c.cout * c.cin * 9), b(c.cout);
+        for (int co = 0; co < c.cout; ++co) {
+            b[co] = c.b[co] * sc[co] + sh[co];
+            for (size_t i = 0; i < (size_t)c.cin * 9; ++i) w[(size_t)co * c.cin * 9 + i] = c.w[(size_t)co * c.cin * 9 + i] * sc[co];
+        }
+        const avc_conv2d c3{w.data(), b.data(), c.cout, c.cin, 3, 3};
+        if (int rc = pack_conv(e, c3, 9, e->u_upc[l], nm, conv_ct(c.cout))) return rc;
+    }
+    // the decoder's concatenations must fit together (unets.py:209-219)
+    const int c6 = e->u_down[5].cout, c5 = e->u_down[4].cout, c4 = e->u_down[3].cout, c3 = e->u_down[2].cout, c2 = e->u_down[1].cout, c1 = e->u_down[0].cout;
+    const int u1 = e->u_up[0].cout / 4, u2 = e->u_up[1].cout / 4, u3 = e->u_up[2].cout / 4;
+    AVC_REQUIRE(e->u_up[0].cin == e->u_down[6].cout && e->u_up[1].cin == u1 + c6 && e->u_up[2].cin == u2 + c5 && e->u_up[2].cin == u3 + c4 &&
+                e->u_upc[0].cin == u3 + c3 && e->u_upc[1].cin == e->u_upc[0].cout + c2 && e->u_upc[2].cin == e->u_upc[1].cout + c1, AVC_ERR_ARG,
+                "avc_unet_pack: the layers' channel counts do not chain as UnetNoCond7DS.forward concatenates them (unets.py:201-219)");
+    e->packed = true;
+    return AVC_OK;
+}
+
+static int build_unet_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
+{
+    free_plan(e);
+    AVC_REQUIRE(Hin % 128 == 0 && Win % 128 == 0 && Hin >= 128 && Win >= 128, AVC_ERR_ARG,
+                "avc_unet_forward: a %d x %d position map; seven stride-2 levels need multiples of 128 (the reference runs 256 x 256)", Hin, Win);
+    Planner P{ctx, e, {}};
+    e->in_buf = static_cast<float *>(P.alloc(sizeof(float) * 6 * (size_t)Hin * Win));
+    e->range_flag = static_cast<unsigned *>(P.alloc(sizeof(unsigned), true));
+    // one convolution: x (raw, pre-activation `slope`) -> the two generic outputs
+    auto conv = [&](const DevConv &w, const Tensor &x, float slope, OutSpec oa, OutSpec ob) {
+        if (P.rc) return;
+        Launch L{}; L.kind = L_CONV; L.TAPS = 9; L.norm = false;
+        L.TWC = x.W >= 32 ? 32 : 16;
+        L.CT = conv_ct(w.cout) > 4 ? 4 : conv_ct(w.cout);
+        L.PT = L.TWC == 32 ? 2 : 1;
+        auto wgs = [&](int PT) { const int rows = 4 * PT * (32 / L.TWC); return ((x.H + rows - 1) / rows) * ((x.W + L.TWC - 1) / L.TWC) * (w.cout / (32 * L.CT)); };
+        if (L.PT == 2 && wgs(2) < ctx->num_cus) L.PT = 1;
+        const int rows = 4 * L.PT * (32 / L.TWC);
+        ConvArgs &a = L.conv;
+        a.x = x.data; a.H = x.H; a.W = x.W; a.Cin = x.C;
+        a.in_cpg = 1; a.in_scale = 16.0f; a.in_slope = slope;
+        const int v = L.CT == 4 ? 2 : (L.CT == 2 ? 1 : 0);
+        a.slice_bytes = (unsigned)(x.C / 32) * 9 * 2 * L.CT * 2048;
+        a.wstream = w.wstream + w.off[v]; a.wbytes = a.slice_bytes * (w.cout / (32 * L.CT));
+        a.bias = w.bias; a.out_scale = w.wscale_inv / a.in_scale; a.Cout = w.cout;
+        a.tiles_x = (x.W + L.TWC - 1) / L.TWC; a.tiles_y = (x.H + rows - 1) / rows;
+        a.oa = oa; a.ob = ob;
+        a.range_flag = e->range_flag;
+        const int wg = a.tiles_x * a.tiles_y * (w.cout / (32 * L.CT)), nchunk = x.C / 32;
+        a.ksplit = 1;
+        if (ctx->opt.enc_ksplit)
+            while (nchunk % (2 * a.ksplit) == 0 && a.ksplit < 8 && 2 * wg * a.ksplit <= ctx->num_cus) a.ksplit *= 2;       // slices of whole chunks
+        if (a.ksplit > 1) {
+            a.kpart = static_cast<float *>(P.alloc(sizeof(float) * (size_t)wg * a.ksplit * 256 * L.PT * L.CT * 16));
+            a.kcounter = static_cast<unsigned *>(P.alloc(sizeof(unsigned) * wg, true));
+        }
+        L.grid = (unsigned)(wg * a.ksplit);
+        P.push(L);
+    };
+    const int H1 = Hin / 2, W1 = Win / 2;
+    // the concatenated decoder tensors [up part | skip] at each resolution, and the space-to-depth forms of the encoder's outputs
+    const DevConv *dn = e->u_down;
+    const int uq[3] = {e->u_up[0].cout / 4, e->u_up[1].cout / 4, e->u_up[2].cout / 4};
+    Tensor x0 = P.tensor(H1, W1, 32);                                          // s2d of the (6, H, W) input
+    Tensor cat6 = P.tensor(H1, W1, e->u_upc[1].cout + dn[0].cout);             // [upC6 | d1]   128^2
+    Tensor cat5 = P.tensor(H1 / 2, W1 / 2, e->u_upc[0].cout + dn[1].cout);     // [upC5 | d2]   64^2
+    Tensor cat4 = P.tensor(H1 / 4, W1 / 4, uq[2] + dn[2].cout);                // [upconv3' | d3]
+    Tensor cat3 = P.tensor(H1 / 8, W1 / 8, uq[2] + dn[3].cout);                // [upconv3 | d4]
+    Tensor cat2 = P.tensor(H1 / 16, W1 / 16, uq[1] + dn[4].cout);              // [upconv2 | d5]
+    Tensor cat1 = P.tensor(H1 / 32, W1 / 32, uq[0] + dn[5].cout);              // [upconv1 | d6]
+    Tensor d7 = P.tensor(H1 / 64, W1 / 64, dn[6].cout);
+    Tensor *cats[6] = {&cat6, &cat5, &cat4, &cat3, &cat2, &cat1};
+    Tensor s2d[6];                                                              // d1..d6 in the layout conv2..conv7 read
+    for (int l = 0; l < 6; ++l) s2d[l] = P.tensor(H1 >> (l + 1), W1 >> (l + 1), 4 * dn[l].cout);
+    if (!P.rc) {
+        Launch L{}; L.kind = L_S2D;
+        L.s2d = S2dArgs{e->in_buf, Hin, Win, H1, W1, x0.data};
+        L.grid = (unsigned)((H1 * W1 * 8 + 255) / 256);
+        P.push(L);
+    }
+    // encoder: conv1 has no activation (use_relu=False), the others LeakyReLU(0.2) on their input (unets.py:72-78, 22-23)
+    for (int l = 0; l < 6; ++l) {
+        const Tensor &in = l == 0 ? x0 : s2d[l - 1];
+        Tensor &cat = *cats[l];
+        conv(dn[l], in, l == 0 ? 1.0f : 0.2f, OutSpec{cat.data, OUT_NORMAL, cat.C, cat.C - dn[l].cout}, OutSpec{s2d[l].data, OUT_S2D, s2d[l].C, 0});
+    }
+    conv(dn[6], s2d[5], 0.2f, OutSpec{d7.data, OUT_NORMAL, d7.C, 0}, OutSpec{});
+    // decoder: ReLU on the (concatenated) input, transposed convolutions scattered into the up part of the next concatenation
+    conv(e->u_up[0], d7, 0.0f, OutSpec{cat1.data, OUT_D2S, cat1.C, 0}, OutSpec{});
+    conv(e->u_up[1], cat1, 0.0f, OutSpec{cat2.data, OUT_D2S, cat2.C, 0}, OutSpec{});
+    conv(e->u_up[2], cat2, 0.0f, OutSpec{cat3.data, OUT_D2S, cat3.C, 0}, OutSpec{});
+    conv(e->u_up[2], cat3, 0.0f, OutSpec{cat4.data, OUT_D2S, cat4.C, 0}, OutSpec{});               // upconv3 again, not upconv4 (unets.py:213-214)
+    auto up2 = [&](const Tensor &x) {
+        Tensor u = P.tensor(2 * x.H, 2 * x.W, x.C);
+        if (P.rc) return u;
+        Launch L{}; L.kind = L_UP2;
+        L.up2 = Up2Args{x.data, u.data, x.H, x.W, x.C};
+        L.grid = (unsigned)(((size_t)4 * x.H * x.W * (x.C / 4) + 255) / 256);
+        P.push(L);
+        return u;
+    };
+    Tensor out = P.tensor(Hin, Win, e->u_upc[2].cout);
+    conv(e->u_upc[0], up2(cat4), 1.0f, OutSpec{cat5.data, OUT_NORMAL, cat5.C, 0}, OutSpec{});      // the ReLU went into the upsample
+    conv(e->u_upc[1], up2(cat5), 1.0f, OutSpec{cat6.data, OUT_NORMAL, cat6.C, 0}, OutSpec{});
+    conv(e->u_upc[2], up2(cat6), 1.0f, OutSpec{out.data, OUT_NORMAL, out.C, 0}, OutSpec{});
+    e->out = out;
+    e->plan_allocs = P.allocs;
+    if (P.rc) { free_plan(e); return P.rc; }
+    e->Hin = Hin; e->Win = Win; e->fork = ctx->opt.enc_fork; e->ksplit = ctx->opt.enc_ksplit;
+    if (ctx->opt.enc_graph) {
+        if (!e->cap_stream) AVC_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+        AVC_HIP(hipDeviceSynchronize());                    // the zero-fills of the plan's buffers (null stream) are done
+        if (int rc = run_plan(e, e->cap_stream)) { free_plan(e); return rc; }
+        AVC_HIP(hipStreamSynchronize(e->cap_stream));
+        AVC_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = run_plan(e, e->cap_stream);
+        hipGraph_t g = nullptr;
+        const hipError_t ee = hipStreamEndCapture(e->cap_stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); free_plan(e); return rc; }
+        AVC_HIP(ee);
+        e->graph = g;
+        AVC_HIP(hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
+    } else {
+        AVC_HIP(hipDeviceSynchronize());
+    }
+    return AVC_OK;
+}
+
+int unet_forward(avc_ctx *ctx, const float *pos_map, int H, int W, float *out_nchw, int bind, hipStream_t s)
+{
+    Encoder *e = static_cast<Encoder *>(ctx->unet);
+    AVC_REQUIRE(e && e->packed, AVC_ERR_STATE, "avc_unet_forward: no U-Net weights (call avc_unet_pack first)");
+    AVC_REQUIRE(pos_map, AVC_ERR_ARG, "avc_unet_forward: NULL position map");
+    if (e->Hin != H || e->Win != W || e->ksplit != ctx->opt.enc_ksplit || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
+        AVC_HIP(hipDeviceSynchronize());
+        if (int rc = build_unet_plan(ctx, e, H, W)) return rc;
+    }
+    AVC_HIP(hipMemcpyAsync(e->in_buf, pos_map, sizeof(float) * 6 * (size_t)H * W, hipMemcpyDeviceToDevice, s));
+    if (ctx->check_range) AVC_HIP(hipMemsetAsync(e->range_flag, 0, sizeof(unsigned), s));
+    if (e->exec) AVC_HIP(hipGraphLaunch(e->exec, s));
+    else if (int rc = run_plan(e, s)) return rc;
+    if (ctx->check_range) {
+        unsigned flag = 0;
+        AVC_HIP(hipMemcpyAsync(&flag, e->range_flag, sizeof flag, hipMemcpyDeviceToHost, s));
+        AVC_HIP(hipStreamSynchronize(s));
+        AVC_REQUIRE(flag == 0, AVC_ERR_RANGE, "avc_unet_forward: an activation exceeded 65504 / 16 in magnitude -- outside the range of the split-fp16 arithmetic "
+                    "(include/avcap.h, 'numeric range'); the pose feature map of this call is not valid");
+    }
+    const Tensor &o = e->out;
+    const int HW = o.H * o.W;
+    if (out_nchw) hipLaunchKernelGGL(hwc_to_nchw_kernel, dim3((HW + 63) / 64, (o.C + 63) / 64), dim3(256), 0, s, o.data, out_nchw, o.C, HW);
+    if (bind) {
+        AVC_REQUIRE(o.C == 64, AVC_ERR_ARG, "avc_unet_forward: the avatar query samples 64 pose-feature channels, this U-Net produces %d", o.C);
+        if (!ctx->pose_feat_hwc || ctx->pose_C != o.C || ctx->pose_H != o.H || ctx->pose_W != o.W) {
+            AVC_HIP(hipStreamSynchronize(s));
+            if (ctx->pose_feat_hwc) AVC_HIP(hipFree(ctx->pose_feat_hwc));
+            ctx->pose_feat_hwc = nullptr;
+            AVC_HIP(hipMalloc((void **)&ctx->pose_feat_hwc, sizeof(float) * (size_t)o.C * HW));
+            ctx->pose_C = o.C; ctx->pose_H = o.H; ctx->pose_W = o.W;
+        }
+        AVC_HIP(hipMemcpyAsync(ctx->pose_feat_hwc, o.data, sizeof(float) * (size_t)o.C * HW, hipMemcpyDeviceToDevice, s));
+    }
+    AVC_HIP(hipGetLastError());
+    return AVC_OK;
+}
+
+void release_unet(avc_ctx *ctx)
+{
+    Encoder *e = static_cast<Encoder *>(ctx->unet);
+    if (!e) return;
+    free_plan(e);
+    free_weights(e);
+    if (e->cap_stream) hipStreamDestroy(e->cap_stream);
+    if (e->side_stream) hipStreamDestroy(e->side_stream);
+    delete e;
+    ctx->unet = nullptr;
 }
 
 }  // namespace enc

@@ -1,28 +1,13 @@
-"""Pose-feature producer: the 7-level U-Net of the warping field (reference `UnetNoCond7DS`,
-network/unets.py:169-229).  Runs once per frame on PyTorch-ROCm / MIOpen (SURVEY.md section 2 row 4:
-10.35 GFLOP, not the hot loop); its *sampling* is fused into the HIP query kernel.
+"""Pose-feature producer: the 7-level U-Net of the warping field (reference `UnetNoCond7DS`, network/unets.py:169-229), once per frame.
 
-state_dict-compatible with the reference (50 keys incl. the dead `upconv4.*`).
+The modules below are WEIGHT CONTAINERS, state_dict-compatible with the reference (50 keys incl. the dead `upconv4.*`); the arithmetic is the
+hand-written gfx950 encoder (csrc/conv_enc.hip, `avc_unet_pack` / `avc_unet_forward`): 18 launches of the split-fp16 MFMA convolution kernel in one
+hipGraph -- stride-2 convolutions as 3x3 convolutions of space-to-depth tensors, transposed convolutions as 3x3 convolutions with parity-major outputs,
+BatchNorm folded into the weights, activations applied while staging, concatenations written in place.  There is no CPU / PyTorch path: a CPU tensor
+raises.  The stock-torch restatement the tests hold the kernels to is tests/torch_unet.py.
 """
-import contextlib
-
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
-
-
-@contextlib.contextmanager
-def deterministic_convs():
-    """MIOpen picks an atomics-based transposed-convolution kernel for this U-Net by default: the pose feature map then differs by ~2e-6
-    from call to call, which is enough to move a marching-cubes vertex count by a few units between two runs of the same frame.  With
-    PyTorch's deterministic flag MIOpen is asked for deterministic solutions only (bit-identical across calls, and 10 % faster here:
-    tools/determinism_producers.py).  The flag is restored on exit."""
-    prev = torch.backends.cudnn.deterministic
-    torch.backends.cudnn.deterministic = True
-    try:
-        yield
-    finally:
-        torch.backends.cudnn.deterministic = prev
 
 
 class _Down(nn.Module):
@@ -35,12 +20,6 @@ class _Down(nn.Module):
         self.conv = nn.Conv2d(cin, cout, 4, 2, 1, bias=False)
         if bn:
             self.bn = nn.BatchNorm2d(cout, affine=False)
-
-    def forward(self, x):
-        if self.act:
-            x = F.leaky_relu(x, 0.2)
-        x = self.conv(x)
-        return self.bn(x) if hasattr(self, 'bn') else x
 
 
 class _Up(nn.Module):
@@ -57,17 +36,13 @@ class _Up(nn.Module):
         if bn:
             self.bn = nn.BatchNorm2d(cout, affine=False)
 
-    def forward(self, x, skip=None):
-        x = self.up(F.relu(x))
-        if hasattr(self, 'bn'):
-            x = self.bn(x)
-        return x if skip is None else torch.cat([x, skip], 1)
-
 
 class UnetNoCond7DS(nn.Module):
     def __init__(self, input_nc=3, output_nc=3, nf=64, up_mode='upconv', use_dropout=False):
         super().__init__()
         assert up_mode == 'upconv' and not use_dropout, 'only the configuration the reference instantiates'
+        if input_nc > 8 or output_nc % 32 or nf % 32:
+            raise NotImplementedError('the HIP U-Net takes <= 8 input channels and channel counts that are multiples of 32 (the reference: 6 -> 64, nf 32)')
         w = [nf, 2 * nf, 4 * nf, 8 * nf, 8 * nf, 8 * nf, 8 * nf]
         self.conv1 = _Down(input_nc, w[0], bn=False, act=False)
         for i in range(1, 7):
@@ -79,63 +54,50 @@ class UnetNoCond7DS(nn.Module):
         self.upconvC5 = _Up(12 * nf, 2 * nf, 'upsample')
         self.upconvC6 = _Up(4 * nf, nf, 'upsample')
         self.upconvC7 = _Up(2 * nf, output_nc, 'upsample', bn=False, bias=True)
+        self.output_nc = output_nc
+        self._packed = None
 
-    def forward(self, x):
-        """On the HIP device the ~70 MIOpen launches of one pass (0.7 ms of kernels that the host needs ~1.4 ms to enqueue -- more when eight ranks share a
-        host) are recorded ONCE per input shape and set of weights as a hipGraph and replayed with one launch per frame (`config.unet_graph`): the same
-        kernels on the same arguments, bit for bit the eager pass (tests/test_gpu_producers.py).  The result is a fresh tensor, not the graph's buffer."""
-        from .. import config
-        if x.is_cuda and getattr(config, 'unet_graph', True) and not (torch.is_grad_enabled() and x.requires_grad):
-            y = self._graph_forward(x)
-            if y is not None:
-                return y
-        with deterministic_convs():
-            return self._forward(x)
-
-    def __getstate__(self):                    # a captured graph belongs to this process and these buffers: never pickled / deep-copied
+    def __getstate__(self):                    # the packed weights belong to this process's device context: never pickled / deep-copied
         d = dict(self.__dict__)
-        d.pop('_graph', None); d.pop('_graph_failed', None)
+        d['_packed'] = None
         return d
 
-    def _graph_forward(self, x):
-        key = (tuple(x.shape), x.dtype, x.device, tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()),
+    def _ctx(self, device):
+        """The device's context with THIS module's weights packed (again after load_state_dict / in-place edits / another module's pack)."""
+        from .. import _lib
+        ctx = _lib.ctx(device)
+        ver = (ctx, id(self), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()),
                tuple(b._version for b in self.buffers()))
-        g = self.__dict__.get('_graph')
-        if g is None or g['key'] != key:
-            if self.__dict__.get('_graph_failed') == key:
-                return None
-            try:
-                with torch.no_grad():
-                    static_in = x.detach().clone()
-                    side = torch.cuda.Stream(device=x.device)
-                    side.wait_stream(torch.cuda.current_stream(x.device))
-                    with torch.cuda.stream(side), deterministic_convs():
-                        for _ in range(2):          # MIOpen's solution search and workspaces settle before the capture
-                            self._forward(static_in)
-                    torch.cuda.current_stream(x.device).wait_stream(side)
-                    graph = torch.cuda.CUDAGraph()
-                    with deterministic_convs(), torch.cuda.graph(graph):
-                        out = self._forward(static_in)
-                g = {'key': key, 'graph': graph, 'in': static_in, 'out': out}
-                self.__dict__['_graph'] = g
-            except Exception as e:              # noqa: BLE001 -- a capture the runtime refuses: the eager launches of the same kernels, and say so once
-                import warnings
-                warnings.warn(f'UNet7DS: hipGraph capture failed ({type(e).__name__}: {e}); launching eagerly')
-                self.__dict__['_graph_failed'] = key
-                self.__dict__.pop('_graph', None)
-                return None
-        g['in'].copy_(x)
-        g['graph'].replay()
-        return g['out'].clone()
+        if self._packed != ver or not _lib.owns(ctx, 'unet', ver):
+            w = _lib.UNetWeights(self)
+            _lib.check(_lib.lib().avc_unet_pack(ctx, w.struct))
+            self._packed = ver
+            _lib.set_owner(ctx, 'unet', ver)
+        _lib.apply_range_check(ctx)
+        return ctx
 
-    def _forward(self, x):
-        d = [x]
-        for i in range(1, 8):
-            d.append(getattr(self, f'conv{i}')(d[-1]))
-        u = self.upconv1(d[7], d[6])
-        u = self.upconv2(u, d[5])
-        u = self.upconv3(u, d[4])
-        u = self.upconv3(u, d[3])                      # reference quirk: upconv3 applied twice (unets.py:213-214)
-        u = self.upconvC5(u, d[2])
-        u = self.upconvC6(u, d[1])
-        return self.upconvC7(u)
+    def forward(self, x, bind=False):
+        """x (B, 6, H, W) float32 on the HIP device, H and W multiples of 128 -> (B, output_nc, H, W)   (unets.py:201-229, eval mode: BatchNorm on
+        its running statistics).  bind=True (B == 1) also makes the result the context's pose feature map without the NCHW round trip."""
+        from .. import _lib
+        if not x.is_cuda:
+            raise RuntimeError('UnetNoCond7DS runs on the HIP device only (csrc/conv_enc.hip); there is no CPU path')
+        if self.training:
+            raise RuntimeError('UnetNoCond7DS: inference only (eval mode: BatchNorm2d on running statistics); call .eval()')
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise RuntimeError('UnetNoCond7DS: inference only -- no gradient flows through the HIP encoder (training is out of scope, SURVEY.md section 2)')
+        if bind and x.shape[0] != 1:
+            raise ValueError('UnetNoCond7DS.forward(bind=True): one frame at a time (B == 1)')
+        x = x.contiguous().float()
+        B, C, H, W = x.shape
+        if C != self.conv1.conv.in_channels:
+            raise ValueError(f'UnetNoCond7DS: {C} input channels, the module was built for {self.conv1.conv.in_channels}')
+        if C != 6:
+            raise NotImplementedError('the HIP U-Net reads the 6-channel SMPL position map (front | back xyz, arch_avatar.py:95)')
+        from .. import config
+        _lib.set_option('enc_graph', 1 if getattr(config, 'hg_graph', True) else 0, x.device)
+        ctx = self._ctx(x.device)
+        y = torch.empty((B, self.output_nc, H, W), dtype=torch.float32, device=x.device)
+        for b in range(B):
+            _lib.check(_lib.lib().avc_unet_forward(ctx, x[b].data_ptr(), H, W, y[b].data_ptr(), 1 if bind else 0, _lib.stream_ptr(x.device)))
+        return y

@@ -113,8 +113,30 @@ int avc_hgfilter_pack(avc_ctx *ctx, const avc_hgfilter *net);
 int avc_hgfilter_forward(avc_ctx *ctx, const float *image_dev, int H, int W, float *feat_out_dev, float *normx_out_dev,
                          int bind_img_feat_map, avc_stream stream);
 
+/* ---- the warping field's U-Net -------------------------------------------------------------------
+ * WarpingField.unet = UnetNoCond7DS(input_nc 6, output_nc 64, nf 32, 'upconv') (network/arch_avatar.py:95; network/unets.py:169-229, blocks :10-60) on
+ * the encoder's convolution kernel: every stride-2 convolution is a 3x3 convolution of a space-to-depth tensor its producer wrote in that form, every
+ * transposed convolution a 3x3 convolution with 4 x parity-major outputs scattered by the epilogue, BatchNorm2d(affine=False, eval) folded into the
+ * weights, the pre-activations (LeakyReLU(0.2) / ReLU) applied while the input is staged, torch.cat free (producers write their channel slice): 18
+ * launches in one hipGraph.  The reference's quirk is kept: upconv3 is applied twice, upconv4 never (unets.py:213-214).
+ *   avc_bn2d     running mean / var of a BatchNorm2d(affine=False); mean == NULL: the layer has no norm (conv1, conv7, upconvC7)
+ *   avc_unet7ds  down[7]: conv1..7 weights (cout, cin, 4, 4), no bias; up[3]: upconv1..3 ConvTranspose2d weights as stored, (cin, cout, 4, 4) with
+ *                avc_conv2d.cin / cout the module's in / out channels; upc[3]: upconvC5..C7 (cout, cin, 3, 3) + bias. */
+typedef struct { const float *mean, *var; float eps; } avc_bn2d;
+typedef struct {
+    avc_conv2d down[7]; avc_bn2d down_bn[7];
+    avc_conv2d up[3]; avc_bn2d up_bn[3];
+    avc_conv2d upc[3]; avc_bn2d upc_bn[3];
+} avc_unet7ds;
+int avc_unet_pack(avc_ctx *ctx, const avc_unet7ds *net);
+/* UnetNoCond7DS.forward for one position map: pos_map_dev (6, H, W) NCHW (batch['smpl_pos_map'][b]; H, W multiples of 128: 256 in the reference) ->
+ * out_nchw_dev (64, H, W) or NULL; with bind_pose_feat_map != 0 the result becomes the context's pose feature map (avc_set_pose_feat_map) without the
+ * NCHW round trip -- WarpingField.precompute_conv (network/arch_avatar.py:109-111). */
+int avc_unet_forward(avc_ctx *ctx, const float *pos_map_dev, int H, int W, float *out_nchw_dev, int bind_pose_feat_map, avc_stream stream);
+
 /* Test hook: the output of launch `launch` of the last avc_hgfilter_forward's plan (which = 0: the launch's own output, 1: the block output y
- * it adds its slice to) as NCHW; *C, *H, *W receive its shape (for a convolution *C also carries the tile configuration in its high bits).
+ * it adds its slice to; which = 2: launch `launch` of the last avc_unet_forward's plan -- the WHOLE destination tensor the launch wrote its channel
+ * slice of) as NCHW; *C, *H, *W receive its shape (for a convolution *C also carries the tile configuration in its high bits).
  * out_nchw_dev may be NULL (shape query).  Returns 1 when the launch has no such output, a negative status on errors. */
 int avc_hgfilter_debug_tensor(avc_ctx *ctx, int launch, int which, float *out_nchw_dev, int32_t *C, int32_t *H, int32_t *W, avc_stream stream);
 

@@ -1,4 +1,4 @@
-"""The two per-frame convolutional producers ON THE GPU (the U-Net on MIOpen, HGFilter on the hand-written HIP encoder) against goldens produced
+"""The two per-frame convolutional producers ON THE GPU (the U-Net and HGFilter, both on the hand-written HIP encoder) against goldens produced
 by the reference's own modules on the CPU: UnetNoCond7DS (network/unets.py:169-229) at 128^2 and at its real 256^2 input,
 HGFilter (network/HGFilters.py:124-219) at 64^2 and at its real 512^2 input, and ReconNetwork.infer end to end (arch_recon.py:45-76).
 Bar: north_star's 1e-4 on O(1) outputs (relative to max(1, |golden|_max)); the measured errors are printed.  Also: the producers must give
@@ -25,47 +25,115 @@ def _rel(got, gold):
     return maxabs(got, gold) / max(1.0, float(np.abs(gold).max()))
 
 
-def test_unet7ds_on_miopen_matches_reference(golden):
+def _unet(seed=gi.SEED_NET):
     from avatarcap_amd.network.unets import UnetNoCond7DS
     un = UnetNoCond7DS(input_nc=6, output_nc=64, nf=32).to('cuda').eval()
-    syn.load_synth(un, gi.SEED_NET)
+    syn.load_synth(un, seed)
+    return un
+
+
+def test_unet7ds_on_hip_matches_reference(golden):
+    """UnetNoCond7DS.forward on the hand-written convolution kernel against goldens of the reference's own module on the CPU (128^2 and the real
+    256^2 position map), and: first call == later calls bit for bit; the module refuses what it does not implement."""
+    un = _unet()
     with torch.no_grad():
         for res, gold in ((128, golden['G7_unet_samples']), (256, PG['G7_unet256_samples'])):
             y = un(_t(gi.pos_map(res)[None]))[0]
             assert y.shape == (64, res, res)
             got = y[:, torch.from_numpy(gi.PIX[:, 0] % res).cuda(), torch.from_numpy(gi.PIX[:, 1] % res).cuda()].cpu().numpy()
             e = _rel(got, gold)
-            print(f'UNet7DS {res}^2 on MIOpen vs reference (CPU): {e:.3e} relative to max(1, |g|max = {np.abs(gold).max():.2f})')
+            print(f'UNet7DS {res}^2 on the HIP encoder vs reference (CPU): {e:.3e} relative to max(1, |g|max = {np.abs(gold).max():.2f})')
             assert e < 1e-4
         assert abs(float(y.abs().mean()) / float(PG['G7_unet256_absmean']) - 1) < 1e-5
-        first = un(_t(gi.pos_map(256, seed=77)[None])).clone()               # a shape / input MIOpen has not seen in this process
+        first = un(_t(gi.pos_map(256, seed=77)[None])).clone()
         again = un(_t(gi.pos_map(256, seed=77)[None]))
         assert torch.equal(first, again), float((first - again).abs().max())  # first call == later calls, bit for bit
+        two = un(torch.cat([_t(gi.pos_map(256, seed=77)[None]), _t(gi.pos_map(256)[None])]))        # a batch is a loop over items
+        assert torch.equal(two[0], first[0]) and torch.equal(two[1], y)
+        with pytest.raises(RuntimeError, match='HIP device only'):
+            un(torch.from_numpy(gi.pos_map(128)[None]))
+        with pytest.raises(Exception, match='multiples of 128'):
+            un(_t(gi.pos_map(256)[None, :, :192, :192]))
+        un.train()
+        with pytest.raises(RuntimeError, match='eval'):
+            un(_t(gi.pos_map(128)[None]))
 
 
-def test_unet_graph_replay_equals_eager_launches():
-    """UnetNoCond7DS.forward replays a hipGraph (config.unet_graph): bit for bit the eager pass, fresh output tensors, a second input through the same
-    graph, new weights picked up; the module still deep-copies and pickles."""
+@pytest.mark.parametrize('res', [128, 256])
+def test_unet_launch_by_launch(res):
+    """Every launch of the U-Net's plan (csrc/conv_enc.hip: 1 space-to-depth, 7 + 4 + 3 convolutions, 3 bilinear upsamples) against the stock-torch
+    restatement of the tensor it wrote (tests/torch_unet.py, fp32 on the same device).  The convolutions write channel slices of the concatenated
+    decoder tensors: an encoder level is compared on its slice, a decoder level on the whole concatenation."""
+    import ctypes as C
+    from avatarcap_amd import _lib
+    from torch_unet import unet7ds_trace
+    un = _unet()
+    x = _t(gi.pos_map(res)[None])
+    with torch.no_grad():
+        y = un(x)
+        torch.cuda.synchronize()
+        trace = unet7ds_trace(un, x)
+    ctx, L = _lib.ctx(x.device), _lib.lib()
+
+    def fetch(launch):
+        c, h, w = C.c_int32(), C.c_int32(), C.c_int32()
+        rc = L.avc_hgfilter_debug_tensor(ctx, launch, 2, None, C.byref(c), C.byref(h), C.byref(w), None)
+        assert rc == 0, (launch, rc, L.avc_last_error())
+        got = torch.empty((c.value & 0xffff, h.value, w.value), dtype=torch.float32, device='cuda')
+        _lib.check(L.avc_hgfilter_debug_tensor(ctx, launch, 2, got.data_ptr(), C.byref(c), C.byref(h), C.byref(w), _lib.stream_ptr(x.device)))
+        torch.cuda.synchronize()
+        cfg = c.value >> 16
+        return got, (f'CT{cfg & 15} PT{(cfg >> 4) & 15}{" splitK" if cfg >> 14 else ""}' if cfg else '')
+    # launch index of every traced tensor: [s2d, conv1..7, upconv1, 2, 3, 3, up2, C5, up2, C6, up2, C7]
+    launches = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17]
+    worst, bad = 0.0, []
+    for (name, ref), launch in zip(trace, launches):
+        got, cfg = fetch(launch)
+        ref = ref[0]
+        if name.startswith('conv') and name != 'conv7':                       # the skip slice of the decoder tensor
+            got = got[-ref.shape[0]:]
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        e = float((got - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        print('  launch %3d %-18s %-18s %-14s %.3e' % (launch, name, tuple(ref.shape), cfg, e))
+        if not e < 1e-4:
+            bad.append((launch, name, e))
+        worst = max(worst, e)
+    assert not bad, f'first launch off: {bad[0]}'
+    assert torch.equal(fetch(17)[0], y[0])
+    print(f'UNet7DS {res}^2, HIP plan vs stock torch ops launch by launch: worst {worst:.3e} (relative to max(1, |ref|max))')
+
+
+def test_unet_graph_replay_equals_plain_launches():
+    """avc_unet_forward replays a hipGraph (config.hg_graph): bit for bit the plain launches of the same kernels, with and without split-K the results
+    agree to rounding, fresh output tensors, new weights and a second module are picked up; the module deep-copies and pickles."""
     import copy
     import pickle
-    from avatarcap_amd.network.unets import UnetNoCond7DS
-    un = UnetNoCond7DS(input_nc=6, output_nc=64, nf=32).to('cuda').eval()
-    syn.load_synth(un, gi.SEED_NET)
+    from avatarcap_amd import _lib
+    un = _unet()
     a, b = _t(gi.pos_map(256, seed=77)[None]), _t(gi.pos_map(256, seed=78)[None])
     with torch.no_grad():
-        config.unet_graph = False
+        config.hg_graph = False
         try:
             ea, eb = un(a).clone(), un(b).clone()
         finally:
-            config.unet_graph = True
+            config.hg_graph = True
         ga = un(a)
-        assert un.__dict__.get('_graph') is not None and un.__dict__.get('_graph_failed') is None       # captured, not fallen back
         gb = un(b)
         assert torch.equal(ga, ea) and torch.equal(gb, eb) and ga.data_ptr() != gb.data_ptr()
+        _lib.set_option('enc_ksplit', 0, a.device)
+        try:
+            na = un(a)
+        finally:
+            _lib.set_option('enc_ksplit', 1, a.device)
+        assert float((na - ea).abs().max()) < 1e-5 * max(1.0, float(ea.abs().max()))
+        assert torch.equal(un(a), ea)
         un2 = pickle.loads(pickle.dumps(copy.deepcopy(un)))
-        assert '_graph' not in un2.__dict__ and torch.equal(un2(a), ea)
+        assert un2._packed is None and torch.equal(un2(a), ea)
+        other = _unet(gi.SEED_NET + 5)
+        oa = other(a)
+        assert not torch.equal(oa, ea) and torch.equal(un(a), ea)             # two modules share the context: each call runs on its own weights
         syn.load_synth(un, gi.SEED_NET + 5)
-        assert not torch.equal(un(a), ea)
+        assert torch.equal(un(a), oa)
 
 
 def _hg():

@@ -77,14 +77,15 @@ def test_config_surface(tmp_path):
 
 
 def test_producers_match_reference_golden(golden):
-    """UNet7DS (incl. the upconv3-twice quirk) vs the reference on CPU; the HGFilter weight container carries the reference's tensors, and the
+    """The stock-torch restatement of UNet7DS (incl. the upconv3-twice quirk; tests/torch_unet.py) vs the reference on CPU; the HGFilter weight container carries the reference's tensors, and the
     stock-torch restatement the GPU tests hold the HIP encoder to launch by launch (tests/torch_hgfilter.py) reproduces the reference's golden."""
     from avatarcap_amd.network.unets import UnetNoCond7DS
     from avatarcap_amd.network.HGFilters import HGFilter
     torch.set_grad_enabled(False)
     un = UnetNoCond7DS(input_nc=6, output_nc=64, nf=32).eval()
     syn.load_synth(un, gi.SEED_NET)
-    y = un(torch.from_numpy(gi.pos_map(128)[None])).numpy()[0]
+    from torch_unet import unet7ds_torch
+    y = unet7ds_torch(un, torch.from_numpy(gi.pos_map(128)[None])).numpy()[0]      # the restatement the GPU tests hold the HIP U-Net to
     g = golden['G7_unet_samples']
     assert maxabs(y[:, gi.PIX[:, 0] % 128, gi.PIX[:, 1] % 128], g) < 1e-4 * max(1.0, np.abs(g).max())
     hg = HGFilter(1, 4, 6, 32, 'group', 'no_down', False).eval()
@@ -97,6 +98,8 @@ def test_producers_match_reference_golden(golden):
     assert len(trace) == 2 + 4 + 3 + 4 + (13 * 3 + 4 + 4) + 3 + 2          # one entry per tensor-producing launch of the HIP plan
     with pytest.raises(RuntimeError, match='HIP device only'):             # the encoder has no CPU / PyTorch path
         hg(torch.from_numpy(gi.normal_maps(64)[None]))
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        un(torch.from_numpy(gi.pos_map(128)[None]))
     with pytest.raises(NotImplementedError):
         HGFilter(2, 4, 6, 32, 'group', 'conv64', False)
 

@@ -101,7 +101,7 @@ int main(int argc, char **argv)
         ConvArgs &a = L.conv;
         a.x = dev_random((size_t)H * W * Cin, -2.f, 2.f, 2); a.H = H; a.W = W; a.Cin = Cin;
         a.in_part2 = dev_part2(32); a.in_nb = 32; a.in_inv_n = 1.0f / 32; a.in_eps = 1e-5f;
-        a.gamma = dev_random(Cin, 0.5f, 1.5f, 4); a.beta = dev_random(Cin, -0.5f, 0.5f, 5); a.in_cpg = Cin / 32; a.in_scale = 16.f;
+        a.gamma = dev_random(Cin, 0.5f, 1.5f, 4); a.beta = dev_random(Cin, -0.5f, 0.5f, 5); a.in_cpg = Cin / 32; a.in_scale = 16.f; a.in_slope = 1.0f;
         const int v = CT == 4 ? 2 : (CT == 2 ? 1 : 0);
         a.slice_bytes = (unsigned)(Cin / 32) * taps * 2 * CT * 2048;
         a.wstream = dc.wstream + dc.off[v]; a.wbytes = a.slice_bytes * (Cout / (32 * CT));
