@@ -58,6 +58,7 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_in
 constexpr int PIXB = 144;                       // bytes per staged pixel: 32 channels x (hi, lo) halves + 16 pad (odd multiple of 16: conflict-free b128 reads)
 constexpr int RING_SLOT = 16384;                // one slot of the weight ring: a group of 4 / CT taps
 constexpr int MAX_CIN = 1024;               // input channels of one convolution (the U-Net's space-to-depth layers reach 1024)
+constexpr int MAX_NORM_CIN = 256;           // ... of one whose input goes through a GroupNorm: its (a, b) per channel sit in LDS
 
 // GroupNorm statistics (torch.nn.GroupNorm: mean and biased variance over (C / G, H, W)) travel from the launch that produces a tensor to the
 // launches that consume it as a table of at most 32 partial (sum, sum of squares) pairs per group, in double: [group][bucket].  A bucket is
@@ -214,9 +215,9 @@ struct ConvGeo {
     static constexpr int RP = TAPS == 1 ? TWC : (TWC == 32 ? HC : 32);       // LDS row pitch in pixels (32 for the 16-wide tiles: bank note in DESIGN.md)
     static constexpr int NPIX = HR * RP;
     static constexpr int ACTB = (NPIX * PIXB + 1023) & ~1023;
-    static constexpr int RS_FIT = (163840 - 8 * MAX_CIN - 64 - 256 - 2 * ACTB) / RING_SLOT;
+    static constexpr int RS_FIT = (163840 - 8 * MAX_NORM_CIN - 64 - 256 - 2 * ACTB) / RING_SLOT;
     static constexpr int RS = RS_FIT > 6 ? 6 : RS_FIT;            // ring slots; RS - 1 groups of weights are in flight
-    static constexpr int L_ACT0 = 0, L_ACT1 = ACTB, L_RING = 2 * ACTB, L_AB = L_RING + RS * RING_SLOT, L_FLAG = L_AB + 8 * MAX_CIN, L_TOTAL = L_FLAG + 64 + 256;     // (flag, then (mean, rstd) of the input's 32 groups)
+    static constexpr int L_ACT0 = 0, L_ACT1 = ACTB, L_RING = 2 * ACTB, L_AB = L_RING + RS * RING_SLOT, L_FLAG = L_AB + 8 * MAX_NORM_CIN, L_TOTAL = L_FLAG + 64 + 256;     // (flag, then (mean, rstd) of the input's 32 groups)
     static_assert(RS >= 3, "no room for the weight ring");
 };
 
@@ -246,15 +247,12 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
             *reinterpret_cast<f32x2 *>(smem + LDS_FLAG + 64 + tid * 8) = fold_group(p.in_part2 + (size_t)tid * p.in_nb * 2, p.in_nb, p.in_inv_n, p.in_eps);
         __syncthreads();
     }
-    for (int c = tid; c < p.Cin; c += 256) {
-        float a = p.in_scale, b = 0.0f;
-        if constexpr (NORM) {
-            const f32x2 mr = *reinterpret_cast<const f32x2 *>(smem + LDS_FLAG + 64 + (c / p.in_cpg) * 8);
-            a = p.gamma[c] * mr[1];
-            b = (p.beta[c] - mr[0] * a) * p.in_scale;
-            a *= p.in_scale;
+    if constexpr (NORM) {                                  // (raw inputs: a = in_scale, b = 0 for every channel -- no table, any Cin)
+        if (tid < p.Cin) {
+            const f32x2 mr = *reinterpret_cast<const f32x2 *>(smem + LDS_FLAG + 64 + (tid / p.in_cpg) * 8);
+            const float a = p.gamma[tid] * mr[1];
+            *reinterpret_cast<f32x2 *>(smem + LDS_AB + tid * 8) = f32x2{a * p.in_scale, (p.beta[tid] - mr[0] * a) * p.in_scale};
         }
-        *reinterpret_cast<f32x2 *>(smem + LDS_AB + c * 8) = f32x2{a, b};
     }
 
     // ---- staging geometry of this thread: piece i = 4 channels `sub` of staged pixel sp = tid / 8 + 32 i
@@ -287,8 +285,11 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
     };
     // pieces [i0, i1) of the staged chunk c: affine + ReLU + split -> LDS buffer `buf`
     auto store_acts = [&](int c, unsigned buf, int i0, int i1) {
-        const f32x4 ab0 = *reinterpret_cast<const f32x4 *>(smem + LDS_AB + (c * 32 + sub * 4) * 8);
-        const f32x4 ab1 = *reinterpret_cast<const f32x4 *>(smem + LDS_AB + (c * 32 + sub * 4) * 8 + 16);
+        f32x4 ab0 = {p.in_scale, 0.0f, p.in_scale, 0.0f}, ab1 = ab0;
+        if constexpr (NORM) {
+            ab0 = *reinterpret_cast<const f32x4 *>(smem + LDS_AB + (c * 32 + sub * 4) * 8);
+            ab1 = *reinterpret_cast<const f32x4 *>(smem + LDS_AB + (c * 32 + sub * 4) * 8 + 16);
+        }
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) {
             if (i < i0 || i >= i1) continue;
@@ -471,22 +472,26 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         for (int n = 0; n < PT; ++n)
 #pragma unroll
             for (int m = 0; m < CT; ++m) {
-                u64 val[8][8];                                 // [k slice (at most 8)][piece]: every load of a tile is issued before the first add
+                float lo[8], hi[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
+                for (int v = 0; v < 8; ++v) lo[v] = hi[v] = 0.0f;
+                for (int kb = 0; kb < p.ksplit; kb += 8) {         // 8 slices at a time: every load of a batch is issued before the first add
+                    u64 val[8][8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+#pragma unroll
+                        for (int v = 0; v < 8; ++v)
+                            val[k][v] = kb + k < p.ksplit ? __hip_atomic_load(all + ((size_t)(kb + k) * NV + (n * CT + m) * 8 + v) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 #pragma unroll
                     for (int v = 0; v < 8; ++v)
-                        val[k][v] = k < p.ksplit ? __hip_atomic_load(all + ((size_t)k * NV + (n * CT + m) * 8 + v) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 #pragma unroll
-                for (int v = 0; v < 8; ++v) {
-                    float lo = 0.0f, hi = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        lo += __builtin_bit_cast(float, (unsigned)val[k][v]);
-                        hi += __builtin_bit_cast(float, (unsigned)(val[k][v] >> 32));
-                    }
-                    acc[n][m][2 * v] = lo; acc[n][m][2 * v + 1] = hi;
+                        for (int k = 0; k < 8; ++k) {
+                            lo[v] += __builtin_bit_cast(float, (unsigned)val[k][v]);
+                            hi[v] += __builtin_bit_cast(float, (unsigned)(val[k][v] >> 32));
+                        }
                 }
+#pragma unroll
+                for (int v = 0; v < 8; ++v) { acc[n][m][2 * v] = lo[v]; acc[n][m][2 * v + 1] = hi[v]; }
             }
         __syncthreads();
     }
@@ -550,33 +555,45 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         }
     };
     // the U-Net's outputs: any layout, no residual, no statistics; these launches are small (the whole U-Net is 10 GFLOP), the addressing is per element
-    if (p.oa.ptr) {
-        auto put = [&](const OutSpec &o, int iy, int ix, unsigned co, float v) {
-            if (o.layout == OUT_NORMAL) o.ptr[((size_t)iy * p.W + ix) * o.C + o.coff + co] = v;
-            else if (o.layout == OUT_S2D) o.ptr[((size_t)(iy >> 1) * (p.W >> 1) + (ix >> 1)) * o.C + (((iy & 1) * 2 + (ix & 1)) * (o.C >> 2)) + o.coff + co] = v;
-            else if (o.layout == OUT_D2S) {
-                const unsigned cq = (unsigned)p.Cout >> 2, par = co / cq, c = co - par * cq;
-                o.ptr[((size_t)(2 * iy + (par >> 1)) * (2 * p.W) + 2 * ix + (par & 1)) * o.C + o.coff + c] = v;
-            }
-        };
-#pragma unroll
-        for (int m = 0; m < CT; ++m) {
-            const unsigned co = (slice * CT + m) * 32 + j;
-            const float bias = p.bias ? p.bias[co] : 0.0f;
-#pragma unroll
-            for (int n = 0; n < PT; ++n) {
+    if constexpr (!NORM && TAPS == 9) {                    // the U-Net's layouts (only its launches set oa)
+        if (p.oa.ptr) {
+            // element offset = f(iy) + g(ix) + k(co) in every layout (see OutSpec); k per channel tile here, f + g per pixel below
+            auto chan = [&](const OutSpec &o, unsigned co) -> int {
+                if (o.layout != OUT_D2S) return o.coff + (int)co;
+                const unsigned cq = (unsigned)p.Cout >> 2, par = co / cq;
+                return (int)(((par >> 1) * 2 * p.W + (par & 1)) * o.C + o.coff + (co - par * cq));
+            };
+            auto pixel = [&](const OutSpec &o, int iy, int ix) -> int {
+                if (o.layout == OUT_NORMAL) return (iy * p.W + ix) * o.C;
+                if (o.layout == OUT_S2D) return ((iy >> 1) * (p.W >> 1) + (ix >> 1)) * o.C + ((iy & 1) * 2 + (ix & 1)) * (o.C >> 2);
+                return (4 * iy * p.W + 2 * ix) * o.C;
+            };
+            int ka[CT], kb[CT]; float bias[CT];
+            static_for<CT>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const unsigned co = (slice * CT + m) * 32 + j;
+                ka[m] = chan(p.oa, co); kb[m] = p.ob.ptr ? chan(p.ob, co) : 0;
+                bias[m] = p.bias ? p.bias[co] : 0.0f;
+            });
+            static_for<PT>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
                 const int q = wave * PT + n;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                static_for<16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
                     const int iy = y0 + q * PTR + (TWC == 32 ? 0 : (r >> 3)), ix = x0 + 4 * h + (TWC == 32 ? d_row0(r) : (d_row0(r) & 15));
-                    if (iy >= p.H || ix >= p.W) continue;
-                    const float v = acc[n][m][r] * p.out_scale + bias;
-                    put(p.oa, iy, ix, co, v);
-                    if (p.ob.ptr) put(p.ob, iy, ix, co, v);
-                }
-            }
+                    if (iy < p.H && ix < p.W) {
+                        const int pa = pixel(p.oa, iy, ix), pb = p.ob.ptr ? pixel(p.ob, iy, ix) : 0;
+                        static_for<CT>([&](auto mc) {
+                            constexpr int m = decltype(mc)::value;
+                            const float v = acc[n][m][r] * p.out_scale + bias[m];
+                            p.oa.ptr[pa + ka[m]] = v;
+                            if (p.ob.ptr) p.ob.ptr[pb + kb[m]] = v;
+                        });
+                    }
+                });
+            });
+            return;
         }
-        return;
     }
     if (!full) emit(std::integral_constant<int, 0>{});
     else if (rawp && yp) emit(std::integral_constant<int, 1>{});
@@ -887,6 +904,7 @@ struct DevConv {            // a packed convolution
     float wscale_inv = 1.0f;     // 2^-sw
     int cout = 0, cin = 0, taps = 0;
     unsigned off[3] = {0, 0, 0}; // byte offset of the stream packed for CT = 1, 2, 4
+    int ct_mask = 0;             // which of them were packed
 };
 struct DevNorm { float *gamma = nullptr, *beta = nullptr; int C = 0, groups = 32; float eps = 1e-5f; };
 struct DevBlock { DevConv conv[3], ds; bool has_ds = false; DevNorm bn[4]; int cin = 0, cout = 0; };
@@ -978,7 +996,7 @@ static int pack_conv(Encoder *e, const avc_conv2d &c, int taps_expected, DevConv
     AVC_REQUIRE(c.kh * c.kw == taps_expected && c.kh == c.kw, AVC_ERR_ARG, "avc_hgfilter_pack: %s: kernel %dx%d, expected %d taps", name, c.kh, c.kw, taps_expected);
     AVC_REQUIRE(c.cin % 32 == 0 && c.cin <= MAX_CIN && c.cout % 32 == 0 && c.cout <= 1024, AVC_ERR_ARG,
                 "pack: %s: (%d <- %d) channels; multiples of 32 up to 1024 are supported", name, c.cout, c.cin);
-    d.cout = c.cout; d.cin = c.cin; d.taps = taps_expected;
+    d.cout = c.cout; d.cin = c.cin; d.taps = taps_expected; d.ct_mask = 0;
     const int taps = taps_expected, nchunk = c.cin / 32;
     double m = 0.0;
     const size_t nw = (size_t)c.cout * c.cin * taps;
@@ -998,6 +1016,7 @@ static int pack_conv(Encoder *e, const avc_conv2d &c, int taps_expected, DevConv
         const int CT = 1 << v;
         off[v] = (unsigned)stream.size();
         if (ntile % CT || !(ct_mask & CT)) continue;
+        d.ct_mask |= CT;
         for (int slice = 0; slice < ntile / CT; ++slice)
             for (int ch = 0; ch < nchunk; ++ch)
                 for (int t = 0; t < taps; ++t)
@@ -1029,7 +1048,7 @@ static int pack_conv(Encoder *e, const avc_conv2d &c, int taps_expected, DevConv
 static int pack_norm(Encoder *e, const avc_groupnorm &g, int C, DevNorm &d, const char *name)
 {
     AVC_REQUIRE(g.gamma && g.beta, AVC_ERR_ARG, "avc_hgfilter_pack: %s: NULL gamma / beta", name);
-    AVC_REQUIRE(g.channels == C && g.groups == 32 && C % 32 == 0 && C <= MAX_CIN, AVC_ERR_ARG,
+    AVC_REQUIRE(g.channels == C && g.groups == 32 && C % 32 == 0 && C <= MAX_NORM_CIN, AVC_ERR_ARG,
                 "avc_hgfilter_pack: %s: GroupNorm(%d, %d), expected GroupNorm(32, %d)", name, g.groups, g.channels, C);
     d.C = C; d.groups = g.groups; d.eps = g.eps;
     std::vector<float> ga(g.gamma, g.gamma + C), be(g.beta, g.beta + C);
@@ -1434,8 +1453,8 @@ int encoder_debug_tensor(avc_ctx *ctx, int launch, int which, float *out, int *C
     }
     else if (L.kind == L_CONV) { src = which ? L.conv.y : L.conv.raw; c = which ? L.conv.yC : L.conv.Cout; h = L.conv.H; w = L.conv.W; }
     else if (L.kind == L_POOL || L.kind == L_UPADD || L.kind == L_UPADD_TILED || L.kind == L_NORMRELU) { src = L.elt.out; c = L.elt.C; h = L.elt.H; w = L.elt.W; }
-    else if (L.kind == L_UP2) { src = L.up2.out; c = L.up2.C; h = 2 * L.up2.H; w = 2 * L.up2.W; }
-    else if (L.kind == L_S2D) { src = L.s2d.out; c = 32; h = L.s2d.H; w = L.s2d.W; }
+    else if (L.kind == L_UP2 && which == 2) { src = L.up2.out; c = L.up2.C; h = 2 * L.up2.H; w = 2 * L.up2.W; }
+    else if (L.kind == L_S2D && which == 2) { src = L.s2d.out; c = 32; h = L.s2d.H; w = L.s2d.W; }
     *C = c; *H = h; *W = w;
     if (L.kind == L_CONV) *C = c | (L.CT << 16) | (L.PT << 20) | (L.TAPS << 24) | ((L.conv.ksplit > 1 ? 1 : 0) << 30);
     if (out && src) hipLaunchKernelGGL(hwc_to_nchw_kernel, dim3((h * w + 63) / 64, (c + 63) / 64), dim3(256), 0, s, src, out, c, h * w);
@@ -1498,7 +1517,7 @@ int pack_unet(avc_ctx *ctx, const avc_unet7ds *net)
                             w[((size_t)co * ci4 + par * c.cin + ci) * 9 + ty * 3 + tx] = c.w[(((size_t)co * c.cin + ci) * 4 + ky) * 4 + kx] * sc[co];
                         }
         const avc_conv2d c3{w.data(), sh.data(), c.cout, ci4, 3, 3};
-        if (int rc = pack_conv(e, c3, 9, e->u_down[l], nm, conv_ct(c.cout))) return rc;
+        if (int rc = pack_conv(e, c3, 9, e->u_down[l], nm, 2 * conv_ct(c.cout) - 1)) return rc;
     }
     // ---- upconv1..3: ConvTranspose2d(ci, co, 4, 2, 1, bias=False), weight (ci, co, 4, 4), as 3x3 with 4 co parity-major outputs
     for (int l = 0; l < 3; ++l) {
@@ -1519,7 +1538,7 @@ int pack_unet(avc_ctx *ctx, const avc_unet7ds *net)
                         }
             }
         const avc_conv2d c3{w.data(), b.data(), 4 * c.cout, c.cin, 3, 3};
-        if (int rc = pack_conv(e, c3, 9, e->u_up[l], nm, 4)) return rc;
+        if (int rc = pack_conv(e, c3, 9, e->u_up[l], nm, 7)) return rc;
     }
     // ---- upconvC5..C7: Conv2d(ci, co, 3, 1, 1, bias=True) behind the bilinear upsample
     for (int l = 0; l < 3; ++l) {
@@ -1533,7 +1552,7 @@ int pack_unet(avc_ctx *ctx, const avc_unet7ds *net)
             for (size_t i = 0; i < (size_t)c.cin * 9; ++i) w[(size_t)co * c.cin * 9 + i] = c.w[(size_t)co * c.cin * 9 + i] * sc[co];
         }
         const avc_conv2d c3{w.data(), b.data(), c.cout, c.cin, 3, 3};
-        if (int rc = pack_conv(e, c3, 9, e->u_upc[l], nm, conv_ct(c.cout))) return rc;
+        if (int rc = pack_conv(e, c3, 9, e->u_upc[l], nm, 2 * conv_ct(c.cout) - 1)) return rc;
     }
     // the decoder's concatenations must fit together (unets.py:209-219)
     const int c6 = e->u_down[5].cout, c5 = e->u_down[4].cout, c4 = e->u_down[3].cout, c3 = e->u_down[2].cout, c2 = e->u_down[1].cout, c1 = e->u_down[0].cout;
@@ -1558,25 +1577,37 @@ static int build_unet_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
         if (P.rc) return;
         Launch L{}; L.kind = L_CONV; L.TAPS = 9; L.norm = false;
         L.TWC = x.W >= 32 ? 32 : 16;
-        L.CT = conv_ct(w.cout) > 4 ? 4 : conv_ct(w.cout);
-        L.PT = L.TWC == 32 ? 2 : 1;
-        auto wgs = [&](int PT) { const int rows = 4 * PT * (32 / L.TWC); return ((x.H + rows - 1) / rows) * ((x.W + L.TWC - 1) / L.TWC) * (w.cout / (32 * L.CT)); };
-        if (L.PT == 2 && wgs(2) < ctx->num_cus) L.PT = 1;
+        const int nchunk = x.C / 32;
+        auto tiles = [&](int PT) { const int rows = 4 * PT * (32 / L.TWC); return ((x.H + rows - 1) / rows) * ((x.W + L.TWC - 1) / L.TWC); };
+        L.CT = conv_ct(w.cout);
+        L.PT = (L.TWC == 32 && tiles(2) * (w.cout / (32 * L.CT)) >= ctx->num_cus) ? 2 : 1;
+        int ks = 1;
+        // The deep levels are a few pixels wide and stream megabytes of weights: a workgroup moves ~15 GB/s of them through its LDS ring, so the
+        // launch is as fast as it has workgroups.  Narrower channel slices (CT) and a deeper split of K until the chip is full; the larger CT on a tie.
+        if (ctx->opt.enc_ksplit && tiles(L.PT) * (w.cout / (32 * L.CT)) < ctx->num_cus) {
+            int best = 0;
+            for (int ct = L.CT; ct >= 1; ct >>= 1) {
+                if (!(w.ct_mask & ct)) continue;
+                const int wg0 = tiles(1) * (w.cout / (32 * ct));
+                int k = 1;
+                while (nchunk % (2 * k) == 0 && k < 16 && 2 * wg0 * k <= ctx->num_cus) k *= 2;
+                if (wg0 * k > best) { best = wg0 * k; L.CT = ct; ks = k; }
+            }
+            L.PT = 1;
+        }
         const int rows = 4 * L.PT * (32 / L.TWC);
         ConvArgs &a = L.conv;
         a.x = x.data; a.H = x.H; a.W = x.W; a.Cin = x.C;
         a.in_cpg = 1; a.in_scale = 16.0f; a.in_slope = slope;
         const int v = L.CT == 4 ? 2 : (L.CT == 2 ? 1 : 0);
-        a.slice_bytes = (unsigned)(x.C / 32) * 9 * 2 * L.CT * 2048;
+        a.slice_bytes = (unsigned)nchunk * 9 * 2 * L.CT * 2048;
         a.wstream = w.wstream + w.off[v]; a.wbytes = a.slice_bytes * (w.cout / (32 * L.CT));
         a.bias = w.bias; a.out_scale = w.wscale_inv / a.in_scale; a.Cout = w.cout;
         a.tiles_x = (x.W + L.TWC - 1) / L.TWC; a.tiles_y = (x.H + rows - 1) / rows;
         a.oa = oa; a.ob = ob;
         a.range_flag = e->range_flag;
-        const int wg = a.tiles_x * a.tiles_y * (w.cout / (32 * L.CT)), nchunk = x.C / 32;
-        a.ksplit = 1;
-        if (ctx->opt.enc_ksplit)
-            while (nchunk % (2 * a.ksplit) == 0 && a.ksplit < 8 && 2 * wg * a.ksplit <= ctx->num_cus) a.ksplit *= 2;       // slices of whole chunks
+        const int wg = a.tiles_x * a.tiles_y * (w.cout / (32 * L.CT));
+        a.ksplit = ks;
         if (a.ksplit > 1) {
             a.kpart = static_cast<float *>(P.alloc(sizeof(float) * (size_t)wg * a.ksplit * 256 * L.PT * L.CT * 16));
             a.kcounter = static_cast<unsigned *>(P.alloc(sizeof(unsigned) * wg, true));
