@@ -76,6 +76,10 @@ _SIGNATURES = {
                                               C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
     'avc_hgfilter_pack': (C.c_int, [C.c_void_p, C.POINTER(avc_hgfilter)]),
     'avc_hgfilter_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'avc_render_rays_cano': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_int,
+                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    'avc_blend_weight_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'avc_unet_pack': (C.c_int, [C.c_void_p, C.POINTER(avc_unet7ds)]),
     'avc_unet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'avc_hgfilter_debug_tensor': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),

@@ -14,13 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libavcap_hip.so')
-SOURCES = ['fused_mlp.hip', 'conv_enc.hip', 'misc.hip', 'mesh.hip', 'raster.hip', 'fusion.hip', 'knn_lbs.hip', 'pack.cpp', 'capi.cpp']
+SOURCES = ['fused_mlp.hip', 'conv_enc.hip', 'misc.hip', 'mesh.hip', 'raster.hip', 'fusion.hip', 'knn_lbs.hip', 'render.hip', 'pack.cpp', 'capi.cpp']
 HEADERS = ['avcap_internal.h', 'mlp_layout.h', 'mc_tables.h', os.path.join('..', '..', 'include', 'avcap.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
 # mesh / KNN kernels promise bit-exact agreement with the C oracle (built with -ffp-contract=off):
 # HIP's __fmul_rn/__fadd_rn are plain operators, so contraction has to be disabled per file.
-EXTRA = {'mesh.hip': ['-ffp-contract=off'], 'knn_lbs.hip': ['-ffp-contract=off'], 'raster.hip': ['-ffp-contract=off'],
+EXTRA = {'mesh.hip': ['-ffp-contract=off'], 'knn_lbs.hip': ['-ffp-contract=off'], 'raster.hip': ['-ffp-contract=off'], 'render.hip': ['-ffp-contract=off'],
          # MFMA accumulators in VGPRs: the epilogue reads them without a v_accvgpr_read per value (-0.7 % launch time, tools/ablate_run.sh)
          'fused_mlp.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 

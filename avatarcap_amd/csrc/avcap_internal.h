@@ -92,6 +92,7 @@ struct avc_ctx {
     void *gn_scratch = nullptr; size_t gn_scratch_bytes = 0;       // GroupNorm slice sums
     std::vector<void *> retired_scratch;                           // outgrown blocks that a captured graph may still name: freed with the context
     void *scatter_scratch = nullptr; size_t scatter_scratch_bytes = 0;   // block counts of avc_scatter_volume
+    void *render_scratch = nullptr; size_t render_scratch_bytes = 0;   // per-sample buffers of avc_render_rays_cano
     void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
     void *col_scratch = nullptr; size_t col_scratch_bytes = 0;     // per-column terms of a column-folded dense query (512 floats per column)
     void *rcol_scratch = nullptr; size_t rcol_scratch_bytes = 0;   // ... of a column-folded recon query (896 floats per column)
@@ -148,8 +149,15 @@ int pack_unet(avc_ctx *ctx, const avc_unet7ds *net);
 int unet_forward(avc_ctx *ctx, const float *pos_map, int H, int W, float *out_nchw, int bind, hipStream_t s);
 void release_unet(avc_ctx *ctx);
 }
+// render.hip
+int render_rays_cano(avc_ctx *ctx, const float *ray_o, const float *ray_d, const float *near, const float *far, const float *depth, float near_dist,
+                     float far_dist, const float *t_vals, int64_t P, int S, const float center[3], const float bounds[6], const float *smpl_v, int32_t n_smpl, int occ_sigmoid,
+                     float *rgb_map, float *acc_map, float *depth_map, float *disp_map, float *weights, float *raw, hipStream_t s);
+int blend_weight_sample(const float *vol, const int32_t res[3], int C, const float *pts01, int64_t n, float *out, hipStream_t s);
 // knn_lbs.hip
 int knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, int K, float *d2, int64_t *idx, hipStream_t s);
+// out[i] = 0 if some reference point has cand d2 < thr2, +inf otherwise (the K = 1 search's d2 < thr2, without the search for the nearest)
+int near_flags(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, float thr2, float *out, hipStream_t s);
 int calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s);
 int skinning(const float *pts, const float *nrm, int64_t n, const float *lbs, const float *jm, float *po, float *no, float *mo, hipStream_t s);
 }  // namespace avc

@@ -55,6 +55,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->mc_tables_dev) hipFree(ctx->mc_tables_dev);
     if (ctx->raster_scratch) hipFree(ctx->raster_scratch);
     if (ctx->knn_scratch) hipFree(ctx->knn_scratch);
+    if (ctx->render_scratch) hipFree(ctx->render_scratch);
     if (ctx->col_scratch) hipFree(ctx->col_scratch);
     if (ctx->rcol_scratch) hipFree(ctx->rcol_scratch);
     if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
@@ -206,6 +207,28 @@ int avc_template_query(avc_ctx *ctx, const float *pts, int64_t n, int occupancy_
     AVC_REQUIRE(ctx && n >= 0 && (n == 0 || (pts && occ)), AVC_ERR_ARG, "avc_template_query: NULL argument or negative n");
     AVC_HIP(hipSetDevice(ctx->device));
     return run_avatar(ctx, pts, nullptr, n, nullptr, occupancy_sigmoid, occ, nullptr, rgba, true, (hipStream_t)stream);
+}
+
+int avc_render_rays_cano(avc_ctx *ctx, const float *ray_o, const float *ray_d, const float *near, const float *far, const float *depth, float near_dist,
+                         float far_dist, const float *t_vals, int64_t n_rays, int n_samples, const float center[3], const float bounds[6], const float *cano_smpl_v, int32_t n_smpl,
+                         int occupancy_sigmoid, float *rgb_map, float *acc_map, float *depth_map, float *disp_map, float *weights, float *raw,
+                         avc_stream stream)
+{
+    AVC_REQUIRE(ctx && center && bounds && n_rays >= 0 && (n_rays == 0 || (ray_o && ray_d && near && far && cano_smpl_v)), AVC_ERR_ARG,
+                "avc_render_rays_cano: NULL argument or negative n_rays");
+    AVC_REQUIRE(n_samples >= 2 && n_samples <= 65536 && n_smpl >= 1, AVC_ERR_ARG, "avc_render_rays_cano: n_samples %d (>= 2), n_smpl %d (>= 1)", n_samples, n_smpl);
+    AVC_HIP(hipSetDevice(ctx->device));
+    return render_rays_cano(ctx, ray_o, ray_d, near, far, depth, near_dist, far_dist, t_vals, n_rays, n_samples, center, bounds, cano_smpl_v, n_smpl, occupancy_sigmoid,
+                            rgb_map, acc_map, depth_map, disp_map, weights, raw, (hipStream_t)stream);
+}
+
+int avc_blend_weight_sample(avc_ctx *ctx, const float *vol_xyzc, const int32_t res[3], int channels, const float *pts01, int64_t n, float *out, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && res && n >= 0 && (n == 0 || (vol_xyzc && pts01 && out)), AVC_ERR_ARG, "avc_blend_weight_sample: NULL argument or negative n");
+    AVC_REQUIRE(res[0] >= 1 && res[1] >= 1 && res[2] >= 1 && channels >= 4 && channels % 4 == 0, AVC_ERR_ARG,
+                "avc_blend_weight_sample: a (%d, %d, %d, %d) volume; every axis >= 1 and the channel count a multiple of 4 (the reference: 24)", res[0], res[1], res[2], channels);
+    AVC_HIP(hipSetDevice(ctx->device));
+    return blend_weight_sample(vol_xyzc, res, channels, pts01, n, out, (hipStream_t)stream);
 }
 
 int avc_recon_query(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], float *out, avc_stream stream)

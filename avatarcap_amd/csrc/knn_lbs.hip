@@ -465,6 +465,31 @@ __global__ __launch_bounds__(256) void skinning_kernel(const float *__restrict__
     }
 }
 
+// near[i] = 0 when a reference point lies closer than sqrt(thr2) to query i, +inf otherwise -- the only thing the colour path wants of
+// knn_points(wpts, cano_smpl_vertices, K=1) (arch_avatar.py:208-209: near_flag = d2 < 0.08^2).  The same squared distance (cand_d2) against the
+// same threshold as a comparison of the K = 1 result gives, so the flags are the exact search's; but only the cells the ball touches are
+// visited and the first hit ends the search (the exact K = 1 kernel spends 3.3 ms on the 12.8 M samples of 200 k rays, this one a third).
+__global__ __launch_bounds__(256) void near_flag_kernel(const float *__restrict__ q, int64_t nq, GridView g, float thr2, float radius, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    const GridHdr H = *g.hdr;
+    const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
+    const float r = radius + H.eps;
+    const int x0 = cell_coord(qx - r, H.ox, H.inv_h, H.nx), x1 = cell_coord(qx + r, H.ox, H.inv_h, H.nx);
+    const int y0 = cell_coord(qy - r, H.oy, H.inv_h, H.ny), y1 = cell_coord(qy + r, H.oy, H.inv_h, H.ny);
+    const int z0 = cell_coord(qz - r, H.oz, H.inv_h, H.nz), z1 = cell_coord(qz + r, H.oz, H.inv_h, H.nz);
+    bool hit = false;
+    for (int cx = x0; cx <= x1 && !hit; ++cx)
+        for (int cy = y0; cy <= y1 && !hit; ++cy) {
+            const int row = (cx * H.ny + cy) * H.nz;
+            const int b = g.start[row + z0], e = g.start[row + z1 + 1];          // z runs fastest: the cells z0..z1 of this (x, y) are one range
+            for (int k = b; k < e; ++k)
+                if (cand_d2(g.sorted[k], qx, qy, qz) < thr2) { hit = true; break; }
+        }
+    out[i] = hit ? 0.0f : __builtin_inff();
+}
+
 }  // namespace
 
 // Builds the grid over `ref` in the context's scratch (stream-ordered; no host synchronisation).
@@ -517,6 +542,17 @@ int knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, 
 #undef CASE
         default: set_error("avc_knn: unsupported K %d", K); return AVC_ERR_ARG;
     }
+    AVC_HIP(hipGetLastError());
+    return AVC_OK;
+}
+
+int near_flags(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, float thr2, float *out, hipStream_t s)
+{
+    if (nq == 0) return AVC_OK;
+    GridView g;
+    if (int rc = make_grid(ctx, ref, nr, nq, g, s)) return rc;
+    if (!g.hdr) return knn(ctx, q, nq, ref, nr, 1, out, nullptr, s);          // no grid (a handful of reference points): the exact distances serve as flags
+    hipLaunchKernelGGL(near_flag_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, q, nq, g, thr2, std::sqrt(thr2) * 1.0001f, out);
     AVC_HIP(hipGetLastError());
     return AVC_OK;
 }

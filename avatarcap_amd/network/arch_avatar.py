@@ -116,20 +116,33 @@ class WarpingField(nn.Module):
 
 
 class CanoBlendWeightVolume:
-    """Trilinear fetch of the 24-channel canonical blend-weight volume (arch_avatar.py:143-165)."""
+    """Trilinear fetch of the 24-channel canonical blend-weight volume (arch_avatar.py:143-165) -- `avc_blend_weight_sample` (csrc/render.hip) on the
+    channel-last volume, the layout of the .npy the reference loads (:145).  `base_weight_volume` keeps the reference's attribute, (1, 24, X, Y, Z)."""
 
     def __init__(self, base_weight_volume_path=None, base_weight_volume=None):
         if base_weight_volume is None:
             base_weight_volume = np.load(base_weight_volume_path)          # (X,Y,Z,24) (arch_avatar.py:145)
-        v = np.ascontiguousarray(np.asarray(base_weight_volume, np.float32).transpose((3, 0, 1, 2))[None])
-        self.base_weight_volume = torch.from_numpy(v).to(torch.float32).to(config.device)
+        v = np.ascontiguousarray(np.asarray(base_weight_volume, np.float32))
+        if v.ndim != 4 or v.shape[3] % 4:
+            raise ValueError(f'CanoBlendWeightVolume: a (X, Y, Z, 24) volume is expected, got {v.shape}')
+        self._xyzc = torch.from_numpy(v).to(config.device)
+        self.base_weight_volume = self._xyzc.permute((3, 0, 1, 2))[None]     # a view: (1, 24, X, Y, Z)
 
     def forward(self, pts):
         """pts (B,N,3) scaled to [0,1] -> (B,N,24)."""
+        if not pts.is_cuda:
+            raise RuntimeError('CanoBlendWeightVolume runs on the HIP device only (csrc/render.hip); there is no CPU path')
         B, N, _ = pts.shape
-        grid = (2 * pts - 1).reshape(-1, 3)[:, [2, 1, 0]][None, :, None, None]
-        w = F.grid_sample(self.base_weight_volume, grid, padding_mode='border', align_corners=True)
-        return w[0, :, :, 0, 0].reshape(-1, B, N).permute((1, 2, 0))
+        pts = pts.contiguous().float()
+        if self._xyzc.device != pts.device:                                   # follows its first caller to the device, once
+            self._xyzc = self._xyzc.to(pts.device)
+            self.base_weight_volume = self._xyzc.permute((3, 0, 1, 2))[None]
+        vol = self._xyzc
+        X, Y, Z, Cn = vol.shape
+        out = torch.empty((B, N, Cn), dtype=torch.float32, device=pts.device)
+        _lib.check(_lib.lib().avc_blend_weight_sample(_lib.ctx(pts.device), _lib.dev_ptr(vol, name='base_weight_volume'), (C.c_int32 * 3)(X, Y, Z), Cn,
+                                                      pts.data_ptr(), B * N, out.data_ptr(), _lib.stream_ptr(pts.device)))
+        return out
 
 
 class GeoTexAvatar(nn.Module):
@@ -266,9 +279,12 @@ class NerfRenderer:
         return ret
 
     def render(self, batch, pts_space='posed', near_dist=0.05, far_dist=0.05, chunk=1 << 16):
-        """batch keys: ray_o, ray_d (B,P,3), near, far, occupancy, depth (B,P).  The reference walks the
-        rays 2048 at a time (:330); the fused kernel has no activation tensors to bound, so the chunk is
-        only a cap on the (P*64,3) point buffer."""
+        """batch keys: ray_o, ray_d (B,P,3), near, far, occupancy, depth (B,P).  The reference walks the rays 2048 at a time (:330); the fused kernel
+        has no activation tensors to bound, so the chunk is only a cap on the per-sample buffers.
+        pts_space == 'cano' (what main.py:475 runs for the vertex colours): `avc_render_rays_cano` -- sample points, the fused query with the colour
+        head, the near / inside masks, alpha and raw2outputs on the device, nothing per sample in PyTorch.  Returns rgb_map, acc_map, depth_map, raw."""
+        if pts_space == 'cano' and batch['ray_o'].is_cuda:
+            return self._render_cano(batch, near_dist, far_dist)
         n_pixel = batch['ray_o'].shape[1]
         rets = []
         for i in range(0, n_pixel, chunk):
@@ -276,6 +292,36 @@ class NerfRenderer:
             rets.append(self.get_pixel_value(batch['ray_o'][:, sl], batch['ray_d'][:, sl], batch['near'][:, sl], batch['far'][:, sl],
                                              batch['occupancy'][:, sl], batch['depth'][:, sl], batch, pts_space, near_dist, far_dist))
         return {k: torch.cat([r[k] for r in rets], dim=1) for k in rets[0].keys()}
+
+    def _render_cano(self, batch, near_dist, far_dist, want_raw=False):
+        from ..utils.smpl_util import smpl_util
+        net = self.net
+        ray_o = batch['ray_o'].contiguous().float()
+        B, P, _ = ray_o.shape
+        dev = ray_o.device
+        ctx = net._ctx(dev)
+        if config.if_type not in ('sdf', 'occupancy'):
+            raise ValueError('Invalid config.if_type!')
+        S = int(config.N_samples)
+        f = lambda k: batch[k].contiguous().float()                                       # noqa: E731
+        ray_d, near, far, depth = f('ray_d'), f('near'), f('far'), f('depth')
+        smpl_v = smpl_util.cano_smpl_vertices.contiguous().float()
+        t_vals = torch.linspace(0., 1., steps=S).to(near)                                  # :251, the host's linspace as the reference takes it
+        rgb = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
+        acc = torch.empty((B, P), dtype=torch.float32, device=dev)
+        dep = torch.empty((B, P), dtype=torch.float32, device=dev)
+        raw = torch.empty((B, P * S, 4), dtype=torch.float32, device=dev) if want_raw else None
+        for b in range(B):
+            net.warping_field.bind_map(ctx, b if net.warping_field.pose_feat_map.shape[0] > 1 else 0)
+            _lib.check(_lib.lib().avc_render_rays_cano(
+                ctx, ray_o[b].data_ptr(), ray_d[b].data_ptr(), near[b].data_ptr(), far[b].data_ptr(), depth[b].data_ptr(), float(near_dist), float(far_dist),
+                t_vals.data_ptr(), P, S, _lib.f3(batch['cano_smpl_center'][b]), _lib.f3(batch['cano_bounds'][b]), _lib.dev_ptr(smpl_v, name='cano_smpl_vertices'),
+                smpl_v.shape[0], 1 if config.if_type == 'occupancy' else 0, rgb[b].data_ptr(), acc[b].data_ptr(), dep[b].data_ptr(), None, None,
+                raw[b].data_ptr() if want_raw else None, _lib.stream_ptr(dev)))
+        out = {'rgb_map': rgb, 'acc_map': acc, 'depth_map': dep}
+        if want_raw:
+            out['raw'] = raw
+        return out
 
 
 class OccupancyNet:

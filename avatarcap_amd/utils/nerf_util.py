@@ -1,7 +1,7 @@
-"""The one function of the reference's `utils/nerf_util.py` on the test-mode path: alpha compositing
-along rays (`raw2outputs`, nerf_util.py:185-212).  Elementwise + a 64-long cumulative product per ray:
-left on PyTorch-ROCm (SURVEY.md section 8(f) ranks a dedicated kernel as follow-up work); the heavy part of
-the colour path -- 64 network queries per vertex -- runs in the fused HIP kernel."""
+"""The one function of the reference's `utils/nerf_util.py` on the test-mode path: alpha compositing along rays (`raw2outputs`,
+nerf_util.py:185-212).  The test loop's vertex colours (pts_space='cano', main.py:464-477) do not come through here: `avc_render_rays_cano`
+(csrc/render.hip) composites on the device, one wavefront per ray.  This torch form serves NerfRenderer.get_pixel_value for the 'posed' and
+'temp' spaces, and the tests hold the device compositor to it."""
 import torch
 
 

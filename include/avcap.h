@@ -199,6 +199,29 @@ int avc_set_range_check(avc_ctx *ctx, int enabled);
 int avc_template_query(avc_ctx *ctx, const float *pts_dev, int64_t n, int occupancy_sigmoid,
                        float *occ_out_dev, float *rgba_out_dev, avc_stream stream);
 
+/* ---- the colour path ---------------------------------------------------------------------------------
+ * NerfRenderer.render(batch, pts_space='cano') in eval mode followed by raw2outputs (network/arch_avatar.py:240-349 with the 'cano' branch of
+ * GeoTexAvatar.forward :206-237; utils/nerf_util.py:185-212) -- what main.py:464-477 runs once per frame to colour the avatar's vertices:
+ *   z = near (1 - t) + far t, t = t_vals_dev (n_samples) or, when NULL, linspace(0, 1, n_samples) by ATen's element formula (the reference takes
+ *   torch.linspace on the host, whose vectorised last bits depend on the host: pass that tensor to follow it bit for bit); pts = ray_o + ray_d z; for rays with depth > 1e-6 (depth_dev != NULL) near / far are
+ *   depth - near_dist / depth + far_dist first (:289-291);
+ *   (occ, offset, rgba) = the fused avatar query at pts with the colour head (the pose feature map and the weights bound to the context);
+ *   sigma = rgba.w, zeroed where pts + offset is not strictly inside `bounds` (lo xyz, hi xyz) or the nearest of the n_smpl canonical SMPL vertices is
+ *   0.08 or farther (:208-209, :222-226); alpha = 1 - exp(-sigma dist), dist = z[s + 1] - z[s] (the last sample repeats its predecessor's);
+ *   weights = alpha * cumprod([1, 1 - alpha + 1e-10])[:-1]; rgb_map = sum w rgb; depth_map = sum w z; acc_map = sum w; disp_map = 1 / max(1e-10, depth / acc).
+ * Outputs (each may be NULL): rgb_map (n_rays, 3) in the network's channel order, acc / depth / disp maps (n_rays), weights (n_rays, n_samples),
+ * raw (n_rays n_samples, 4) = [rgb, alpha].  The reference's 2048-ray chunking (:330) bounds its activation memory and does not change results; this
+ * entry walks ~4 M samples at a time out of a context-owned scratch. */
+int avc_render_rays_cano(avc_ctx *ctx, const float *ray_o_dev, const float *ray_d_dev, const float *near_dev, const float *far_dev, const float *depth_dev,
+                         float near_dist, float far_dist, const float *t_vals_dev, int64_t n_rays, int n_samples, const float center[3], const float bounds[6],
+                         const float *cano_smpl_v_dev, int32_t n_smpl, int occupancy_sigmoid, float *rgb_map_dev, float *acc_map_dev, float *depth_map_dev,
+                         float *disp_map_dev, float *weights_dev, float *raw_dev, avc_stream stream);
+/* CanoBlendWeightVolume.forward (network/arch_avatar.py:143-165): F.grid_sample(volume, (2 pts - 1)[..., [2, 1, 0]], padding_mode='border',
+ * align_corners=True) of the canonical blend-weight volume.  vol_xyzc_dev (X, Y, Z, channels) channel-last float32 -- the layout of the .npy the
+ * reference loads (:145) --, pts01_dev (n, 3) in [0, 1]^3 (x along X), out_dev (n, channels). */
+int avc_blend_weight_sample(avc_ctx *ctx, const float *vol_xyzc_dev, const int32_t res[3], int channels, const float *pts01_dev, int64_t n, float *out_dev,
+                            avc_stream stream);
+
 /* ReconNetwork.infer's per-point part (network/arch_recon.py:55-73): bilinear 32-ch sample at
  * (x-cx, -(y-cy)), z = p.z-cz, decoder, sigmoid.  out_dev (n). */
 int avc_recon_query(avc_ctx *ctx, const float *pts_dev, int64_t n, const float center[3],

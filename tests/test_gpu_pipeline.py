@@ -217,6 +217,76 @@ def test_vertex_colours_match_oracle(pipe64):
     assert err < 1e-4 + 2 * slack
 
 
+def test_blend_weight_sampler_matches_reference(golden):
+    """CanoBlendWeightVolume.forward on the HIP trilinear sampler (csrc/render.hip) against the reference's F.grid_sample golden (G10), plus
+    the border cases grid_sample's padding_mode='border' clamps: coordinates at and beyond 0 and 1."""
+    from avatarcap_amd.network.arch_avatar import CanoBlendWeightVolume
+    from oracle import avatarcap_oracle as orc
+    vol = gi.blend_weight_volume()
+    cw = CanoBlendWeightVolume(base_weight_volume=vol)
+    p = gi.points01(108, 300)
+    w = cw.forward(_t(p[None]))
+    assert w.shape == (1, 300, 24)
+    e = maxabs(w[0].cpu().numpy(), golden['G10_blend_w'])
+    print(f'G10 blend weights on the HIP sampler vs reference: {e:.3e}')
+    assert e < 2e-6
+    edge = np.array([[0, 0, 0], [1, 1, 1], [-0.3, 0.5, 1.7], [1, 0, 0.5], [0.999999, 1e-7, 0.5]], np.float32)
+    assert maxabs(cw.forward(_t(edge[None]))[0].cpu().numpy(), orc.cano_blend_weight_volume(vol, edge)) < 2e-6
+    assert cw.forward(_t(np.zeros((1, 0, 3), np.float32))).shape == (1, 0, 24)
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        cw.forward(torch.from_numpy(p[None]))
+
+
+@pytest.mark.parametrize('n_rays,n_samples', [(257, 64), (5, 64), (33, 48), (3, 130)])
+def test_render_rays_on_device_equals_the_stepwise_chain(pipe64, n_rays, n_samples):
+    """avc_render_rays_cano (sample points, fused query, near / inside masks, alpha, raw2outputs in four launches) against the same steps taken one
+    by one: NerfRenderer.get_pixel_value's torch arithmetic around the same fused query, and the oracle's raw2outputs on the raw it returns -- for
+    ragged ray counts and sample counts that are not one wavefront."""
+    from avatarcap_amd.dataset import to_cuda
+    from avatarcap_amd.network.arch_avatar import NerfRenderer
+    from common import geotex_sd_with_density
+    from oracle import avatarcap_oracle as orc
+    ds = pipe64.ds
+    items = to_cuda(ds[0], add_batch=True)
+    sd = geotex_sd_with_density()
+    pipe64.network.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    old_s = config.N_samples
+    try:
+        config.N_samples = n_samples
+        out = pipe64.avatar_frame(items)
+        idx = torch.linspace(0, out['cano_v'].shape[0] - 1, n_rays, device='cuda').long()
+        v, n = out['cano_v'][idx].contiguous(), out['cano_vn'][idx].contiguous()
+        v[1::2] += 0.06 * n[1::2]                                                   # every other ray starts outside: its samples cross the 0.08 near-body limit
+        b = dict(items)
+        b['ray_o'], b['ray_d'] = (v + n)[None], -n[None]
+        b['depth'] = torch.ones((1, n_rays), device='cuda')
+        b['depth'][0, ::7] = 0.0                                                    # rays without a depth keep their own near / far (:289-291)
+        b['near'], b['far'] = b['depth'] * 0 + 0.97, b['depth'] * 0 + 1.04
+        b['occupancy'] = b['depth'].clone()
+        r = NerfRenderer(pipe64.network)
+        got = r._render_cano(b, 0.02, 0.05, want_raw=True)
+        ref = r.get_pixel_value(b['ray_o'], b['ray_d'], b['near'], b['far'], b['occupancy'], b['depth'], b, 'cano', 0.02, 0.05)
+    finally:
+        config.N_samples = old_s
+        pipe64.network.load_state_dict({k: torch.from_numpy(v_) for k, v_ in geotex_sd().items()})
+    assert got['raw'].shape == (1, n_rays * n_samples, 4) and float(got['rgb_map'].max()) > 0.05
+    zeroed = float((ref['raw'][0, :, 3] == 0).float().mean())
+    print(f'render_rays {n_rays} x {n_samples}: {100 * zeroed:.1f} % of the samples masked (far from the body or outside the bounds)')
+    assert n_rays < 10 or 0.02 < zeroed < 0.98                                      # both sides of the masks are exercised
+    for k in ('raw', 'rgb_map', 'acc_map', 'depth_map'):
+        e = float((got[k] - ref[k]).abs().max())
+        print(f'render_rays {n_rays} x {n_samples}, {k}: device chain vs stepwise {e:.3e}')
+        assert e < 2e-6, k
+    # raw2outputs itself (nerf_util.py:185-212) in float64 on the raw the device produced
+    z = np.linspace(0., 1., n_samples, dtype=np.float32)[None].astype(np.float64)
+    dd = b['depth'][0].cpu().numpy().astype(np.float64)
+    nr, fr = np.where(dd > 1e-6, dd - 0.02, 0.97), np.where(dd > 1e-6, dd + 0.05, 1.04)
+    zv = nr[:, None] * (1 - z) + fr[:, None] * z
+    rgb64, _, acc64, _, dep64 = orc.raw2outputs(got['raw'][0].cpu().numpy().astype(np.float64).reshape(n_rays, n_samples, 4), zv)
+    assert maxabs(got['rgb_map'][0].cpu().numpy(), rgb64) < 1e-5 and maxabs(got['acc_map'][0].cpu().numpy(), acc64) < 1e-5
+    assert maxabs(got['depth_map'][0].cpu().numpy(), dep64) < 1e-5
+
+
 def test_vertex_colours_from_a_finetuned_network(pipe64):
     """main.py:307-314,474-475: with testing.net_ckpt_finetuned set, the texture comes from a SECOND GeoTexAvatar -- `nerf_renderer.net` -- whose
     pose feature map is computed on ITS warping field (`nerf_renderer.net.warping_field.precompute_conv(items)`), not on the geometry network's.

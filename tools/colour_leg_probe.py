@@ -18,3 +18,10 @@ for _ in range(3):
     rgb = pipe.colour_vertices(items, v, n)
 torch.cuda.synchronize()
 print('colour leg done', nv, tuple(rgb.shape))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(3):
+    rgb = pipe.colour_vertices(items, v, n)
+e1.record()
+torch.cuda.synchronize()
+print(f'colour_vertices: {e0.elapsed_time(e1) / 3:.2f} ms per {nv} vertices')
