@@ -15,15 +15,20 @@
 //   * every cut edge of a cell appears in the cell's tiling, so the vertex of a grid edge is created by the
 //     FIRST cell in traversal order among the (up to 4) cells around it -- a function of the cell's position
 //     only (creator_mask);  inside a cell new vertices are numbered by first appearance in its triangle list;
-//   pass A  count  : per 1024-point tile: #vertices created, #triangles, #crossed cells        -> tile sums
-//   scan           : exclusive scan of the tile sums (one workgroup), totals to the host
-//   pass B  verts  : per non-empty tile: resolve the cells again, in-tile scan, number the new vertices, record
-//                    their ids in the edge map (3 ints per grid point, sparsely written), write one 16-byte
-//                    record per crossed cell {cell, table row, first face, centre-vertex id} and, into each new
-//                    vertex's output slot, which (cell, edge) it is
-//   pass B' eval   : one thread per vertex: position (the library's fp64 formula) + normal (64-tap stencil)
-//   pass C  faces  : one thread per crossed cell: ids from the edge map -> triangles
-// HBM-bound: the volume is read twice (passes A, B; B skips empty tiles) + 24 B/vertex + 12 B/face written.
+//   pass A1 classify: the one streaming read of the volume: a thread takes four consecutive cells (their four corner rows as 16-byte loads, the fifth
+//                     column from the next lane) and one comparison of 20 "above the level" bits tells that none is crossed (most are not).  Tiles
+//                     (1024 consecutive grid points) with a crossed cell get their cells' cube indices stored (1 byte each) and a place in the list of
+//                     crossed tiles; the volume is not walked again.  No tables, 32 registers: bound by the cache's request rate (four rows per cell row)
+//   pass A2 count   : per crossed tile: cube index -> tiling-table row (the face / interior tests in fp64 read the 8 corner values of the few cells
+//                     that need them), stored as 2 bytes per cell; #vertices created, #triangles, #crossed cells -> tile sums
+//   scan            : exclusive scan of the tile sums (one workgroup, through LDS), totals and "fits the caller's capacity" left on the device
+//   pass B  verts   : per crossed tile, in any order: the stored rows, in-tile scan, number the new vertices, record their ids in the edge map (3 ints
+//                     per grid point, sparsely written), write one 16-byte record per crossed cell {cell, table row, first face, centre-vertex id}
+//                     and, into each new vertex's output slot, which (cell, edge) it is
+//   pass B' eval    : one thread per vertex: position (the library's fp64 formula) + normal (64-tap stencil)
+//   pass C  faces   : one thread per crossed cell: ids from the edge map -> triangles
+// A2, B, B' and C take their sizes from the device: the six launches are enqueued back to back and the host waits once, at the end, for the counts.
+// HBM-bound: the volume is read once (A1) + 3 B per cell of the crossed tiles + 24 B/vertex + 12 B/face written.
 // The 18 KB of look-up tables live in LDS.  Face / interior tests and the interpolation run in fp64 exactly as
 // the library's C code does (translation unit built with -ffp-contract=off).
 #include <hip/hip_runtime.h>
@@ -200,12 +205,6 @@ __device__ int resolve_row(const float *val, const McArgs &a, int idx, const uin
     }
 }
 
-struct Cell {
-    int z, y, x;           // library naming: z = axis 0, x = axis 2
-    int row;               // tiling row, -1 = not crossed (or not a cell)
-    float val[8];
-};
-
 // which of the cell's 13 possible vertices it is the FIRST cell (in traversal order) to refer to: edges 5, 6, 10 and the centre
 // always; the others only when the earlier neighbours that share them do not exist (see the header)
 __device__ __forceinline__ unsigned creator_mask(int z, int y, int x)
@@ -218,25 +217,6 @@ __device__ __forceinline__ unsigned creator_mask(int z, int y, int x)
     if (x == 0 && z == 0) m |= 1u << 3;
     if (x == 0 && y == 0) m |= 1u << 8;
     return m;
-}
-
-__device__ __forceinline__ void load_cell(const McArgs &a, int64_t li, const uint32_t *lds, Cell &c)
-{
-    const int yx = a.n1 * a.n2;
-    c.z = (int)(li / yx);
-    const int r = (int)(li - (int64_t)c.z * yx);
-    c.y = r / a.n2;
-    c.x = r - c.y * a.n2;
-    c.row = -1;
-    if (c.z + 1 >= a.n0 || c.y + 1 >= a.n1 || c.x + 1 >= a.n2) return;
-    const float *p = a.vol + li;
-    c.val[0] = p[0]; c.val[1] = p[1]; c.val[2] = p[a.n2 + 1]; c.val[3] = p[a.n2];
-    c.val[4] = p[yx]; c.val[5] = p[yx + 1]; c.val[6] = p[yx + a.n2 + 1]; c.val[7] = p[yx + a.n2];
-    unsigned idx = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) idx |= (c.val[k] > a.iso_f ? 1u : 0u) << k;     // == ((double)val - iso > 0), the library's test
-    if (idx == 0u || idx == 255u) return;
-    c.row = resolve_row(c.val, a, (int)idx, lds);
 }
 
 // cube edge e -> base grid point offset (dx, dy, dz) and axis (0 = x, 1 = y, 2 = z), packed 5 bits per edge
@@ -266,24 +246,116 @@ __device__ __forceinline__ unsigned block_exclusive(unsigned v, unsigned *lds4, 
     return base + incl - v;
 }
 
-// ---------------- pass A ----------------
-__global__ __launch_bounds__(256) void mc_count_kernel(McArgs a, unsigned *__restrict__ tile_v, unsigned *__restrict__ tile_t, unsigned *__restrict__ tile_c)
+// ---------------- pass A1: classify ----------------
+// The streaming pass over the volume: a thread takes four consecutive cells -- the rows (z, y), (z, y + 1), (z + 1, y), (z + 1, y + 1) as one 16-byte load
+// each, the fifth column from the next lane --, and one comparison of the 20 "above the level" bits tells that none of them is crossed (most are not).
+// For a tile with a crossed cell: the 8-bit cube index of each of its cells (idx8, 0 = not crossed / not a cell) and its number in the list of crossed
+// tiles, which the later passes walk instead of the volume.  Every tile's three counters are zeroed here (pass A2 fills in the crossed ones).
+// Few registers, no tables: bound by the read of the volume.
+__global__ __launch_bounds__(256) void mc_classify_kernel(McArgs a, unsigned *__restrict__ tile_v, unsigned *__restrict__ tile_t, unsigned *__restrict__ tile_c,
+                                                          uint8_t *__restrict__ idx8, unsigned *__restrict__ list, unsigned *__restrict__ list_n)
+{
+    const int yx = a.n1 * a.n2;
+    const bool vec = (a.n2 & 3) == 0 && (reinterpret_cast<uintptr_t>(a.vol) & 15) == 0;      // a thread's four cells then lie in one x row, 16-byte aligned
+    const int lane = threadIdx.x & 63;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int64_t li0 = (int64_t)tile * TILE + threadIdx.x * 4;
+        unsigned word = 0;                                   // the four cube indices, cell k in byte k
+        if (li0 < a.N) {
+            const int z = (int)(li0 / yx), rem = (int)(li0 - (int64_t)z * yx), y = rem / a.n2, x0 = rem - y * a.n2;
+            if (vec) {
+                const bool cellrow = z + 1 < a.n0 && y + 1 < a.n1;
+                const bool fifth = x0 + 4 < a.n2;            // the cell at x0 + 3 exists
+                unsigned above = 0;                          // bit q * 5 + i: value (row q, x0 + i) > iso  (== ((double)val - iso > 0), the library's test)
+                if (cellrow) {
+                    const float *p = a.vol + li0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float *pq = p + (q >> 1) * (int64_t)yx + (q & 1) * a.n2;
+                        const float4 v4 = *reinterpret_cast<const float4 *>(pq);
+                        above |= ((v4.x > a.iso_f ? 1u : 0u) | (v4.y > a.iso_f ? 2u : 0u) | (v4.z > a.iso_f ? 4u : 0u) | (v4.w > a.iso_f ? 8u : 0u)) << (q * 5);
+                    }
+                }
+                // fifth column = the next lane's first (the same rows, x0 + 4), unless that lane is in another wave or on another x row
+                const unsigned nb = __shfl_down(above, 1, 64);
+                const bool nb_ok = lane < 63 && fifth;       // (lane + 1 then holds x0 + 4 of the same (z, y): its li0 is this one's + 4)
+                unsigned col5 = (nb & 1u) | (((nb >> 5) & 1u) << 1) | (((nb >> 10) & 1u) << 2) | (((nb >> 15) & 1u) << 3);
+                if (cellrow && fifth && !nb_ok) {
+                    const float *p = a.vol + li0 + 4;
+                    col5 = (p[0] > a.iso_f ? 1u : 0u) | (p[a.n2] > a.iso_f ? 2u : 0u) | (p[yx] > a.iso_f ? 4u : 0u) | (p[(int64_t)yx + a.n2] > a.iso_f ? 8u : 0u);
+                }
+                if (!fifth) col5 = ((above >> 3) & 1u) | (((above >> 8) & 1u) << 1) | (((above >> 13) & 1u) << 2) | (((above >> 18) & 1u) << 3);
+                above |= ((col5 & 1u) << 4) | (((col5 >> 1) & 1u) << 9) | (((col5 >> 2) & 1u) << 14) | (((col5 >> 3) & 1u) << 19);
+                if (cellrow && above != 0u && above != 0xfffffu) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (k == 3 && !fifth) break;
+                        // corners 0..7 of the cell at x0 + k: (z,y,x) (z,y,x+1) (z,y+1,x+1) (z,y+1,x) (z+1,y,x) (z+1,y,x+1) (z+1,y+1,x+1) (z+1,y+1,x)
+                        const unsigned idx = ((above >> k) & 1u) | (((above >> (k + 1)) & 1u) << 1) | (((above >> (5 + k + 1)) & 1u) << 2) | (((above >> (5 + k)) & 1u) << 3) |
+                                             (((above >> (10 + k)) & 1u) << 4) | (((above >> (10 + k + 1)) & 1u) << 5) | (((above >> (15 + k + 1)) & 1u) << 6) |
+                                             (((above >> (15 + k)) & 1u) << 7);
+                        if (idx != 255u) word |= idx << (8 * k);
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t li = li0 + k;
+                    if (li >= a.N) break;
+                    const int zz = (int)(li / yx), r2 = (int)(li - (int64_t)zz * yx), yy = r2 / a.n2, xx = r2 - yy * a.n2;
+                    if (zz + 1 >= a.n0 || yy + 1 >= a.n1 || xx + 1 >= a.n2) continue;
+                    const float *p = a.vol + li;
+                    const float val[8] = {p[0], p[1], p[a.n2 + 1], p[a.n2], p[yx], p[yx + 1], p[yx + a.n2 + 1], p[yx + a.n2]};
+                    unsigned idx = 0;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) idx |= (val[c] > a.iso_f ? 1u : 0u) << c;
+                    if (idx != 255u) word |= idx << (8 * k);
+                }
+            }
+        }
+        const int any = __syncthreads_or(word != 0u);
+        if (threadIdx.x == 0) {
+            tile_v[tile] = 0; tile_t[tile] = 0; tile_c[tile] = 0;
+            if (any) list[atomicAdd(list_n, 1u)] = (unsigned)tile;
+        }
+        if (any && li0 < a.N) *reinterpret_cast<unsigned *>(idx8 + li0) = word;       // (the array is padded to whole tiles)
+    }
+}
+
+// ---------------- pass A2: the crossed tiles' cells -> tiling rows, counts ----------------
+// rows16: one int16 per grid point of a crossed tile (the tiling row of the cell whose low corner it is, -1 = not crossed / not a cell)
+__global__ __launch_bounds__(256) void mc_count_kernel(McArgs a, const unsigned *__restrict__ list, const unsigned *__restrict__ list_n,
+                                                       const uint8_t *__restrict__ idx8, unsigned *__restrict__ tile_v, unsigned *__restrict__ tile_t,
+                                                       unsigned *__restrict__ tile_c, int16_t *__restrict__ rows16)
 {
     __shared__ uint32_t tab[mc::BLOB_WORDS];
     __shared__ unsigned red[12];
+    const unsigned n = *list_n;
+    if (blockIdx.x >= n) return;
     load_tables(a.tables, tab);
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int yx = a.n1 * a.n2;
+    for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
+        const int tile = (int)list[it];
         unsigned nv = 0, nt = 0, nc = 0;
+        int rows[4] = {-1, -1, -1, -1};
+        const int64_t li0 = (int64_t)tile * TILE + threadIdx.x * 4;
+        const unsigned word = li0 < a.N ? *reinterpret_cast<const unsigned *>(idx8 + li0) : 0u;
+        if (word) {
 #pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
-            if (li >= a.N) break;
-            Cell c;
-            load_cell(a, li, tab, c);
-            if (c.row >= 0) {
-                nt += row_ntri(tab, c.row);
-                nv += __popc(row_mask(tab, c.row) & creator_mask(c.z, c.y, c.x));
-                nc += 1;
+            for (int k = 0; k < 4; ++k) {
+                const unsigned idx = (word >> (8 * k)) & 255u;
+                if (idx == 0u) continue;
+                const int64_t li = li0 + k;
+                const int z = (int)(li / yx), r2 = (int)(li - (int64_t)z * yx), y = r2 / a.n2, x = r2 - y * a.n2;
+                const float *p = a.vol + li;
+                const float val[8] = {p[0], p[1], p[a.n2 + 1], p[a.n2], p[yx], p[yx + 1], p[yx + a.n2 + 1], p[yx + a.n2]};
+                const int row = resolve_row(val, a, (int)idx, tab);
+                rows[k] = row;
+                if (row >= 0) {
+                    nt += row_ntri(tab, row);
+                    nv += __popc(row_mask(tab, row) & creator_mask(z, y, x));
+                    nc += 1;
+                }
             }
         }
         for (int o = 32; o > 0; o >>= 1) { nv += __shfl_down(nv, o, 64); nt += __shfl_down(nt, o, 64); nc += __shfl_down(nc, o, 64); }
@@ -295,35 +367,54 @@ __global__ __launch_bounds__(256) void mc_count_kernel(McArgs a, unsigned *__res
             tile_t[tile] = red[4] + red[5] + red[6] + red[7];
             tile_c[tile] = red[8] + red[9] + red[10] + red[11];
         }
+        if (li0 < a.N) {
+            const unsigned lo = ((unsigned)rows[0] & 0xffffu) | ((unsigned)rows[1] << 16), hi = ((unsigned)rows[2] & 0xffffu) | ((unsigned)rows[3] << 16);
+            *reinterpret_cast<uint2 *>(rows16 + li0) = make_uint2(lo, hi);
+        }
     }
 }
 
-// exclusive scan of three arrays (one workgroup of 1024); totals written to totals[0..2]
-__global__ void mc_scan_kernel(unsigned *__restrict__ t0, unsigned *__restrict__ t1, unsigned *__restrict__ t2, int n, unsigned long long *__restrict__ totals)
+// exclusive scan of three arrays by one workgroup of 1024: a batch of 16384 elements goes through LDS (coalesced in and out), a thread sums its 16
+// consecutive ones, the block scans the thread sums.  totals[0..2] = the sums, totals[3] = 1 when the mesh fits the caller's capacity (and 32-bit
+// indices), which the later passes require before they write anything.
+__global__ __launch_bounds__(1024) void mc_scan_kernel(unsigned *__restrict__ t0, unsigned *__restrict__ t1, unsigned *__restrict__ t2, int n,
+                                                       unsigned long long cap_v, unsigned long long cap_f, unsigned long long *__restrict__ totals)
 {
-    __shared__ unsigned buf[3][1024];
-    __shared__ unsigned carry[3];
+    constexpr int PER = 16, BATCH = 1024 * PER;
+    __shared__ unsigned buf[BATCH + BATCH / 16];             // padded: a thread's 16 consecutive words start 17 words apart
+    __shared__ unsigned wsum[16];
     unsigned *arr[3] = {t0, t1, t2};
-    if (threadIdx.x < 3) carry[threadIdx.x] = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < n; b0 += 1024) {
-        const int i = b0 + threadIdx.x;
-        unsigned v[3];
-        for (int q = 0; q < 3; ++q) { v[q] = i < n ? arr[q][i] : 0u; buf[q][threadIdx.x] = v[q]; }
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            unsigned add[3];
-            for (int q = 0; q < 3; ++q) add[q] = threadIdx.x >= o ? buf[q][threadIdx.x - o] : 0u;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    auto at = [](int i) { return i + (i >> 4); };
+    unsigned long long tot[3];
+    for (int q = 0; q < 3; ++q) {
+        unsigned long long carry = 0;
+        for (int b0 = 0; b0 < n; b0 += BATCH) {
+            for (int j = 0; j < PER; ++j) { const int i = j * 1024 + threadIdx.x; buf[at(i)] = b0 + i < n ? arr[q][b0 + i] : 0u; }
             __syncthreads();
-            for (int q = 0; q < 3; ++q) buf[q][threadIdx.x] += add[q];
+            unsigned v[PER], sum = 0;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) { v[j] = buf[at(threadIdx.x * PER + j)]; sum += v[j]; }
+            unsigned incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            if (lane == 63) wsum[w] = incl;
+            __syncthreads();
+            unsigned base = 0, all = 0;
+            for (int k = 0; k < 16; ++k) { if (k < w) base += wsum[k]; all += wsum[k]; }
+            unsigned run = (unsigned)carry + base + incl - sum;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) { buf[at(threadIdx.x * PER + j)] = run; run += v[j]; }
+            carry += all;
+            __syncthreads();
+            for (int j = 0; j < PER; ++j) { const int i = j * 1024 + threadIdx.x; if (b0 + i < n) arr[q][b0 + i] = buf[at(i)]; }
             __syncthreads();
         }
-        if (i < n) for (int q = 0; q < 3; ++q) arr[q][i] = carry[q] + buf[q][threadIdx.x] - v[q];
-        __syncthreads();
-        if (threadIdx.x == 1023) for (int q = 0; q < 3; ++q) carry[q] += buf[q][1023];
-        __syncthreads();
+        tot[q] = carry;
     }
-    if (threadIdx.x < 3) totals[threadIdx.x] = carry[threadIdx.x];
+    if (threadIdx.x == 0) {
+        totals[0] = tot[0]; totals[1] = tot[1]; totals[2] = tot[2];
+        totals[3] = (tot[0] <= cap_v && tot[1] <= cap_f && tot[0] < (1ull << 31) && tot[1] < (1ull << 31)) ? 1ull : 0ull;
+    }
 }
 
 // ---------------- pass B: vertices + normals ----------------
@@ -458,32 +549,38 @@ struct CellRec { uint32_t li, row, face0; int32_t cvid; };     // one per crosse
 // in a worst-case LDS array and the evaluation at the end of this kernel, by the lanes of the tile's workgroup: the case logic's 170 registers
 // held the 64-tap normal stencil at three waves per SIMD, and half of the lanes had no vertex.)
 __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, const unsigned *__restrict__ tile_voff, const unsigned *__restrict__ tile_toff,
-                                                       const unsigned *__restrict__ tile_coff, unsigned total_v, unsigned total_t,
-                                                       int32_t *__restrict__ edge_map, CellRec *__restrict__ cells, float *__restrict__ verts)
+                                                       const unsigned *__restrict__ tile_coff, const unsigned long long *__restrict__ totals,
+                                                       const unsigned *__restrict__ list, const unsigned *__restrict__ list_n,
+                                                       const int16_t *__restrict__ rows16, int32_t *__restrict__ edge_map, CellRec *__restrict__ cells,
+                                                       float *__restrict__ verts)
 {
     __shared__ uint32_t tab[mc::BLOB_WORDS];
     __shared__ unsigned red[4];
+    if (!totals[3]) return;                                  // the mesh does not fit the caller's buffers: nothing is written (AVC_ERR_CAPACITY)
+    const unsigned nlist = *list_n;
+    if (blockIdx.x >= nlist) return;
     load_tables(a.tables, tab);
     const int yx = a.n1 * a.n2;
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (unsigned it = blockIdx.x; it < nlist; it += gridDim.x) {          // the crossed tiles, in any order: their offsets say where they write
+        const int tile = (int)list[it];
         const unsigned vbase = tile_voff[tile], tbase = tile_toff[tile], cbase = tile_coff[tile];
-        const unsigned vnext = tile + 1 < a.ntiles ? tile_voff[tile + 1] : total_v;
-        const unsigned tnext = tile + 1 < a.ntiles ? tile_toff[tile + 1] : total_t;
-        if (vnext == vbase && tnext == tbase) continue;          // nothing crosses this tile (block-uniform)
-        int rows[4];
+        int rows[4] = {-1, -1, -1, -1};
         int cz[4], cy[4], cx[4];
         unsigned nv = 0, nt = 0, nc = 0;
-#pragma unroll 1
+        const int64_t li0 = (int64_t)tile * TILE + threadIdx.x * 4;
+        if (li0 < a.N) {
+            const uint2 rw = *reinterpret_cast<const uint2 *>(rows16 + li0);
+            rows[0] = (int16_t)(rw.x & 0xffffu); rows[1] = (int16_t)(rw.x >> 16); rows[2] = (int16_t)(rw.y & 0xffffu); rows[3] = (int16_t)(rw.y >> 16);
+        }
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
-            rows[k] = -1;
-            const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
-            if (li >= a.N) continue;
-            Cell c;
-            load_cell(a, li, tab, c);
-            rows[k] = c.row; cz[k] = c.z; cy[k] = c.y; cx[k] = c.x;
-            if (c.row >= 0) {
-                nt += row_ntri(tab, c.row);
-                nv += __popc(row_mask(tab, c.row) & creator_mask(c.z, c.y, c.x));
+            const int64_t li = li0 + k;
+            cz[k] = (int)(li / yx);
+            const int r = (int)(li - (int64_t)cz[k] * yx);
+            cy[k] = r / a.n2; cx[k] = r - cy[k] * a.n2;
+            if (rows[k] >= 0) {
+                nt += row_ntri(tab, rows[k]);
+                nv += __popc(row_mask(tab, rows[k]) & creator_mask(cz[k], cy[k], cx[k]));
                 nc += 1;
             }
         }
@@ -496,7 +593,7 @@ __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, con
             if (rows[k] < 0) continue;
             const int row = rows[k], n = 3 * row_ntri(tab, row);
             const unsigned creator = creator_mask(cz[k], cy[k], cx[k]);
-            const int64_t li = (int64_t)tile * TILE + threadIdx.x * 4 + k;
+            const int64_t li = li0 + k;
             unsigned seen = 0;
             int32_t cvid = -1;
             for (int i = 0; i < n; ++i) {
@@ -522,8 +619,11 @@ __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, con
 }
 
 // ---------------- pass B': positions + normals, one vertex per thread ----------------
-__global__ __launch_bounds__(256) void mc_eval_kernel(McArgs a, EmitArgs e, unsigned total_v, float *__restrict__ verts, float *__restrict__ normals)
+__global__ __launch_bounds__(256) void mc_eval_kernel(McArgs a, EmitArgs e, const unsigned long long *__restrict__ totals, float *__restrict__ verts,
+                                                      float *__restrict__ normals)
 {
+    if (!totals[3]) return;
+    const size_t total_v = (size_t)totals[0];
     const int yx = a.n1 * a.n2;
     for (size_t id = (size_t)blockIdx.x * 256 + threadIdx.x; id < total_v; id += (size_t)gridDim.x * 256) {
         const uint32_t *dw = reinterpret_cast<const uint32_t *>(verts) + 3 * id;
@@ -545,10 +645,12 @@ __global__ __launch_bounds__(256) void mc_eval_kernel(McArgs a, EmitArgs e, unsi
 }
 
 // ---------------- pass C: faces ----------------
-__global__ __launch_bounds__(256) void mc_faces_kernel(McArgs a, const CellRec *__restrict__ cells, unsigned ncells,
+__global__ __launch_bounds__(256) void mc_faces_kernel(McArgs a, const CellRec *__restrict__ cells, const unsigned long long *__restrict__ totals,
                                                        const int32_t *__restrict__ edge_map, int32_t *__restrict__ faces)
 {
     __shared__ uint32_t tab[mc::BLOB_WORDS];
+    if (!totals[3]) return;
+    const unsigned ncells = (unsigned)totals[2];
     load_tables(a.tables, tab);
     const int yx = a.n1 * a.n2;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < ncells; i += gridDim.x * 256u) {
@@ -584,12 +686,16 @@ int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float
         AVC_HIP(hipMemcpy(ctx->mc_tables_dev, mc::BLOB, sizeof(mc::BLOB), hipMemcpyHostToDevice));
     }
     a.tables = ctx->mc_tables_dev;
-    // scratch: 3 x tile sums [ntiles], totals[3] (u64), edge map 3 x int32 per grid point (sparsely written, never cleared)
+    // scratch: 3 x tile sums + the list of crossed tiles [ntiles each], totals[4] (u64) + the list's length, the cells' cube indices (1 byte) and rows
+    // (int16) per grid point of whole tiles, edge map 3 x int32 per grid point (sparsely written, never cleared)
     const size_t off_t = sizeof(unsigned) * (size_t)a.ntiles;
-    const size_t off_tot = (3 * off_t + 15) & ~(size_t)15;
-    const size_t off_map = off_tot + 32;
+    const size_t off_tot = (4 * off_t + 15) & ~(size_t)15;
+    const size_t off_idx = off_tot + 48;
+    const size_t off_rows = (off_idx + (size_t)a.ntiles * TILE + 15) & ~(size_t)15;
+    const size_t off_map = (off_rows + sizeof(int16_t) * (size_t)a.ntiles * TILE + 15) & ~(size_t)15;
     const size_t need = off_map + sizeof(int32_t) * 3 * (size_t)a.N;
     if (need > ctx->mc_scratch_bytes) {
+        AVC_HIP(hipStreamSynchronize(s));
         if (ctx->mc_scratch) AVC_HIP(hipFree(ctx->mc_scratch));
         ctx->mc_scratch = nullptr; ctx->mc_scratch_bytes = 0;
         AVC_HIP(hipMalloc(&ctx->mc_scratch, need));
@@ -597,13 +703,45 @@ int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float
     }
     char *base = (char *)ctx->mc_scratch;
     unsigned *tile_v = (unsigned *)base, *tile_t = (unsigned *)(base + off_t), *tile_c = (unsigned *)(base + 2 * off_t);
+    unsigned *list = (unsigned *)(base + 3 * off_t);
     unsigned long long *totals = (unsigned long long *)(base + off_tot);
+    unsigned *list_n = (unsigned *)(base + off_tot + 32);
+    uint8_t *idx8 = (uint8_t *)(base + off_idx);
+    int16_t *rows16 = (int16_t *)(base + off_rows);
     int32_t *edge_map = (int32_t *)(base + off_map);
+    // what the later passes may write: the caller's capacities (none without output buffers); a crossed cell has at least one triangle, so cap_f bounds
+    // the cell records too
+    const unsigned long long eff_v = verts ? (unsigned long long)std::max<int64_t>(cap_v, 0) : 0ull;
+    const unsigned long long eff_f = (verts && faces) ? (unsigned long long)std::max<int64_t>(cap_f, 0) : 0ull;
+    const size_t cell_bytes = sizeof(CellRec) * (size_t)eff_f;
+    if (cell_bytes > ctx->mc_cells_bytes) {
+        AVC_HIP(hipStreamSynchronize(s));
+        if (ctx->mc_cells) AVC_HIP(hipFree(ctx->mc_cells));
+        ctx->mc_cells = nullptr; ctx->mc_cells_bytes = 0;
+        AVC_HIP(hipMalloc(&ctx->mc_cells, cell_bytes + 4096));
+        ctx->mc_cells_bytes = cell_bytes + 4096;
+    }
+    CellRec *cells = (CellRec *)ctx->mc_cells;
+    EmitArgs e{};
+    for (int c = 0; c < 3; ++c) {
+        e.b0[c] = bounds[c];
+        e.len[c] = bounds[3 + c] - bounds[c];
+        e.vox[c] = e.len[c] / (float)res[c];
+    }
 
-    const int grid = std::min(a.ntiles, ctx->num_cus * 8);
-    hipLaunchKernelGGL(mc_count_kernel, dim3(grid), dim3(256), 0, s, a, tile_v, tile_t, tile_c);
-    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, tile_v, tile_t, tile_c, a.ntiles, totals);
-    unsigned long long h_tot[3];
+    const int grid = std::min(a.ntiles, ctx->num_cus * 8), lgrid = std::min(a.ntiles, ctx->num_cus * 4);
+    AVC_HIP(hipMemsetAsync(list_n, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(mc_classify_kernel, dim3(grid), dim3(256), 0, s, a, tile_v, tile_t, tile_c, idx8, list, list_n);
+    hipLaunchKernelGGL(mc_count_kernel, dim3(lgrid), dim3(256), 0, s, a, list, list_n, idx8, tile_v, tile_t, tile_c, rows16);
+    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, tile_v, tile_t, tile_c, a.ntiles, eff_v, eff_f, totals);
+    if (eff_v && eff_f) {
+        hipLaunchKernelGGL(mc_verts_kernel, dim3(lgrid), dim3(256), 0, s, a, e, tile_v, tile_t, tile_c, totals, list, list_n, rows16, edge_map, cells, verts);
+        const int egrid = (int)std::min<unsigned long long>((eff_v + 255ull) / 256ull, (unsigned long long)ctx->num_cus * 16ull);
+        hipLaunchKernelGGL(mc_eval_kernel, dim3(egrid), dim3(256), 0, s, a, e, totals, verts, normals);
+        const int fgrid = (int)std::min<unsigned long long>((eff_f + 255ull) / 256ull, (unsigned long long)ctx->num_cus * 8ull);
+        hipLaunchKernelGGL(mc_faces_kernel, dim3(fgrid), dim3(256), 0, s, a, cells, totals, edge_map, faces);
+    }
+    unsigned long long h_tot[4];
     AVC_HIP(hipMemcpyAsync(h_tot, totals, sizeof h_tot, hipMemcpyDeviceToHost, s));
     AVC_HIP(hipStreamSynchronize(s));
     counts[0] = (int64_t)h_tot[0]; counts[1] = (int64_t)h_tot[1];
@@ -613,28 +751,6 @@ int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float
     if (counts[1] == 0) return AVC_OK;
     AVC_REQUIRE(counts[0] < ((int64_t)1 << 31) && counts[1] < ((int64_t)1 << 31), AVC_ERR_ARG, "avc_recon_mesh: mesh too large for 32-bit indices");
     AVC_REQUIRE(verts && faces, AVC_ERR_ARG, "avc_recon_mesh: verts/faces output is NULL");
-    const size_t cell_bytes = sizeof(CellRec) * (size_t)h_tot[2];
-    if (cell_bytes > ctx->mc_cells_bytes) {
-        if (ctx->mc_cells) AVC_HIP(hipFree(ctx->mc_cells));
-        ctx->mc_cells = nullptr; ctx->mc_cells_bytes = 0;
-        const size_t want = cell_bytes + cell_bytes / 4 + 4096;
-        AVC_HIP(hipMalloc(&ctx->mc_cells, want));
-        ctx->mc_cells_bytes = want;
-    }
-    CellRec *cells = (CellRec *)ctx->mc_cells;
-    EmitArgs e{};
-    for (int c = 0; c < 3; ++c) {
-        e.b0[c] = bounds[c];
-        e.len[c] = bounds[3 + c] - bounds[c];
-        e.vox[c] = e.len[c] / (float)res[c];
-    }
-    hipLaunchKernelGGL(mc_verts_kernel, dim3(grid), dim3(256), 0, s, a, e, tile_v, tile_t, tile_c, (unsigned)h_tot[0], (unsigned)h_tot[1],
-                       edge_map, cells, verts);
-    const int egrid = (int)std::min<unsigned long long>((h_tot[0] + 255ull) / 256ull, (unsigned long long)ctx->num_cus * 16ull);
-    hipLaunchKernelGGL(mc_eval_kernel, dim3(egrid), dim3(256), 0, s, a, e, (unsigned)h_tot[0], verts, normals);
-    const unsigned ncells = (unsigned)h_tot[2];
-    const int fgrid = (int)std::min<unsigned>((ncells + 255u) / 256u, (unsigned)ctx->num_cus * 8u);
-    hipLaunchKernelGGL(mc_faces_kernel, dim3(fgrid), dim3(256), 0, s, a, cells, ncells, edge_map, faces);
     AVC_HIP(hipGetLastError());
     return AVC_OK;
 }
