@@ -8,7 +8,7 @@
     python bench.py --gpus 2 --dry-run                       (no GPU: launcher + gloo all-gather of stand-in meshes; what the CPU test runs)
 
 A step = one frame of BASELINE.json configs[1] ("AvatarNet occupancy-only, 256^3 grid, random SMPL
-pose") on every rank: UNet7DS pose-feature map (MIOpen) -> fused warp+template occupancy query over
+pose") on every rank: UNet7DS pose-feature map (the hand-written convolution kernel, csrc/conv_enc.hip) -> fused warp+template occupancy query over
 ALL 256^3 grid points (dense: nothing is masked out) -> marching cubes + normals -> KNN-4 LBS ->
 skinned live mesh, all on the device (avatarcap_amd.pipeline.FramePipeline.avatar_frame, i.e.
 main.py:357-367,383-389).  Frames are independent, so ranks process different frames (weak scaling,
@@ -362,7 +362,7 @@ def main():
                 t_lbs = timed(lbs_all)
                 mc_bytes, lbs_bytes = 4 * N + 24 * V + 12 * Fc, V * (12 + 96 + 24 + 12 + 12 + 64) + 83_000
                 line['roofline_secondary'] = {
-                    'marching cubes + normals (mesh.hip, 5 launches + one host sync)': {'bound': 'hbm', 'ms': t_mc * 1e3, 'algorithmic_bytes': mc_bytes,
+                    'marching cubes + normals (mesh.hip, 6 launches, one host wait at the end)': {'bound': 'hbm', 'ms': t_mc * 1e3, 'algorithmic_bytes': mc_bytes,
                                                                                        'achieved': mc_bytes / t_mc / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': mc_bytes / t_mc / 8e12},
                     'KNN-4 LBS + skinning of points and normals (knn_lbs.hip)': {'bound': 'hbm', 'ms': t_lbs * 1e3, 'algorithmic_bytes': lbs_bytes,
                                                                                 'achieved': lbs_bytes / t_lbs / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': lbs_bytes / t_lbs / 8e12,
@@ -438,12 +438,13 @@ def other_configs(device, frames=3):
         t_re, r = stage_ms(lambda: pipe.recon_frame(it), 3)
         imgs = torch.cat([it['front_normal'], it['back_normal']], dim=1)
         t_hg, _ = stage_ms(lambda: rn.bind_feat_map(imgs), 3)          # the encoder as recon_frame runs it: its channel-last output bound as the decoder's map
+        t_un, _ = stage_ms(lambda: net.warping_field.unet(items[1]['smpl_pos_map']), 3)
         leg = {'workload': 'AvatarCap full (main.py:357-453): avatar query + marching cubes + LBS, canonical normal fusion (100 iterations), HGFilter '
                            '(hand-written HIP encoder), reconstruction query + marching cubes + LBS; ' + what, 'vol_res': list(res), 'frames': frames,
                'valid_points': int(ds.infer_pts.shape[0]), 'valid_fraction': float(ds.infer_pts.shape[0]) / float(np.prod(res)),
                'ms_per_frame': full_ms, 'frames_per_s': 1e3 / full_ms,
                'stage_ms': {'avatar_frame (unet + band query + mc + lbs)': t_av, 'normal maps + fusion': t_fu,
-                            'recon_frame (hgfilter + band query + mc + lbs)': t_re, 'of which hgfilter': t_hg},
+                            'recon_frame (hgfilter + band query + mc + lbs)': t_re, 'of which hgfilter': t_hg, 'of which unet7ds (in avatar_frame)': t_un},
                'kernel_ms': {'avatar query (band, column-folded)': q[0][0].value, 'recon query (band, point by point on generated coordinates)': q[1][0].value},
                'avatar_vertices': int(a['cano_v'].shape[0]), 'recon_vertices': int(r['cano_v'].shape[0])}
         del ds, pipe, items, a, r, obs, fm, it, imgs
@@ -458,6 +459,7 @@ def other_configs(device, frames=3):
         'avatar band query (avatar_kernel, column-folded band)': {'bound': 'mfma', 'achieved_tflops': nb * FLOP_PER_POINT / (c2['kernel_ms']['avatar query (band, column-folded)'] * 1e-3) / 1e12},
         'recon band query (recon_kernel)': {'bound': 'mfma', 'achieved_tflops': nb * 387072 / (c2['kernel_ms']['recon query (band, point by point on generated coordinates)'] * 1e-3) / 1e12},
         'HGFilter encoder (conv_enc.hip, ~70 launches incl. their gaps)': {'bound': 'mfma', 'achieved_tflops': 232.3e9 / (c2['stage_ms']['of which hgfilter'] * 1e-3) / 1e12},
+        'UNet7DS (conv_enc.hip, 18 launches; weight-stream bound at its deep levels)': {'bound': 'mfma', 'achieved_tflops': 10.35e9 / (c2['stage_ms']['of which unet7ds (in avatar_frame)'] * 1e-3) / 1e12},
     }
     for v in out['secondary_rooflines'].values():
         v['peak_tflops'] = PEAK_F16_TFLOPS
