@@ -59,6 +59,7 @@ struct Options {
     int enc_graph = 1;        // the image encoder's launches replayed as a hipGraph
     int enc_ksplit = 1;       // convolutions with few workgroups split K over several (partial sums in HBM, added in a fixed order by the last to arrive)
     int enc_fork = 1;         // the hourglass' upper branches (b1_k) run on a second stream beside the lower ones
+    int mc_walk = 1;          // marching cubes: the classify pass that walks z inside a workgroup, where the volume's shape allows it (0: the general one)
 };
 
 }  // namespace avc

@@ -420,6 +420,7 @@ int avc_set_option(avc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "fusion_graph")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: fusion_graph is 0 or 1"); ctx->opt.fusion_graph = value; }
     else if (!strcmp(name, "enc_graph")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: enc_graph is 0 or 1"); ctx->opt.enc_graph = value; }
     else if (!strcmp(name, "enc_ksplit")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: enc_ksplit is 0 or 1"); ctx->opt.enc_ksplit = value; }
+    else if (!strcmp(name, "mc_walk")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: mc_walk is 0 or 1"); ctx->opt.mc_walk = value; }
     else if (!strcmp(name, "enc_fork")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: enc_fork is 0 or 1"); ctx->opt.enc_fork = value; }
     else AVC_REQUIRE(false, AVC_ERR_ARG, "avc_set_option: unknown option '%s'", name);
     return AVC_OK;

@@ -253,7 +253,7 @@ __device__ __forceinline__ unsigned block_exclusive(unsigned v, unsigned *lds4, 
 // tiles, which the later passes walk instead of the volume.  Every tile's three counters are zeroed here (pass A2 fills in the crossed ones).
 // Few registers, no tables: bound by the read of the volume.
 __global__ __launch_bounds__(256) void mc_classify_kernel(McArgs a, unsigned *__restrict__ tile_v, unsigned *__restrict__ tile_t, unsigned *__restrict__ tile_c,
-                                                          uint8_t *__restrict__ idx8, unsigned *__restrict__ list, unsigned *__restrict__ list_n)
+                                                          uint8_t *__restrict__ idx8)
 {
     const int yx = a.n1 * a.n2;
     const bool vec = (a.n2 & 3) == 0 && (reinterpret_cast<uintptr_t>(a.vol) & 15) == 0;      // a thread's four cells then lie in one x row, 16-byte aligned
@@ -314,12 +314,117 @@ __global__ __launch_bounds__(256) void mc_classify_kernel(McArgs a, unsigned *__
             }
         }
         const int any = __syncthreads_or(word != 0u);
-        if (threadIdx.x == 0) {
-            tile_v[tile] = 0; tile_t[tile] = 0; tile_c[tile] = 0;
-            if (any) list[atomicAdd(list_n, 1u)] = (unsigned)tile;
-        }
+        if (threadIdx.x == 0) { tile_v[tile] = 0; tile_t[tile] = 0; tile_c[tile] = any ? 1u : 0u; }      // tile_c: the "crossed" flag until pass A2 counts
         if (any && li0 < a.N) *reinterpret_cast<unsigned *>(idx8 + li0) = word;       // (the array is padded to whole tiles)
     }
+}
+
+// Pass A1 for volumes whose tiles are whole x rows of one z plane (n2 divides 1024, n1 a multiple of the 1024 / n2 rows of a tile: 256^3, 512^3,
+// 384 x 384 x 128 ...): a workgroup walks ZS consecutive z planes of one tile column and keeps the "above the level" bits of the plane it has just
+// read as the lower plane of the next cell layer, and a thread gets the bits of the row above its own (y + 1) from the thread that read it, through LDS:
+// one 16-byte load per thread and plane (plus one for the threads of a tile's last row) instead of four -- the general kernel above is bound by the
+// caches' request rate, four corner rows per cell row.  Same outputs, bit for bit (the bits are the same comparisons).
+template <int ZS>
+__global__ __launch_bounds__(256) void mc_classify_walk_kernel(McArgs a, unsigned *__restrict__ tile_v, unsigned *__restrict__ tile_t, unsigned *__restrict__ tile_c,
+                                                               uint8_t *__restrict__ idx8)
+{
+    __shared__ unsigned sh[2][256];
+    const int yx = a.n1 * a.n2, R = TILE / a.n2, TP = a.n1 / R, q4 = a.n2 >> 2;         // rows per tile, tiles per z plane, threads per row
+    const int lane = threadIdx.x & 63;
+    const int row = threadIdx.x / q4, x0 = (threadIdx.x - row * q4) * 4;
+    const bool fifth = x0 + 4 < a.n2;                      // the cell at x0 + 3 exists
+    const bool last_row = row + 1 == R;
+    const int nseg = (a.n0 + ZS - 1) / ZS;
+    unsigned flip = 0;
+    for (int work = blockIdx.x; work < TP * nseg; work += gridDim.x) {
+        const int yt = work % TP, z0 = (work / TP) * ZS, z1 = min(a.n0, z0 + ZS);
+        const int y = yt * R + row;
+        const bool has_y1 = y + 1 < a.n1;
+        // every load of the segment first (ZS + 1 planes of this thread's row; for a tile's last row also the row above, which belongs to the next tile):
+        // the pass is a latency chain otherwise -- one 16-byte load per thread between two barriers moves 1 TB/s, a stock reduction 2.7
+        const float *p0 = a.vol + ((int64_t)z0 * yx + (int64_t)y * a.n2 + x0);
+        float4 own[ZS + 1], upr[ZS + 1];
+#pragma unroll
+        for (int i = 0; i <= ZS; ++i) {
+            const bool in = z0 + i < a.n0;
+            own[i] = in ? *reinterpret_cast<const float4 *>(p0 + (int64_t)i * yx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            upr[i] = in && last_row && has_y1 ? *reinterpret_cast<const float4 *>(p0 + (int64_t)i * yx + a.n2) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // bits 0..4: a row at x0 .. x0 + 4 (the fifth column from the next lane, which holds x0 + 4 of the same row when that column exists and the lane is in this wave)
+        auto row_bits = [&](const float4 v4, const float *pr) -> unsigned {
+            unsigned b = (v4.x > a.iso_f ? 1u : 0u) | (v4.y > a.iso_f ? 2u : 0u) | (v4.z > a.iso_f ? 4u : 0u) | (v4.w > a.iso_f ? 8u : 0u);
+            const unsigned nb = __shfl_down(b, 1, 64);
+            unsigned c5 = (b >> 3) & 1u;                       // no fifth column: repeat the fourth (the cell at x0 + 3 is not a cell)
+            if (fifth) c5 = lane < 63 ? (nb & 1u) : (pr[4] > a.iso_f ? 1u : 0u);
+            return b | (c5 << 4);
+        };
+        // bits 0..4: row (z0 + i, y);  bits 5..9: row (z0 + i, y + 1), from the thread that read it (LDS) or from this thread's second load
+        auto plane_bits = [&](const float4 vo, const float4 vu, int i) -> unsigned {
+            const float *pr = p0 + (int64_t)i * yx;
+            const unsigned mine = row_bits(vo, pr);
+            sh[flip][threadIdx.x] = mine;
+            __syncthreads();
+            unsigned up = 0;
+            if (!last_row) up = sh[flip][threadIdx.x + q4];
+            else if (has_y1) up = row_bits(vu, pr + a.n2);
+            flip ^= 1u;
+            return mine | (up << 5);
+        };
+        unsigned lower = plane_bits(own[0], upr[0], 0);
+#pragma unroll
+        for (int i = 0; i < ZS; ++i) {
+            const int z = z0 + i;
+            if (z >= z1) break;                                  // (block-uniform)
+            const bool cells = z + 1 < a.n0 && has_y1;
+            const unsigned upper = z + 1 < a.n0 ? plane_bits(own[i + 1], upr[i + 1], i + 1) : 0u;
+            const unsigned above = lower | (upper << 10);
+            unsigned word = 0;
+            if (cells && above != 0u && above != 0xfffffu) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k == 3 && !fifth) break;
+                    const unsigned idx = ((above >> k) & 1u) | (((above >> (k + 1)) & 1u) << 1) | (((above >> (5 + k + 1)) & 1u) << 2) | (((above >> (5 + k)) & 1u) << 3) |
+                                         (((above >> (10 + k)) & 1u) << 4) | (((above >> (10 + k + 1)) & 1u) << 5) | (((above >> (15 + k + 1)) & 1u) << 6) |
+                                         (((above >> (15 + k)) & 1u) << 7);
+                    if (idx != 255u) word |= idx << (8 * k);
+                }
+            }
+            const int tile = z * TP + yt;
+            const int any = __syncthreads_or(word != 0u);
+            if (threadIdx.x == 0) { tile_v[tile] = 0; tile_t[tile] = 0; tile_c[tile] = any ? 1u : 0u; }
+            if (any) *reinterpret_cast<unsigned *>(idx8 + (int64_t)tile * TILE + threadIdx.x * 4) = word;
+            lower = upper;
+        }
+    }
+}
+
+// The list of crossed tiles from their flags, in tile order: one workgroup, 16 consecutive flags per thread, a block scan of the thread sums.  (An atomic
+// counter in the classify pass did this for free in the source and for 40 us on the device: ~5,000 same-address atomics are served one after the other.)
+__global__ __launch_bounds__(1024) void mc_compact_kernel(const unsigned *__restrict__ flags, int n, unsigned *__restrict__ list, unsigned *__restrict__ list_n)
+{
+    constexpr int PER = 16;
+    __shared__ unsigned wsum[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned carry = 0;
+    for (int b0 = 0; b0 < n; b0 += 1024 * PER) {
+        const int i0 = b0 + threadIdx.x * PER;
+        unsigned f[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { f[j] = i0 + j < n ? flags[i0 + j] : 0u; sum += f[j] != 0u; }
+        unsigned incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        __syncthreads();
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        unsigned base = 0, all = 0;
+        for (int k = 0; k < 16; ++k) { if (k < w) base += wsum[k]; all += wsum[k]; }
+        unsigned pos = carry + base + incl - sum;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (f[j]) list[pos++] = (unsigned)(i0 + j);
+        carry += all;
+    }
+    if (threadIdx.x == 0) *list_n = carry;
 }
 
 // ---------------- pass A2: the crossed tiles' cells -> tiling rows, counts ----------------
@@ -730,8 +835,20 @@ int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float
     }
 
     const int grid = std::min(a.ntiles, ctx->num_cus * 8), lgrid = std::min(a.ntiles, ctx->num_cus * 4);
-    AVC_HIP(hipMemsetAsync(list_n, 0, sizeof(unsigned), s));
-    hipLaunchKernelGGL(mc_classify_kernel, dim3(grid), dim3(256), 0, s, a, tile_v, tile_t, tile_c, idx8, list, list_n);
+    // whole x rows of one z plane per tile, 16-byte aligned rows: the walking classify (see its header); anything else: the general one
+    const bool walk = a.n2 >= 4 && TILE % a.n2 == 0 && a.n1 % (TILE / a.n2) == 0 && (reinterpret_cast<uintptr_t>(a.vol) & 15) == 0 && ctx->opt.mc_walk;
+    if (walk) {
+        const int TP = a.n1 / (TILE / a.n2);
+        int ZS = 8;                                            // planes per workgroup: 1 / ZS extra reads at the start of a segment against workgroups to fill the chip
+        while (ZS > 2 && TP * ((a.n0 + ZS - 1) / ZS) < ctx->num_cus * 4) ZS /= 2;
+        const int wgrid = std::min(TP * ((a.n0 + ZS - 1) / ZS), ctx->num_cus * 8);
+        if (ZS == 8) hipLaunchKernelGGL(mc_classify_walk_kernel<8>, dim3(wgrid), dim3(256), 0, s, a, tile_v, tile_t, tile_c, idx8);
+        else if (ZS == 4) hipLaunchKernelGGL(mc_classify_walk_kernel<4>, dim3(wgrid), dim3(256), 0, s, a, tile_v, tile_t, tile_c, idx8);
+        else hipLaunchKernelGGL(mc_classify_walk_kernel<2>, dim3(wgrid), dim3(256), 0, s, a, tile_v, tile_t, tile_c, idx8);
+    } else {
+        hipLaunchKernelGGL(mc_classify_kernel, dim3(grid), dim3(256), 0, s, a, tile_v, tile_t, tile_c, idx8);
+    }
+    hipLaunchKernelGGL(mc_compact_kernel, dim3(1), dim3(1024), 0, s, tile_c, a.ntiles, list, list_n);
     hipLaunchKernelGGL(mc_count_kernel, dim3(lgrid), dim3(256), 0, s, a, list, list_n, idx8, tile_v, tile_t, tile_c, rows16);
     hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, tile_v, tile_t, tile_c, a.ntiles, eff_v, eff_f, totals);
     if (eff_v && eff_f) {

@@ -354,6 +354,8 @@ int avc_timing_read_cycles(avc_ctx *ctx, int which, double *avg_cycles_out, int6
  *   "enc_graph"    1 (default: avc_hgfilter_forward replays a hipGraph) | 0 plain launches -- same kernels, same bits
  *   "enc_ksplit"   1 (default: a convolution that would run on fewer than half the CUs splits its input channels over several workgroups per
  *                  tile, whose partial sums the last to arrive adds in a fixed order) | 0 -- deterministic either way; the two differ by fp32 rounding
+ *   "mc_walk"      1 (default: marching cubes classifies volumes whose 1024-point tiles are whole x rows of one z plane -- 256^3, 512^3, 384 x 384 x 128 --
+ *                  with a pass that walks z inside a workgroup: a quarter of the cache requests) | 0 (the general classify pass for every volume); same results
  *   "enc_fork"     1 (default: the hourglass' upper branches run on a second stream -- parallel branches of the hipGraph -- beside the lower ones) |
  *                  0 one stream -- same kernels, same bits */
 int avc_set_option(avc_ctx *ctx, const char *name, int value);

@@ -184,3 +184,61 @@ def test_image_encoder_stays_inside(hw):
     finally:
         for name in ('enc_graph', 'enc_ksplit', 'enc_fork'):
             _lib.set_option(name, 1)
+
+
+@pytest.mark.parametrize('hw', [(128, 128), (128, 256)])
+def test_unet_stays_inside(hw):
+    """avc_unet_forward on position maps whose deep levels are one or two pixels wide (every convolution tile partial), with and without split-K / the
+    hipGraph: the NCHW output ends where it should and is finite; the framed input is not read past its ends."""
+    from avatarcap_amd.network.unets import UnetNoCond7DS
+    L = _lib.lib()
+    un = UnetNoCond7DS(input_nc=6, output_nc=64, nf=32).to('cuda').eval()
+    syn.load_synth(un, gi.SEED_NET)
+    ctx = un._ctx(torch.device('cuda', 0))
+    x = _framed(torch.randn(6, hw[0], hw[1], generator=torch.Generator().manual_seed(hw[1])).cuda())
+    try:
+        for graph, ksplit in ((1, 1), (0, 1), (1, 0)):
+            _lib.set_option('enc_graph', graph)
+            _lib.set_option('enc_ksplit', ksplit)
+            out = Guarded(64 * hw[0] * hw[1])
+            _lib.check(L.avc_unet_forward(ctx, x.ptr, hw[0], hw[1], out.ptr, 0, None))
+            _ok(out, x, finite=(out,))
+    finally:
+        _lib.set_option('enc_graph', 1)
+        _lib.set_option('enc_ksplit', 1)
+
+
+@pytest.mark.parametrize('n_rays,n_samples', [(0, 64), (1, 64), (3, 2), (65, 64), (130, 33), (7, 200)])
+def test_render_rays_and_blend_weights_stay_inside(n_rays, n_samples):
+    """avc_render_rays_cano with every optional output requested, at ray / sample counts around the wavefront size (its composite kernel takes 64 samples
+    per pass, 4 rays per workgroup), and avc_blend_weight_sample on a small volume with points at and beyond the borders."""
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar, OccupancyNet
+    from common import geotex_sd
+    config.cfg = config.default_cfg()
+    L, ctx = _lib.lib(), _lib.ctx(0)
+    net = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume()).to('cuda').eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in geotex_sd().items()})
+    net.warping_field.pose_feat_map = torch.from_numpy(gi.pose_feat_map()[None]).cuda()
+    center = torch.from_numpy(gi.center()[None]).cuda()
+    OccupancyNet(net).query({'cano_pts': torch.from_numpy(gi.query_points(5, 8)).cuda()[None], 'cano_smpl_center': center})     # packs + binds
+    g = torch.Generator().manual_seed(n_rays * 131 + n_samples)
+    P, S = n_rays, n_samples
+    d = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=1)
+    o = _framed((torch.rand(P, 3, generator=g) * 0.6 - 0.3 + d).cuda())
+    dd = _framed((-d).cuda())
+    near, far = _framed(torch.full((P,), 0.95).cuda()), _framed(torch.full((P,), 1.05).cuda())
+    depth = _framed((torch.rand(P, generator=g) > 0.3).float().cuda())
+    t = _framed(torch.linspace(0., 1., steps=S).cuda())
+    smpl = _framed(torch.from_numpy(syn.synthetic_body()['cano_smpl_v']).cuda())
+    rgb, acc, dep, disp, wts, raw = Guarded(3 * P), Guarded(P), Guarded(P), Guarded(P), Guarded(P * S), Guarded(4 * P * S)
+    c3, b6 = (C.c_float * 3)(*gi.center().tolist()), (C.c_float * 6)(*syn.CANO_BOUNDS.reshape(-1).tolist())
+    _lib.check(L.avc_render_rays_cano(ctx, o.ptr, dd.ptr, near.ptr, far.ptr, depth.ptr, 0.02, 0.05, t.ptr, P, S, c3, b6, smpl.ptr, smpl.t.numel() // 3, 0,
+                                      rgb.ptr, acc.ptr, dep.ptr, disp.ptr, wts.ptr, raw.ptr, None))
+    _ok(rgb, acc, dep, disp, wts, raw, o, dd, near, far, depth, t, smpl, finite=(rgb, acc, dep, wts, raw))
+    vol = _framed(torch.from_numpy(gi.blend_weight_volume()).cuda())
+    X, Y, Z, Cn = gi.blend_weight_volume().shape
+    n = P * 3 + 1
+    pts = _framed((torch.rand(n, 3, generator=g) * 1.4 - 0.2).cuda())              # inside, on and beyond the unit cube
+    out = Guarded(n * Cn)
+    _lib.check(L.avc_blend_weight_sample(ctx, vol.ptr, (C.c_int32 * 3)(X, Y, Z), Cn, pts.ptr, n, out.ptr, None))
+    _ok(out, vol, pts, finite=(out,))

@@ -218,3 +218,28 @@ def test_scatter_volume():
     _lib.check(_lib.lib().avc_scatter_volume(_lib.ctx(), tv.data_ptr(), N, tval.data_ptr(), tf.data_ptr(), vol.data_ptr(), _lib.stream_ptr()))
     ref = np.empty(N, np.float32); ref[valid] = values; ref[~valid] = fill          # main.py:362-363
     assert np.array_equal(vol.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('res,kind', [((64, 64, 64), 'blobs'), ((19, 32, 128), 'noise'), ((9, 8, 256), 'noise'), ((5, 6, 512), 'noise'), ((4, 3, 1024), 'noise'),
+                                      ((33, 64, 16), 'noise'), ((40, 512, 4), 'ints'), ((2, 16, 64), 'noise'), ((17, 48, 128), 'torus')])
+def test_recon_mesh_walking_classify_equals_the_general_one(res, kind):
+    """Volumes whose 1024-point tiles are whole x rows of one z plane take the classify pass that walks z inside a workgroup (avc_set_option "mc_walk"):
+    the mesh must be the oracle's bit for bit, and the general pass's, on shapes that put 1, 2, 4, 8, 16, 64 and 256 rows into a tile, a last axis shorter
+    than a wavefront's reach, a first axis that is not a multiple of the z segment and the two-plane minimum."""
+    from avatarcap_amd.utils import recon_util
+    from oracle import avatarcap_oracle as orc
+    assert 1024 % res[2] == 0 and res[1] % (1024 // res[2]) == 0
+    vol = np.random.RandomState(sum(res)).randint(-2, 3, res).astype(np.float32) if kind == 'ints' else _fields(res, kind, seed=sum(res))
+    iso = 0.1 if kind == 'noise' else 0.0
+    out = {}
+    for walk in (1, 0):
+        _lib.set_option('mc_walk', walk)
+        try:
+            out[walk] = recon_util.recon_mesh(_t(vol), list(res), syn.CANO_BOUNDS, iso_value=iso)
+        finally:
+            _lib.set_option('mc_walk', 1)
+    ov, of, _ = orc.recon_mesh(vol, list(res), syn.CANO_BOUNDS, iso)
+    for walk in (1, 0):
+        v, f, n = out[walk]
+        assert f.shape == of.shape and np.array_equal(f, of) and v.shape == ov.shape and np.array_equal(v, ov), f'mc_walk {walk}'
+    assert np.array_equal(out[0][2], out[1][2])

@@ -27,3 +27,11 @@ for wn in (True,):
     for _ in range(20): v, f, n = recon_util.recon_mesh_device(lvl, res, syn.CANO_BOUNDS, iso_value=0.0, with_normals=wn)
     e1.record(); torch.cuda.synchronize()
     print(f'rippled ellipsoid, res {res} normals={wn}: {e0.elapsed_time(e1) / 20:.3f} ms  {v.shape[0]} vertices {f.shape[0]} faces', flush=True)
+# reference points for the classify pass (one streaming read of the same 67 MB): what stock reductions take on this box
+for name, fn in (('lvl.sum()', lambda: lvl.sum()), ('(lvl > 0).sum()', lambda: (lvl > 0).sum()), ('lvl.max()', lambda: lvl.max())):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f'{name}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us  ({lvl.numel() * 4 / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e12:.2f} TB/s)', flush=True)
