@@ -107,6 +107,8 @@ struct ConvArgs {
     unsigned *kcounter;          // split-K: one ticket per (tile, slice)
     unsigned *range_flag;        // set to 1 when a staged value exceeds the fp16 range of the split (avc_set_range_check reads it)
     OutSpec oa, ob;              // generic outputs (the U-Net's layouts); when oa.ptr != null they replace raw / y and no statistics are produced
+    int tap_mode, tap_div;       // TAPS == 4: where the 2 x 2 taps start in the 3 x 3 neighbourhood: 1 = by input parity (chunk / tap_div: stride-2 convolution
+                                 // of a space-to-depth tensor, origin (1 - py, 1 - px)), 2 = by output parity (output channel / tap_div: transposed convolution, (a, b))
 };
 
 __device__ __forceinline__ float relu_bits(float x)
@@ -208,9 +210,10 @@ template <int PT, int TAPS, int TWC>
 struct ConvGeo {
     static constexpr int PTR = 32 / TWC;                          // image rows of one pixel tile
     static constexpr int ROWS = 4 * PT * PTR;                     // image rows of the workgroup's tile
-    // halo: 3x3 pad 1; 4x4 (the space-to-depth form of conv1's 7x7 stride 2 pad 3) 2 before and 1 after; 1x1 none
-    static constexpr int PAD = TAPS == 9 ? 1 : (TAPS == 16 ? 2 : 0), PADH = TAPS == 9 ? 1 : (TAPS == 16 ? 1 : 0);
-    static constexpr int KW = TAPS == 9 ? 3 : (TAPS == 16 ? 4 : 1);
+    // halo: 3x3 pad 1; 4x4 (the space-to-depth form of conv1's 7x7 stride 2 pad 3) 2 before and 1 after; 1x1 none; TAPS == 4: the 2 x 2 taps of a 3 x 3
+    // neighbourhood that a stride-2 4 x 4 kernel leaves non-zero for one input (output) parity -- the 3 x 3 halo, walked from a runtime origin
+    static constexpr int PAD = (TAPS == 9 || TAPS == 4) ? 1 : (TAPS == 16 ? 2 : 0), PADH = (TAPS == 9 || TAPS == 4) ? 1 : (TAPS == 16 ? 1 : 0);
+    static constexpr int KW = TAPS == 9 ? 3 : (TAPS == 16 ? 4 : (TAPS == 4 ? 2 : 1));
     static constexpr int HR = ROWS + PAD + PADH, HC = TWC + PAD + PADH;
     static constexpr int RP = TAPS == 1 ? TWC : (TWC == 32 ? HC : 32);       // LDS row pitch in pixels (32 for the 16-wide tiles: bank note in DESIGN.md)
     static constexpr int NPIX = HR * RP;
@@ -385,10 +388,16 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
     // the next chunk's staged tile is transformed and written late: consuming a staging load waits for every weight group requested before it
     // (vmcnt completes in order), so it is consumed where those groups are due anyway: from the second group on when two are in flight, in the
     // chunk's last group otherwise
-    constexpr int T0 = TAPS == 1 ? 0 : (LA == 2 ? G : G * (NG - 1));
+    constexpr int T0 = (TAPS == 1 || NG == 1) ? 0 : (LA == 2 ? G : G * (NG - 1));
     for (int c = c0; c < c1; ++c) {
         const unsigned abuf = ((c - c0) & 1) ? LDS_ACT1 : LDS_ACT0, nbuf = ((c - c0) & 1) ? LDS_ACT0 : LDS_ACT1;
         const bool more = c + 1 < c1;
+        unsigned org = 0;
+        if constexpr (TAPS == 4) {
+            const int par = p.tap_mode == 1 ? c / p.tap_div : (int)(slice * CT * 32) / p.tap_div;
+            const int ty0 = p.tap_mode == 1 ? 1 - (par >> 1) : (par >> 1), tx0 = p.tap_mode == 1 ? 1 - (par & 1) : (par & 1);
+            org = (unsigned)((ty0 * RP + tx0) * PIXB);
+        }
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value, NT = group_taps(g);
             const int gi = (c - c0) * NG + g;
@@ -409,8 +418,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
                     }
 #pragma unroll
                     for (int n = 0; n < PT; ++n) {
-                        ah[n] = *reinterpret_cast<const half8 *>(smem + abuf + abase[n] + toff + kk * 32);
-                        al[n] = *reinterpret_cast<const half8 *>(smem + abuf + abase[n] + toff + kk * 32 + 64);
+                        ah[n] = *reinterpret_cast<const half8 *>(smem + abuf + abase[n] + org + toff + kk * 32);
+                        al[n] = *reinterpret_cast<const half8 *>(smem + abuf + abase[n] + org + toff + kk * 32 + 64);
                     }
 #pragma unroll
                     for (int n = 0; n < PT; ++n)
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         }
     };
     // the U-Net's outputs: any layout, no residual, no statistics; these launches are small (the whole U-Net is 10 GFLOP), the addressing is per element
-    if constexpr (!NORM && TAPS == 9) {                    // the U-Net's layouts (only its launches set oa)
+    if constexpr (!NORM && (TAPS == 9 || TAPS == 4)) {     // the U-Net's layouts (only its launches set oa)
         if (p.oa.ptr) {
             // element offset = f(iy) + g(ix) + k(co) in every layout (see OutSpec); k per channel tile here, f + g per pixel below
             auto chan = [&](const OutSpec &o, unsigned co) -> int {
@@ -1314,6 +1323,7 @@ static int launch_conv(const Launch &L, hipStream_t s)
 #define AVC_ENC_GEO(TAPS_, NORM_) AVC_ENC_CT(2, TAPS_, 32, NORM_) AVC_ENC_CT(1, TAPS_, 32, NORM_) AVC_ENC_CT(1, TAPS_, 16, NORM_)
     AVC_ENC_GEO(9, true)
     AVC_ENC_GEO(9, false)
+    AVC_ENC_GEO(4, false)
     AVC_ENC_GEO(1, true)
     AVC_ENC_GEO(1, false)
     AVC_ENC_CASE(2, 1, 16, 32, false)
@@ -1467,6 +1477,8 @@ int encoder_debug_tensor(avc_ctx *ctx, int launch, int which, float *out, int *C
 // The warping field's U-Net (UnetNoCond7DS, network/unets.py:169-229; blocks :10-60) on the same convolution kernel
 // =====================================================================================================================
 // Every layer becomes ONE launch of conv_mfma_kernel<.., TAPS = 9, .., NORM = false> on tensors that are already in the layout the next layer reads:
+//   (Of the 3x3 neighbourhood of a space-to-depth pixel only 2 x 2 taps meet the 4x4 kernel for a given input parity -- likewise for a given output parity
+//   of a transposed convolution: those layers are packed and walked as 4 taps from a per-chunk / per-slice origin, TAPS == 4.)
 //   Conv2DBlock (LeakyReLU(0.2) -> Conv2d k4 s2 p1 -> BatchNorm2d(affine=False)):  a stride-2 4x4 convolution is a 3x3 convolution (pad 1) of the
 //     space-to-depth tensor (4 C channels per pixel: input row 2 o - 1 + k is row o - 1 + ty of parity py with k = 2 ty + py - 1); its producer writes the
 //     s2d form directly (OUT_S2D), plus the plain form into its channel slice of the decoder tensor it will be concatenated into (OUT_NORMAL: torch.cat
@@ -1506,6 +1518,21 @@ int pack_unet(avc_ctx *ctx, const avc_unet7ds *net)
         AVC_REQUIRE(l == 0 ? c.cin * 4 <= 32 : (c.cin == net->down[l - 1].cout), AVC_ERR_ARG, "avc_unet_pack: %s: %d input channels", nm, c.cin);
         if (int rc = fold_bn(net->down_bn[l], c.cout, sc, sh, nm)) return rc;
         const int ci4 = l == 0 ? 32 : 4 * c.cin;
+        if (l > 0 && c.cin % 32 == 0) {
+            // a chunk of 32 space-to-depth channels lies inside one parity (py, px): only the 2 x 2 taps (1 - py + a, 1 - px + b) of its 3 x 3 neighbourhood
+            // meet the 4 x 4 kernel (k = 1 - py + 2 a): packed and walked as 4 taps from that origin -- 4/9 of the bytes and MFMAs of the 3 x 3 form
+            std::vector<float> w((size_t)c.cout * ci4 * 4, 0.0f);
+            for (int co = 0; co < c.cout; ++co)
+                for (int par = 0; par < 4; ++par)
+                    for (int ci = 0; ci < c.cin; ++ci)
+                        for (int t = 0; t < 4; ++t) {
+                            const int ky = 1 - (par >> 1) + 2 * (t >> 1), kx = 1 - (par & 1) + 2 * (t & 1);
+                            w[((size_t)co * ci4 + par * c.cin + ci) * 4 + t] = c.w[(((size_t)co * c.cin + ci) * 4 + ky) * 4 + kx] * sc[co];
+                        }
+            const avc_conv2d c2{w.data(), sh.data(), c.cout, ci4, 2, 2};
+            if (int rc = pack_conv(e, c2, 4, e->u_down[l], nm, 2 * conv_ct(c.cout) - 1)) return rc;
+            continue;
+        }
         std::vector<float> w((size_t)c.cout * ci4 * 9, 0.0f);
         for (int co = 0; co < c.cout; ++co)
             for (int par = 0; par < 4; ++par)
@@ -1525,20 +1552,19 @@ int pack_unet(avc_ctx *ctx, const avc_unet7ds *net)
         snprintf(nm, sizeof nm, "upconv%d", l + 1);
         AVC_REQUIRE(c.w && c.kh == 4 && c.kw == 4 && !c.b && c.cout % 32 == 0 && c.cin % 32 == 0, AVC_ERR_ARG, "avc_unet_pack: %s must be ConvTranspose2d(k4, s2, p1, bias=False)", nm);
         if (int rc = fold_bn(net->up_bn[l], c.cout, sc, sh, nm)) return rc;
-        std::vector<float> w((size_t)4 * c.cout * c.cin * 9, 0.0f), b((size_t)4 * c.cout);
+        // output parity (a, b) takes the 2 x 2 taps (a + ta, b + tb) of the 3 x 3 neighbourhood, with k = 3 - a - 2 ta: 4 taps from an origin per output slice
+        std::vector<float> w((size_t)4 * c.cout * c.cin * 4, 0.0f), b((size_t)4 * c.cout);
         for (int par = 0; par < 4; ++par)
             for (int co = 0; co < c.cout; ++co) {
                 b[(size_t)par * c.cout + co] = sh[co];
                 for (int ci = 0; ci < c.cin; ++ci)
-                    for (int ty = 0; ty < 3; ++ty)
-                        for (int tx = 0; tx < 3; ++tx) {
-                            const int ky = (par >> 1) + 3 - 2 * ty, kx = (par & 1) + 3 - 2 * tx;
-                            if (ky < 0 || ky > 3 || kx < 0 || kx > 3) continue;
-                            w[(((size_t)par * c.cout + co) * c.cin + ci) * 9 + ty * 3 + tx] = c.w[(((size_t)ci * c.cout + co) * 4 + ky) * 4 + kx] * sc[co];
-                        }
+                    for (int t = 0; t < 4; ++t) {
+                        const int ky = 3 - (par >> 1) - 2 * (t >> 1), kx = 3 - (par & 1) - 2 * (t & 1);
+                        w[(((size_t)par * c.cout + co) * c.cin + ci) * 4 + t] = c.w[(((size_t)ci * c.cout + co) * 4 + ky) * 4 + kx] * sc[co];
+                    }
             }
-        const avc_conv2d c3{w.data(), b.data(), 4 * c.cout, c.cin, 3, 3};
-        if (int rc = pack_conv(e, c3, 9, e->u_up[l], nm, 7)) return rc;
+        const avc_conv2d c2{w.data(), b.data(), 4 * c.cout, c.cin, 2, 2};
+        if (int rc = pack_conv(e, c2, 4, e->u_up[l], nm, 7)) return rc;
     }
     // ---- upconvC5..C7: Conv2d(ci, co, 3, 1, 1, bias=True) behind the bilinear upsample
     for (int l = 0; l < 3; ++l) {
@@ -1575,7 +1601,7 @@ static int build_unet_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
     // one convolution: x (raw, pre-activation `slope`) -> the two generic outputs
     auto conv = [&](const DevConv &w, const Tensor &x, float slope, OutSpec oa, OutSpec ob) {
         if (P.rc) return;
-        Launch L{}; L.kind = L_CONV; L.TAPS = 9; L.norm = false;
+        Launch L{}; L.kind = L_CONV; L.TAPS = w.taps; L.norm = false;
         L.TWC = x.W >= 32 ? 32 : 16;
         const int nchunk = x.C / 32;
         auto tiles = [&](int PT) { const int rows = 4 * PT * (32 / L.TWC); return ((x.H + rows - 1) / rows) * ((x.W + L.TWC - 1) / L.TWC); };
@@ -1586,11 +1612,12 @@ static int build_unet_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
         // launch is as fast as it has workgroups.  Narrower channel slices (CT) and a deeper split of K until the chip is full; the larger CT on a tie.
         if (ctx->opt.enc_ksplit && tiles(L.PT) * (w.cout / (32 * L.CT)) < ctx->num_cus) {
             int best = 0;
+            constexpr int ks_cap = 8;                          // beyond 8 slices the exchange of partial sums costs more than the shorter K walk saves (4 / 8 / 16: 0.282 / 0.263 / 0.297 ms per map)
             for (int ct = L.CT; ct >= 1; ct >>= 1) {
                 if (!(w.ct_mask & ct)) continue;
                 const int wg0 = tiles(1) * (w.cout / (32 * ct));
                 int k = 1;
-                while (nchunk % (2 * k) == 0 && k < 16 && 2 * wg0 * k <= ctx->num_cus) k *= 2;
+                while (nchunk % (2 * k) == 0 && k < ks_cap && 2 * wg0 * k <= ctx->num_cus) k *= 2;
                 if (wg0 * k > best) { best = wg0 * k; L.CT = ct; ks = k; }
             }
             L.PT = 1;
@@ -1600,11 +1627,15 @@ static int build_unet_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
         a.x = x.data; a.H = x.H; a.W = x.W; a.Cin = x.C;
         a.in_cpg = 1; a.in_scale = 16.0f; a.in_slope = slope;
         const int v = L.CT == 4 ? 2 : (L.CT == 2 ? 1 : 0);
-        a.slice_bytes = (unsigned)nchunk * 9 * 2 * L.CT * 2048;
+        a.slice_bytes = (unsigned)nchunk * w.taps * 2 * L.CT * 2048;
         a.wstream = w.wstream + w.off[v]; a.wbytes = a.slice_bytes * (w.cout / (32 * L.CT));
         a.bias = w.bias; a.out_scale = w.wscale_inv / a.in_scale; a.Cout = w.cout;
         a.tiles_x = (x.W + L.TWC - 1) / L.TWC; a.tiles_y = (x.H + rows - 1) / rows;
         a.oa = oa; a.ob = ob;
+        if (w.taps == 4) {                                     // by input parity for the stride-2 convolutions, by output parity for the transposed ones
+            a.tap_mode = oa.layout == OUT_D2S ? 2 : 1;
+            a.tap_div = oa.layout == OUT_D2S ? w.cout / 4 : nchunk / 4;
+        }
         a.range_flag = e->range_flag;
         const int wg = a.tiles_x * a.tiles_y * (w.cout / (32 * L.CT));
         a.ksplit = ks;
