@@ -439,6 +439,7 @@ __global__ __launch_bounds__(256) void mc_count_kernel(McArgs a, const unsigned 
     if (blockIdx.x >= n) return;
     load_tables(a.tables, tab);
     const int yx = a.n1 * a.n2;
+    const bool vec = (a.n2 & 3) == 0 && (reinterpret_cast<uintptr_t>(a.vol) & 15) == 0;      // a thread's four cells lie in one x row, 16-byte aligned
     for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
         const int tile = (int)list[it];
         unsigned nv = 0, nt = 0, nc = 0;
@@ -446,20 +447,48 @@ __global__ __launch_bounds__(256) void mc_count_kernel(McArgs a, const unsigned 
         const int64_t li0 = (int64_t)tile * TILE + threadIdx.x * 4;
         const unsigned word = li0 < a.N ? *reinterpret_cast<const unsigned *>(idx8 + li0) : 0u;
         if (word) {
+            const int z = (int)(li0 / yx), r2 = (int)(li0 - (int64_t)z * yx), y = r2 / a.n2, x0 = r2 - y * a.n2;
+            if (vec) {
+                // the four corner rows of the thread's four cells in one round of loads (a crossed cell exists: the rows (z + 1, .) and (., y + 1) do)
+                float r[4][5];
+                const bool fifth = x0 + 4 < a.n2;
+                const float *p = a.vol + li0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float *pq = p + (q >> 1) * (int64_t)yx + (q & 1) * a.n2;
+                    const float4 v4 = *reinterpret_cast<const float4 *>(pq);
+                    r[q][0] = v4.x; r[q][1] = v4.y; r[q][2] = v4.z; r[q][3] = v4.w;
+                    r[q][4] = fifth ? pq[4] : v4.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned idx = (word >> (8 * k)) & 255u;
+                    if (idx == 0u) continue;
+                    const float val[8] = {r[0][k], r[0][k + 1], r[1][k + 1], r[1][k], r[2][k], r[2][k + 1], r[3][k + 1], r[3][k]};
+                    const int row = resolve_row(val, a, (int)idx, tab);
+                    rows[k] = row;
+                    if (row >= 0) {
+                        nt += row_ntri(tab, row);
+                        nv += __popc(row_mask(tab, row) & creator_mask(z, y, x0 + k));
+                        nc += 1;
+                    }
+                }
+            } else {
 #pragma unroll 1
-            for (int k = 0; k < 4; ++k) {
-                const unsigned idx = (word >> (8 * k)) & 255u;
-                if (idx == 0u) continue;
-                const int64_t li = li0 + k;
-                const int z = (int)(li / yx), r2 = (int)(li - (int64_t)z * yx), y = r2 / a.n2, x = r2 - y * a.n2;
-                const float *p = a.vol + li;
-                const float val[8] = {p[0], p[1], p[a.n2 + 1], p[a.n2], p[yx], p[yx + 1], p[yx + a.n2 + 1], p[yx + a.n2]};
-                const int row = resolve_row(val, a, (int)idx, tab);
-                rows[k] = row;
-                if (row >= 0) {
-                    nt += row_ntri(tab, row);
-                    nv += __popc(row_mask(tab, row) & creator_mask(z, y, x));
-                    nc += 1;
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned idx = (word >> (8 * k)) & 255u;
+                    if (idx == 0u) continue;
+                    const int64_t li = li0 + k;
+                    const int zz = (int)(li / yx), r3 = (int)(li - (int64_t)zz * yx), yy = r3 / a.n2, xx = r3 - yy * a.n2;
+                    const float *p = a.vol + li;
+                    const float val[8] = {p[0], p[1], p[a.n2 + 1], p[a.n2], p[yx], p[yx + 1], p[yx + a.n2 + 1], p[yx + a.n2]};
+                    const int row = resolve_row(val, a, (int)idx, tab);
+                    rows[k] = row;
+                    if (row >= 0) {
+                        nt += row_ntri(tab, row);
+                        nv += __popc(row_mask(tab, row) & creator_mask(zz, yy, xx));
+                        nc += 1;
+                    }
                 }
             }
         }
@@ -852,7 +881,7 @@ int recon_mesh(avc_ctx *ctx, const float *vol, const int32_t res[3], const float
     hipLaunchKernelGGL(mc_count_kernel, dim3(lgrid), dim3(256), 0, s, a, list, list_n, idx8, tile_v, tile_t, tile_c, rows16);
     hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, s, tile_v, tile_t, tile_c, a.ntiles, eff_v, eff_f, totals);
     if (eff_v && eff_f) {
-        hipLaunchKernelGGL(mc_verts_kernel, dim3(lgrid), dim3(256), 0, s, a, e, tile_v, tile_t, tile_c, totals, list, list_n, rows16, edge_map, cells, verts);
+        hipLaunchKernelGGL(mc_verts_kernel, dim3(grid), dim3(256), 0, s, a, e, tile_v, tile_t, tile_c, totals, list, list_n, rows16, edge_map, cells, verts);
         const int egrid = (int)std::min<unsigned long long>((eff_v + 255ull) / 256ull, (unsigned long long)ctx->num_cus * 16ull);
         hipLaunchKernelGGL(mc_eval_kernel, dim3(egrid), dim3(256), 0, s, a, e, totals, verts, normals);
         const int fgrid = (int)std::min<unsigned long long>((eff_f + 255ull) / 256ull, (unsigned long long)ctx->num_cus * 8ull);
