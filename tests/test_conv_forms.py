@@ -1,4 +1,4 @@
-"""The algebra the HIP U-Net rests on (csrc/conv_enc.hip, pack_unet), checked on the CPU with stock torch ops:
+"""The algebra the HIP encoders rest on (csrc/conv_enc.hip: pack_unet, pack_encoder, the up-sampling kernels), checked on the CPU with stock torch ops:
   * Conv2d(k4, s2, p1) == a 3x3 convolution (pad 1) of the space-to-depth tensor, and only the 2 x 2 taps (1 - py + a, 1 - px + b) of the 3 x 3
     neighbourhood are non-zero for input parity (py, px): the 4-tap form with kernel index k = 1 - p + 2 a;
   * ConvTranspose2d(k4, s2, p1) == a 3x3 convolution with 4 Cout parity-major outputs scattered depth-to-space, and output parity (a, b) takes only the
@@ -100,4 +100,48 @@ def test_bilinear_x2_is_the_four_tap_formula_of_up2_kernel():
         for ox in range(2 * W):
             rx = max((ox + 0.5) * 0.5 - 0.5, 0.0); x0 = int(rx); x1 = min(x0 + 1, W - 1); lx = rx - x0
             out[0, :, oy, ox] = (x[0, :, y0, x0] * (1 - ly) * (1 - lx) + x[0, :, y0, x1] * (1 - ly) * lx + x[0, :, y1, x0] * ly * (1 - lx) + x[0, :, y1, x1] * ly * lx)
+    assert torch.allclose(out, ref, atol=1e-12)
+
+
+def test_hgfilter_conv1_is_a_4x4_tap_conv_of_the_space_to_depth_image():
+    """pack_encoder: Conv2d(6, 64, 7, stride 2, padding 3) (HGFilters.py:134) == a 4 x 4-tap convolution of the space-to-depth image, halo 2 before and 1
+    after, with kernel index k = 2 t + p - 1 (csrc/conv_enc.hip, TAPS == 16)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 6, 20, 28, generator=g, dtype=torch.float64)
+    w = torch.randn(8, 6, 7, 7, generator=g, dtype=torch.float64)
+    ref = F.conv2d(x, w, stride=2, padding=3)
+    w4 = torch.zeros(8, 24, 4, 4, dtype=torch.float64)
+    for par in range(4):
+        for ty in range(4):
+            for tx in range(4):
+                ky, kx = 2 * ty + (par >> 1) - 1, 2 * tx + (par & 1) - 1
+                if 0 <= ky <= 6 and 0 <= kx <= 6:
+                    w4[:, par * 6:(par + 1) * 6, ty, tx] = w[:, :, ky, kx]
+    got = F.conv2d(F.pad(_s2d(x), (2, 1, 2, 1)), w4)
+    assert got.shape == ref.shape and torch.allclose(got, ref, atol=1e-12)
+
+
+def test_bicubic_x2_align_corners_is_the_kernels_16_tap_formula():
+    """upadd_kernel / upadd_tiled_kernel: F.interpolate(scale_factor=2, mode='bicubic', align_corners=True) (HGFilters.py:116) with ATen's cubic
+    convolution coefficients (A = -0.75) and clamped taps."""
+    def coeffs(t, A=-0.75):
+        x0, x1, x2 = t + 1.0, t, 1.0 - t
+        x3 = x2 + 1.0
+        return [((A * x0 - 5 * A) * x0 + 8 * A) * x0 - 4 * A, ((A + 2) * x1 - (A + 3)) * x1 * x1 + 1, ((A + 2) * x2 - (A + 3)) * x2 * x2 + 1,
+                ((A * x3 - 5 * A) * x3 + 8 * A) * x3 - 4 * A]
+    x = torch.randn(1, 2, 6, 5, generator=torch.Generator().manual_seed(6), dtype=torch.float64)
+    ref = F.interpolate(x, scale_factor=2, mode='bicubic', align_corners=True)
+    Hb, Wb = x.shape[2:]
+    H, W = 2 * Hb, 2 * Wb
+    sy, sx = (Hb - 1) / (H - 1), (Wb - 1) / (W - 1)
+    out = torch.zeros_like(ref)
+    for oy in range(H):
+        ry = sy * oy; iy = int(np.floor(ry)); cy = coeffs(ry - iy)
+        for ox in range(W):
+            rx = sx * ox; ix = int(np.floor(rx)); cx = coeffs(rx - ix)
+            acc = 0
+            for m in range(4):
+                yy = min(max(iy - 1 + m, 0), Hb - 1)
+                acc = acc + cy[m] * sum(cx[k] * x[0, :, yy, min(max(ix - 1 + k, 0), Wb - 1)] for k in range(4))
+            out[0, :, oy, ox] = acc
     assert torch.allclose(out, ref, atol=1e-12)
