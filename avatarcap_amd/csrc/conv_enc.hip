@@ -1304,11 +1304,13 @@ struct Planner {
 template <int CT, int PT, int TAPS, int TWC, bool NORM>
 static int launch_conv_t(const ConvArgs &a, unsigned grid, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[64] = {};                               // per device: the attribute belongs to the function on the current device
+    int dev = 0;
+    AVC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr[dev]) {
         AVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<CT, PT, TAPS, TWC, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     ConvGeo<PT, TAPS, TWC>::L_TOTAL));
-        attr = true;
+        if (dev >= 0 && dev < 64) attr[dev] = true;
     }
     constexpr int lds = ConvGeo<PT, TAPS, TWC>::L_TOTAL;
     hipLaunchKernelGGL((conv_mfma_kernel<CT, PT, TAPS, TWC, NORM>), dim3(grid), dim3(256), lds, s, a);

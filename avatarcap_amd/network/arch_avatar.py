@@ -305,6 +305,8 @@ class NerfRenderer:
         S = int(config.N_samples)
         f = lambda k: batch[k].contiguous().float()                                       # noqa: E731
         ray_d, near, far, depth = f('ray_d'), f('near'), f('far'), f('depth')
+        if smpl_util.cano_smpl_vertices is None:
+            raise ValueError('Canonical smpl vertices are invalid!')                          # utils/smpl_util.py:31
         smpl_v = smpl_util.cano_smpl_vertices.contiguous().float()
         t_vals = torch.linspace(0., 1., steps=S).to(near)                                  # :251, the host's linspace as the reference takes it
         rgb = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
