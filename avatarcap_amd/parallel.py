@@ -6,12 +6,15 @@ grid / SMPL tables replicated.  The only exchange is an all-gather(v) of the fin
 (torch.distributed; backend 'nccl' = RCCL over xGMI on the GPU box, 'gloo' in the CPU tests), exact-size
 and overlapped with the frames that follow (MeshExchange):
   step k = the frames k * world .. k * world + world - 1, one per rank;
-  1. submit(mesh) starts an asynchronous all-gather of the step's (V, F) counts (16 bytes per rank) and returns;
-  2. one step later the counts are on the host: the step's meshes travel as `world` asynchronous broadcasts of EXACTLY
-     6 V + 3 F 32-bit words each ([verts | normals] and the faces in one buffer), issued on the communication stream while
-     the next frame's kernels run -- RCCL moves them over xGMI / SDMA; no padding to the largest rank, and nothing of the
-     exchange sits behind the last frame except that frame's own mesh;
-  3. finish() waits for what is still in flight and returns all meshes in frame order on every rank.
+  1. submit(mesh) packs the frame's mesh into one buffer and starts an asynchronous all-gather of the step's (V, F) counts (16 bytes per
+     rank) from a side stream: pinned host buffers in and out, an event behind the copy -- the compute stream is never drained for it;
+  2. pump() -- called by FramePipeline.avatar_frame right behind the NEXT frame's query launch, while the host has nothing to do -- waits
+     for that event and issues the step's meshes as `world` asynchronous broadcasts of EXACTLY 6 V + 3 F 32-bit words each ([verts |
+     normals] and the faces in one buffer) from the side stream, so RCCL moves step k - 1 over xGMI while frame k computes; no padding to
+     the largest rank.  A caller that never pumps still gets the same collectives in the same order (submit(k) sends step k - 1 first);
+  3. finish() sends what has not travelled -- with pump() in the frame loop: the LAST step only, i.e. each rank's last mesh --, makes the
+     caller's stream wait for everything in flight and returns all meshes in frame order on every rank.
+verify_gathered_meshes() is the exchange's self-check (per-frame integer checksums from the owners against what arrived, slot by slot).
 all_gather_meshes(meshes, n_frames) is the same exchange for meshes that already exist.
 """
 from __future__ import annotations
@@ -62,20 +65,26 @@ def _collective_device(meshes, group, device):
 class MeshExchange:
     """Exact-size, overlapped all-gather(v) of a batch's per-frame meshes (module docstring).  Every rank calls submit() once per step, in step
     order, with its frame of that step ({'v' (V,3) f32, 'vn' (V,3) f32, 'f' (F,3) i32}) or None when it owns none (the last step of a batch whose
-    size is not a multiple of the world size), then finish().  `force` runs the collectives even with one rank (the single-GPU RCCL test)."""
+    size is not a multiple of the world size), then finish().  pump() may be called at any time in between (FramePipeline.avatar_frame calls it right
+    behind the query launch): it issues the payload broadcasts of every step submitted so far, so that step k - 1 travels WHILE frame k computes and
+    only the last step is left for finish().  Whoever calls what when, every rank issues the same collectives in the same order -- AG(0), B(0) x world,
+    AG(1), B(1) x world, ... -- because submit(k) pumps step k - 1 itself before it starts AG(k).
+    `force` runs the collectives even with one rank (the single-GPU RCCL test)."""
 
     def __init__(self, n_frames: int, group=None, device=None, force: bool = False):
         self.n_frames, self.group, self.force = int(n_frames), group, force
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.active = self.world > 1 or force
-        self.device = device
+        self.device = torch.device(device) if device is not None else None
         self.steps = (self.n_frames + self.world - 1) // self.world
         self.out = [None] * self.n_frames
         self._k = 0                    # steps submitted
         self._sent = 0                 # steps whose payload broadcasts have been issued
-        self._counts, self._mine, self._works = [], [], []
+        self._counts, self._mine, self._own, self._works, self._foreign = [], [], [], [], []
+        self._comm = None              # HIP: the side stream the collectives are issued from (they then wait for IT, not for the compute stream)
         self.bytes_received = 0
+        self.pumped_early = 0          # steps whose broadcasts were issued by pump() (inside the next frame), not by submit() / finish()
 
     def _src(self, r):                 # global rank of group rank r (broadcast takes global ranks)
         return dist.get_global_rank(self.group, r) if self.group is not None else r
@@ -87,56 +96,154 @@ class MeshExchange:
         f = k * self.world + self.rank
         if (mesh is None) != (f >= self.n_frames):
             raise ValueError(f'MeshExchange: rank {self.rank} step {k}: frame {f} of {self.n_frames} ' + ('is missing' if mesh is None else 'does not exist'))
-        self._k += 1
         if not self.active:
+            self._k += 1
             self.out[f] = {'v': mesh['v'], 'vn': mesh['vn'], 'f': mesh['f']}
             return
         if self.device is None:
             self.device = _collective_device([mesh] if mesh is not None else [], self.group, None)
         dev = self.device
+        self._pump(early=False)        # step k - 1, unless pump() has sent it already: B(k - 1) precedes AG(k) on every rank
         if mesh is None:
             buf, V, F = torch.empty(0, dtype=torch.int32, device=dev), 0, 0
         else:
             V, F = int(mesh['v'].shape[0]), int(mesh['f'].shape[0])
             vn = torch.cat([mesh['v'].reshape(-1, 3), mesh['vn'].reshape(-1, 3)], 1).to(torch.float32).contiguous()
             buf = torch.cat([vn.reshape(-1).view(torch.int32), mesh['f'].reshape(-1).to(torch.int32)])       # 6 V + 3 F words, exactly
-        counts = torch.tensor([V, F], dtype=torch.int64, device=dev)
-        allc = torch.empty(2 * self.world, dtype=torch.int64, device=dev)
-        w = dist.all_gather_into_tensor(allc, counts, group=self.group, async_op=True)
-        self._counts.append((allc, w))
+        if dev.type == 'cuda':
+            # The counts are host integers (tensor shapes): they go out from a pinned buffer on the side stream and come back into one, with an event
+            # behind the copy.  Nothing of this touches the compute stream: no `.cpu()` that would drain it, and RCCL's stream -- which waits for
+            # the stream a collective is ISSUED from -- waits for the side stream only.
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(dev)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))                      # the packed buffer is complete once the compute stream gets here
+            cin = torch.tensor([V, F], dtype=torch.int64).pin_memory()
+            chost = torch.empty(2 * self.world, dtype=torch.int64).pin_memory()
+            with torch.cuda.stream(self._comm):
+                counts = cin.to(dev, non_blocking=True)
+                allc = torch.empty(2 * self.world, dtype=torch.int64, device=dev)
+                w = dist.all_gather_into_tensor(allc, counts, group=self.group, async_op=True)
+                w.wait()                                                       # the SIDE stream waits for RCCL's; the host does not
+                chost.copy_(allc, non_blocking=True)
+                arrived = torch.cuda.Event()
+                arrived.record(self._comm)
+            self._counts.append({'host': chost, 'arrived': arrived, 'ready': ready, 'keep': (cin, counts, allc)})
+        else:
+            counts = torch.tensor([V, F], dtype=torch.int64, device=dev)
+            allc = torch.empty(2 * self.world, dtype=torch.int64, device=dev)
+            w = dist.all_gather_into_tensor(allc, counts, group=self.group, async_op=True)
+            self._counts.append({'host': allc, 'work': w})
         self._mine.append(buf)
-        if k >= 1:
-            self._send(k - 1)          # its counts were requested a whole frame ago
+        self._own.append((V, F))
+        self._k += 1
+
+    def pump(self):
+        """Issue the payload broadcasts of every submitted step that has not travelled yet (normally: the previous frame's step, called from inside
+        the current frame, behind its query launch).  Waits on the host for that step's counts, i.e. for the slowest rank to have SUBMITTED the
+        step -- never for this rank's own compute stream.  A no-op when there is nothing to send."""
+        if self.active:
+            self._pump(early=True)
+
+    def _pump(self, early):
+        for j in range(self._sent, self._k):
+            self._send(j)
+            self.pumped_early += int(early)
 
     def _send(self, j):
         """Step j's payload: `world` broadcasts of exact size (asynchronous; the receive buffers are the output meshes' storage)."""
-        allc, w = self._counts[j]
-        w.wait()
-        c = allc.cpu().reshape(self.world, 2)
-        for r in range(self.world):
-            f = j * self.world + r
-            if f >= self.n_frames:
-                continue
-            V, F = int(c[r, 0]), int(c[r, 1])
-            buf = self._mine[j] if r == self.rank else torch.empty(6 * V + 3 * F, dtype=torch.int32, device=self.device)
-            if r != self.rank:
-                self.bytes_received += 4 * buf.numel()
-            if buf.numel():
-                self._works.append(dist.broadcast(buf, src=self._src(r), group=self.group, async_op=True))
-            vn = buf[:6 * V].view(torch.float32).reshape(V, 6)
-            self.out[f] = {'v': vn[:, :3], 'vn': vn[:, 3:], 'f': buf[6 * V:].reshape(F, 3)}
+        c = self._counts[j]
+        if 'arrived' in c:
+            c['arrived'].synchronize()                                         # side stream only
+        else:
+            c['work'].wait()
+        cnt = c['host'].reshape(self.world, 2).tolist()
+        if cnt[self.rank] != list(self._own[j]):
+            raise RuntimeError(f'MeshExchange: rank {self.rank} step {j}: the gathered counts hold {cnt[self.rank]} in this rank\'s slot, it sent {list(self._own[j])}')
+        import contextlib
+        on_side = self._comm is not None
+        with (torch.cuda.stream(self._comm) if on_side else contextlib.nullcontext()):
+            if on_side:
+                self._comm.wait_event(c['ready'])                              # this rank's packed buffer of step j
+            for r in range(self.world):
+                f = j * self.world + r
+                if f >= self.n_frames:
+                    continue
+                V, F = int(cnt[r][0]), int(cnt[r][1])
+                if r == self.rank:
+                    buf = self._mine[j]
+                    if buf.numel() != 6 * V + 3 * F:
+                        raise RuntimeError(f'MeshExchange: rank {self.rank} step {j}: own buffer holds {buf.numel()} words, counts say {6 * V + 3 * F}')
+                else:
+                    buf = torch.empty(6 * V + 3 * F, dtype=torch.int32, device=self.device)       # HIP: from the side stream's pool (finish() hands it over)
+                    self.bytes_received += 4 * buf.numel()
+                    self._foreign.append(buf)
+                if buf.numel():
+                    self._works.append(dist.broadcast(buf, src=self._src(r), group=self.group, async_op=True))
+                vn = buf[:6 * V].view(torch.float32).reshape(V, 6)
+                self.out[f] = {'v': vn[:, :3], 'vn': vn[:, 3:], 'f': buf[6 * V:].reshape(F, 3)}
         self._sent = j + 1
 
     def finish(self) -> list:
         if self._k != self.steps:
             raise ValueError(f'MeshExchange.finish: {self._k} of {self.steps} steps were submitted')
         if self.active:
-            for j in range(self._sent, self.steps):
-                self._send(j)
+            self._pump(early=False)
             for w in self._works:
-                w.wait()
+                w.wait()                                                       # HIP: the CURRENT stream waits for RCCL's; the meshes are its to read from here on
             self._works.clear()
+            if self._comm is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_stream(self._comm)
+                for buf in self._foreign:                                      # allocated on the side stream, read (and one day freed) on the caller's
+                    buf.record_stream(cur)
+            self._foreign.clear()
+            self._counts.clear()
         return self.out
+
+
+def mesh_checksum(mesh, device=None) -> torch.Tensor:
+    """(V, F, sum of the 32-bit patterns of [v | vn], sum of the face indices, position-weighted sum of all words) as five int64 -- exact integer
+    arithmetic (wrapping), so two copies of a mesh agree bit for bit or the checksums differ; the weighted sum catches permuted or shifted content."""
+    if mesh is None:
+        return torch.zeros(5, dtype=torch.int64, device=device)
+    v = torch.cat([mesh['v'].reshape(-1, 3), mesh['vn'].reshape(-1, 3)], 1).to(torch.float32).contiguous().reshape(-1).view(torch.int32).to(torch.int64)
+    f = mesh['f'].reshape(-1).to(torch.int64)
+    words = torch.cat([v, f])
+    weighted = (words * (torch.arange(words.numel(), dtype=torch.int64, device=words.device) % 65521 + 1)).sum() if words.numel() else words.sum()
+    return torch.stack([torch.tensor(mesh['v'].shape[0], dtype=torch.int64, device=words.device), torch.tensor(mesh['f'].shape[0], dtype=torch.int64, device=words.device),
+                        v.sum(), f.sum(), weighted])
+
+
+def verify_gathered_meshes(gathered: list, mine: dict, group=None, force: bool = False) -> list[str]:
+    """Self-validation of an exchange (bench.py runs it OUTSIDE the timed region): every owner's checksum of the mesh it PRODUCED (`mine`: frame -> mesh,
+    this rank's frames) is all-gathered, and every rank compares the checksum of every mesh it RECEIVED, slot by slot.  Returns the list of
+    complaints (empty: every mesh is in its frame slot, complete and bit-identical to its owner's)."""
+    n = len(gathered)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = next((m['v'].device for m in gathered if m is not None), torch.device('cpu'))
+    own = torch.zeros((n, 5), dtype=torch.int64, device=dev)
+    for f, m in mine.items():
+        if f % world != rank:
+            return [f'rank {rank} claims frame {f}, which rank {f % world} owns']
+        own[f] = mesh_checksum(m, dev)
+    if (world > 1 or force) and dist.is_initialized():
+        allsum = torch.empty((world, n, 5), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allsum.reshape(-1), own.reshape(-1).contiguous(), group=group)
+    else:
+        allsum = own[None]
+    allsum = allsum.cpu()
+    bad = []
+    for f in range(n):
+        want = allsum[f % world, f]
+        if gathered[f] is None:
+            bad.append(f'frame {f}: nothing received')
+            continue
+        got = mesh_checksum(gathered[f], dev).cpu()
+        if not torch.equal(got, want):
+            bad.append(f'frame {f} (owner rank {f % world}) on rank {rank}: received (V, F, sums) {got.tolist()} != produced {want.tolist()}')
+    return bad
 
 
 def all_gather_meshes(meshes: list[dict], n_frames: int, group=None, force: bool = False, device=None) -> list[dict]:
@@ -268,14 +375,22 @@ def barrier_or_die(what: str, rank: int, timeout_s: float = 120.0, group=None):
         raise SystemExit(f'rank {rank}: barrier "{what}" failed ({type(e).__name__}: {e}) -- a peer rank is gone or stuck')
 
 
-def _fatal(e: BaseException) -> bool:
-    """Errors after which the device or the process is not worth another frame: out of memory, a HIP runtime fault (sticky: every later call fails too)."""
+def device_is_gone(e: BaseException) -> bool:
+    """Errors after which the DEVICE is not worth another call -- neither a frame nor a collective: out of memory, a HIP runtime fault (sticky: every
+    later call fails too)."""
     if isinstance(e, (MemoryError, torch.cuda.OutOfMemoryError)):
         return True
     msg = str(e)
-    if getattr(e, 'status', None) == -5 or '(status -5)' in msg:       # AVC_ERR_RANGE: these WEIGHTS leave the range of the split-fp16 arithmetic -- every frame would
-        return True
-    return 'HIP error' in msg or 'hipError' in msg or 'AVC_ERR_HIP' in msg or '(status -3)' in msg
+    return 'HIP error' in msg or 'hipError' in msg or 'AVC_ERR_HIP' in msg or '(status -3)' in msg or getattr(e, 'status', None) == -3
+
+
+def _range_error(e: BaseException) -> bool:
+    """AVC_ERR_RANGE: these WEIGHTS leave the range of the split-fp16 arithmetic -- every frame would; the device itself is fine."""
+    return getattr(e, 'status', None) == -5 or '(status -5)' in str(e)
+
+
+def _fatal(e: BaseException) -> bool:
+    return device_is_gone(e) or _range_error(e)
 
 
 def run_sharded(frames: list, process, rank: int = 0, world: int = 1, log=print, max_consecutive_failures: int = 3) -> dict:
@@ -283,12 +398,13 @@ def run_sharded(frames: list, process, rank: int = 0, world: int = 1, log=print,
     frame (next_frame: the one this rank runs after it, or None -- FramePipeline's look-ahead).  A frame that raises is logged and SKIPPED: the
     loop carries no state between frames (main.py:348), so one bad frame -- a missing .exr, an empty surface -- does not take the others down.
     What is NOT contained: an out-of-memory or HIP runtime error (the device state is gone: the remaining frames are reported as failed without being
-    tried), and `max_consecutive_failures` failures in a row (something systematic: same treatment).
+    tried), and `max_consecutive_failures` failures in a row OF THE SAME EXCEPTION TYPE (something systematic: same treatment; 0 or None disables
+    the limit -- three missing .exr files in a row are then three skipped frames and nothing more).
     Returns {'done': [frames], 'failed': [(frame, 'Type: message')], 'results': {frame: what process returned}, 'aborted': reason or None}."""
     import traceback
     mine = [frames[i] for i in shard_frames(len(frames), rank, world)]
     done, failed, results = [], [], {}
-    streak, aborted = 0, None
+    streak, streak_type, aborted = 0, None, None
     for k, fr in enumerate(mine):
         if aborted:
             failed.append((fr, f'not attempted: {aborted}'))
@@ -297,17 +413,18 @@ def run_sharded(frames: list, process, rank: int = 0, world: int = 1, log=print,
         try:
             results[fr] = process(k, fr, nxt)
             done.append(fr)
-            streak = 0
+            streak, streak_type = 0, None
         except Exception as e:      # noqa: BLE001 -- per-frame containment is the point
             failed.append((fr, f'{type(e).__name__}: {e}'))
             log(f'# rank {rank}: frame {fr} FAILED and is skipped -- {type(e).__name__}: {e}')
             log(''.join(traceback.format_exception(type(e), e, e.__traceback__)).rstrip())
-            streak += 1
+            streak = streak + 1 if type(e) is streak_type else 1
+            streak_type = type(e)
             if _fatal(e):
                 aborted = (f'frame {fr}: AVC_ERR_RANGE -- the checkpoint drives a feature or activation out of the fp16 range of the fused kernels'
-                           if getattr(e, 'status', None) == -5 or '(status -5)' in str(e) else f'frame {fr} hit a fatal device error ({type(e).__name__})')
-            elif streak >= max_consecutive_failures:
-                aborted = f'{streak} frames in a row failed'
+                           if _range_error(e) else f'frame {fr} hit a fatal device error ({type(e).__name__})')
+            elif max_consecutive_failures and streak >= max_consecutive_failures:
+                aborted = f'{streak} frames in a row failed ({type(e).__name__})'
             if aborted:
                 log(f'# rank {rank}: {aborted} -- the remaining {len(mine) - k - 1} frame(s) of this rank are not attempted')
     return {'done': done, 'failed': failed, 'results': results, 'aborted': aborted}

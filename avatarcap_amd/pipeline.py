@@ -59,6 +59,7 @@ class FramePipeline:
         self.recon_net = recon_net
         self.ds = dataset
         self.vol_res = list(dataset.vol_res)
+        self.exchange = None          # a parallel.MeshExchange while a sharded batch is running: avatar_frame pumps it behind its query launch
         smpl_util.set_smpl_skinning_weights(dataset.body['skin_weights'])
         smpl_util.set_cano_smpl_vertices(dataset.cano_smpl_v)                 # main.py:335
 
@@ -95,6 +96,11 @@ class FramePipeline:
         if next_items is not None:
             with _stage('avc/unet7ds (next frame)'):
                 self._next_map = (next_items['smpl_pos_map'], wf.unet(next_items['smpl_pos_map']).contiguous())
+        if self.exchange is not None:
+            # the query is enqueued and the host is idle until marching cubes' wait: the PREVIOUS frame's mesh goes out now, beside this frame's
+            # kernels (parallel.MeshExchange.pump -- waits for the peers' counts of that step, never for this stream)
+            with _stage('avc/mesh_exchange pump'):
+                self.exchange.pump()
         with _stage('avc/marching_cubes'):
             vol = fill_volume(out['cano_pts_ov'][0, :, 0], self.ds.valid_u8, self.ds.invalid_pts_ov)   # :362-364
             v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds, iso_value=config.iso_value)   # :367

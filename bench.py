@@ -181,15 +181,29 @@ def dry_run(args, world, rank):
                       'f': torch.full((2 * sizes[f], 3), f, dtype=torch.int32)}
     t0 = time.perf_counter()
     with _stdout_to_stderr():
-        got = all_gather_meshes([mesh(f) for f in shard_frames(n_frames, rank, world)], n_frames)
+        from avatarcap_amd.parallel import MeshExchange, verify_gathered_meshes
+        ex = MeshExchange(n_frames)                      # driven as the timed loop drives it: pump() inside "the next frame", submit() behind it
+        for k in range(ex.steps):
+            ex.pump()
+            ex.submit(mesh(k * world + rank))
+        got = ex.finish()
     dt = time.perf_counter() - t0
-    ok = len(got) == n_frames and all(got[f]['v'].shape[0] == sizes[f] and float(got[f]['v'][0, 0]) == float(f) and int(got[f]['f'][0, 0]) == f
-                                      for f in range(n_frames))
+    with _stdout_to_stderr():
+        complaints = verify_gathered_meshes(got, {f: mesh(f) for f in shard_frames(n_frames, rank, world)})
+    for c in complaints:
+        print('# bench.py --dry-run: ' + c, file=sys.stderr, flush=True)
+    ok = not complaints and len(got) == n_frames and all(got[f]['v'].shape[0] == sizes[f] and float(got[f]['v'][0, 0]) == float(f) and int(got[f]['f'][0, 0]) == f
+                                                        for f in range(n_frames))
+    if world > 1:
+        flag = torch.tensor([0 if ok else 1])
+        with _stdout_to_stderr():
+            dist.all_reduce(flag)
+        ok = int(flag) == 0
     ranks = dist.get_world_size() if dist.is_initialized() else 1
     if rank == 0:
         print(json.dumps({'metric': 'dry run (no GPU): launcher + gloo all-gather of stand-in meshes', 'value': n_frames / max(dt, 1e-9),
                           'unit': 'frames/s', 'n_gpus': ranks, 'rccl_ranks': 0, 'gloo_ranks': ranks, 'steps': K, 'warmup': 0,
-                          'frames': n_frames, 'all_gather_ok': bool(ok), 'data': 'synthetic'}), flush=True)
+                          'frames': n_frames, 'all_gather_ok': bool(ok), 'meshes_verified': bool(ok), 'data': 'synthetic'}), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
     return 0 if ok else 1
@@ -271,29 +285,52 @@ def main():
     # the batch's meshes are exchanged step by step WHILE the following frames compute (parallel.MeshExchange: exact sizes, asynchronous
     # broadcasts on RCCL's stream); what is left behind the last frame is that frame's own mesh
     ex = MeshExchange(world * K, force=force_dist) if (world > 1 or force_dist) else None
+    pipe.exchange = ex                              # avatar_frame pumps it behind its query launch: step s - 1 travels while frame s computes
     for s in range(W, W + K):
         out = pipe.avatar_frame(my[s], next_items=my[s + 1] if s + 1 < W + K else None)
         if ex is not None:
             ex.submit({'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']})
+    pipe.exchange = None
     torch.cuda.synchronize()
     t_frames = time.perf_counter() - t0            # this rank's K frames (the exchange of the earlier steps ran beside them)
-    t_gather, rx_bytes = 0.0, 0
+    t_gather, rx_bytes, gathered = 0.0, 0, None
     if ex is not None:
         tg = time.perf_counter()
         gathered = ex.finish()
         torch.cuda.synchronize()
-        t_gather = time.perf_counter() - tg        # what of the exchange was still outstanding, incl. waiting for the slowest rank's last frame
+        t_gather = time.perf_counter() - tg        # the exchange's tail: the LAST step's meshes (+ waiting for the slowest rank's last frame)
         rx_bytes = ex.bytes_received
-        assert len(gathered) == world * K and all(m is not None for m in gathered)
     barrier('end of the timed region')
     dt = time.perf_counter() - t0
     _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
-    per_rank = [[dt, t_frames, t_gather, float(rx_bytes)]]
+    # ---- outside the timed region: the exchange validates itself.  Every owner's integer checksums (V, F, sum of the bit patterns of [v | vn], sum of the
+    # face indices, position-weighted sum) of the meshes it produced are all-gathered and compared, on every rank, with what arrived in each frame
+    # slot (parallel.verify_gathered_meshes); the owner's last produced mesh is compared tensor for tensor with its slot (the packing).
+    meshes_verified, complaints = None, []
+    if ex is not None:
+        from avatarcap_amd.parallel import verify_gathered_meshes
+        with _stdout_to_stderr():
+            if len(gathered) != world * K:
+                complaints.append(f'rank {rank}: {len(gathered)} meshes gathered, {world * K} expected')
+            else:
+                complaints += verify_gathered_meshes(gathered, {s_ * world + rank: gathered[s_ * world + rank] for s_ in range(K)}, force=force_dist)
+                last = gathered[(K - 1) * world + rank]
+                if not (torch.equal(last['v'], out['live_v']) and torch.equal(last['vn'], out['live_vn']) and torch.equal(last['f'], out['f'])):
+                    complaints.append(f'rank {rank}: the slot of its last frame does not hold the mesh it produced')
+            bad = torch.tensor([len(complaints)], dtype=torch.int64, device=device)
+            if world > 1:
+                dist.all_reduce(bad)
+        meshes_verified = int(bad.item()) == 0
+        for c in complaints:
+            print('# bench.py: MESH EXCHANGE CHECK FAILED -- ' + c, file=sys.stderr, flush=True)
+    pumped = ex.pumped_early if ex is not None else 0
+    del gathered, ex
+    per_rank = [[dt, t_frames, t_gather, float(rx_bytes), float(pumped)]]
     if world > 1:
-        mine_t = torch.tensor([dt, t_frames, t_gather, float(rx_bytes)], dtype=torch.float64, device=device)
-        all_t = torch.empty(world * 4, dtype=torch.float64, device=device)
+        mine_t = torch.tensor(per_rank[0], dtype=torch.float64, device=device)
+        all_t = torch.empty(world * 5, dtype=torch.float64, device=device)
         dist.all_gather_into_tensor(all_t, mine_t)
-        per_rank = all_t.reshape(world, 4).cpu().tolist()
+        per_rank = all_t.reshape(world, 5).cpu().tolist()
         dt = max(r[0] for r in per_rank)           # MAX over ranks
 
     import ctypes as C
@@ -308,8 +345,9 @@ def main():
             'metric': 'reconstructed-mesh frames/sec at 256^3 grid (avatar occupancy-only, dense query + marching cubes + LBS)',
             'value': world * K / dt, 'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': K, 'warmup': W,
             'ms_per_step': dt / K * 1e3,
-            'ms_per_step_per_rank': [r[1] / K * 1e3 for r in per_rank], 'all_gather_ms_per_rank': [r[2] * 1e3 for r in per_rank],
-            'all_gather_rx_mb_per_rank': [r[3] / 1e6 for r in per_rank],
+            'ms_per_step_per_rank': [r[1] / K * 1e3 for r in per_rank], 'exchange_tail_ms_per_rank': [r[2] * 1e3 for r in per_rank],
+            'exchange_tail_ms': max(r[2] for r in per_rank) * 1e3, 'all_gather_rx_mb_per_rank': [r[3] / 1e6 for r in per_rank],
+            'exchange_steps_sent_inside_the_next_frame_per_rank': [int(r[4]) for r in per_rank], 'meshes_verified': meshes_verified,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (products as 3 split-fp16 MFMA passes, fp32 accumulate)', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[1]: AvatarNet occupancy-only, {res}^3 grid dense ({N} points/frame), random SMPL pose, '
@@ -317,7 +355,9 @@ def main():
                        'grid': [res] * 3, 'points_per_frame': N, 'vertices_last_frame': int(out['cano_v'].shape[0]),
                        'faces_last_frame': int(out['f'].shape[0]), 'parallelism': f'frame-sharded x{world}',
                        'frames_in_batch': world * K, 'meshes_all_gathered': bool(world > 1 or force_dist),
-                       'mesh_exchange': 'exact-size broadcasts per step, overlapped with the following frames (parallel.MeshExchange)',
+                       'mesh_exchange': 'exact-size broadcasts per step, issued from a side stream behind the NEXT frame\'s query launch (parallel.MeshExchange.pump): '
+                                        'K - 1 of a rank\'s K steps travel beside compute, the last one is `exchange_tail_ms`; `meshes_verified`: per-frame integer checksums '
+                                        'of every received mesh against its owner\'s, checked on every rank outside the timed region',
                        'semantics': '`value` is the DENSE stress variant BASELINE configs[1] names (every one of the 256^3 grid points evaluated); the reference itself '
                                     'evaluates only the valid band around the canonical SMPL and fills the rest (main.py:362-363): that is `masked` and the '
                                     '`configs` legs below',
@@ -386,6 +426,8 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if meshes_verified is False:
+        raise SystemExit('bench.py: the gathered meshes do not match what their owners produced (see stderr): the line above is not a valid measurement')
 
 
 def other_configs(device, frames=3):

@@ -49,9 +49,12 @@ class _StandInPipeline:
 
     def __init__(self, fail=()):
         self.fail = set(fail)
+        self.exchange = None
 
     def avatar_frame(self, items, next_items=None):
         f = int(items['data_idx'])
+        if self.exchange is not None:            # where FramePipeline.avatar_frame pumps: behind the query launch
+            self.exchange.pump()
         if f in self.fail:
             raise RuntimeError(f'stand-in failure of frame {f}')
         nv = 5 + f % 7
@@ -62,7 +65,7 @@ class _StandInPipeline:
 
 def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w_nerf=False, frame_idx=None, view_idx=0, interval=1,
                   synthetic=False, n_frames=2, valid='band', integrate_manner='merge', rank=0, world=1, gather_meshes=False, gather_batch=8,
-                  dry_run=False, dry_fail=()):
+                  dry_run=False, dry_fail=(), max_failure_streak=3):
     from avatarcap_amd import config, parallel
     cfg = config.cfg
     out_dir = cfg['testing']['output_dir']
@@ -132,11 +135,13 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
     # and activation stays below 65504 (include/avcap.h, "numeric range"), and an overflow is SILENT (a ReLU swallows the NaN).  The first frame
     # of every rank therefore runs with the range check on (avc_set_range_check: the checked flavour of the kernels, one synchronisation per
     # query); a trip is fatal for the whole run (parallel.run_sharded: AVC_ERR_RANGE).  Synthetic weights are generated inside the range.
-    check_first = not (synthetic or dry_run)
+    # The user's own setting (config.check_range) is kept; the forced check stays on until one frame has COMPLETED under it (a first frame that fails
+    # on a missing file has not checked anything).
+    check = {'user': bool(getattr(config, 'check_range', False)), 'pending': not (synthetic or dry_run)}
 
     def process(k, i, nxt_i):
-        if check_first:
-            config.check_range = (k == 0)
+        checking = check['user'] or check['pending']
+        config.check_range = checking
         items = items_of(i)
         nxt = None
         if nxt_i is not None:
@@ -183,6 +188,8 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
                  **{k_: v.cpu().numpy() for k_, v in save.items() if v is not None})
         log('# %sframe %d (data idx %d): avatar %d verts / %d faces%s' % ('rank %d: ' % rank if world > 1 else '', i, data_idx, a['cano_v'].shape[0],
             a['f'].shape[0], (', recon %d verts' % save['recon_cano_v'].shape[0]) if w_recon else ''))
+        if checking:
+            check['pending'] = False              # this frame went through every kernel with the range check on
         if gather_meshes and a.get('live_v') is not None:
             return {'v': a['live_v'], 'vn': a['live_vn'], 'f': a['f']}
         return None
@@ -205,30 +212,45 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
         if gather['ex'] is None:
             lo, hi = b0 * world, min(len(frames), (b0 + gather_batch) * world)
             gather['ex'] = (parallel.MeshExchange(hi - lo, device=dev), lo, hi)
+            pipe.exchange = gather['ex'][0]                   # avatar_frame pumps it: step k - 1 travels while frame k computes
         ex, lo, hi = gather['ex']
         has_frame = k * world + rank < len(frames)
         ex.submit((mesh or empty_mesh()) if has_frame else None)
         gather['step'] = k + 1
         if k + 1 == min(steps, b0 + gather_batch):            # the batch is complete: collect it, keep nothing on the device
+            pipe.exchange = None
             for fr, m in zip(frames[lo:hi], ex.finish()):
                 if rank == 0:
                     gathered[fr] = {key: m[key].cpu().numpy() for key in ('v', 'vn', 'f')}
-            gather['ex'] = None
+            gather['ex'] = None                               # drops the exchange and with it every device copy of the batch (own and received)
 
     def process_and_submit(k, fr, nxt):
-        mesh = None
         try:
             mesh = process(k, fr, nxt)
-            return mesh
-        finally:
-            if gather_meshes:
-                submit_step(mesh)
+        except BaseException as e:
+            if parallel.device_is_gone(e):
+                # a sticky HIP fault or an out-of-memory error: no collective can be issued on this device any more.  The rank ends the JOB (below) --
+                # under torch.distributed.run the launcher then stops its peers -- instead of leaving them in a collective until the watchdog's timeout.
+                gather['dead'] = f'{type(e).__name__}: {e}'
+            elif gather_meshes:
+                submit_step(None)                             # the failed frame travels as an empty mesh: the ranks' steps stay aligned
+            raise
+        if gather_meshes:
+            submit_step(mesh)
+            # what stays in run_sharded's `results` is host data: the device tensors belong to the exchange and go with its batch
+            return None if mesh is None else (int(mesh['v'].shape[0]), int(mesh['f'].shape[0]))
+        return mesh
 
-    summary = parallel.run_sharded(frames, process_and_submit, rank, world, log)
-    if gather_meshes:
+    summary = parallel.run_sharded(frames, process_and_submit, rank, world, log, max_consecutive_failures=max_failure_streak)
+    if gather.get('dead') and world > 1:
+        log('# rank %d: device lost (%s) -- leaving the job without touching the process group; the launcher stops the other ranks' % (rank, gather['dead']))
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(3)
+    if gather_meshes and not gather.get('dead'):
         while gather['step'] < steps:                          # frames this rank never attempted (abort) or does not own (last, partial step)
             submit_step(None)
-    summary['results'] = {}                                    # the meshes have been handed over: nothing of the batch stays on the device
+    pipe.exchange = None
+    summary['results'] = {}
     everyone = parallel.gather_summaries(summary)
     n_failed = sum(len(s_['failed']) for s_ in everyone)
     if gather_meshes and rank == 0:
@@ -257,6 +279,9 @@ def main(argv=None):
     arg_parser.add_argument('--gpus', type=int, default=0, help='shard the frames over this many GPUs of the node (one process each); 0: whatever launched us')
     arg_parser.add_argument('--gather-meshes', action='store_true', help='all-gather the live avatar meshes of the batch (RCCL) and write them on rank 0')
     arg_parser.add_argument('--gather-batch', type=int, default=8, help='--gather-meshes: steps (frames per rank) exchanged and moved to the host at a time')
+    arg_parser.add_argument('--max-failure-streak', type=int, default=3,
+                            help='give up on a rank\'s remaining frames after this many consecutive failures OF THE SAME KIND (0: never)')
+    arg_parser.add_argument('--check-range', action='store_true', help='run EVERY frame with the fp16 range check of the fused kernels (default: until one frame has passed it)')
     arg_parser.add_argument('--dist-timeout', type=float, default=180.0, help='seconds a rank may take to show up at the rendezvous')
     arg_parser.add_argument('--collective-timeout', type=float, default=None,
                             help='seconds a collective may wait for the slowest rank AFTER the rendezvous (default: 10 x --dist-timeout, at least 1800)')
@@ -276,6 +301,8 @@ def main(argv=None):
     config.cfg = config.load_config(args.config_path) if args.config_path else config.default_cfg()
     if args.output_dir:
         config.cfg['testing']['output_dir'] = args.output_dir
+    if args.check_range:
+        config.check_range = True
     if args.dry_run:
         config.device = torch.device('cpu')
     else:
@@ -292,7 +319,7 @@ def main(argv=None):
         n_failed = run_avatarcap(w_recon=True, save_avatar_mesh=args.save_ply, save_final_mesh=args.save_ply, w_nerf=args.nerf,
                                  synthetic=args.synthetic, n_frames=args.frames, valid=args.valid, integrate_manner=args.integrate,
                                  rank=rank, world=world, gather_meshes=args.gather_meshes, gather_batch=max(1, args.gather_batch), dry_run=args.dry_run,
-                                 dry_fail=args.dry_fail)
+                                 dry_fail=args.dry_fail, max_failure_streak=args.max_failure_streak)
     finally:
         if world > 1:
             import torch.distributed as dist

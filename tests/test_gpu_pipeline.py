@@ -418,3 +418,43 @@ def test_bench_single_rank_through_rccl():
     line = json.loads(lines[0])
     assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1 and line['config']['meshes_all_gathered'] is True
     assert line['steps'] == 2 and line['value'] > 0 and line['config']['vertices_last_frame'] > 0
+    # round 5: the exchange validates itself (checksums of every gathered mesh against its owner's, outside the timed region), step 0 went out from inside
+    # frame 1 (FramePipeline.avatar_frame -> MeshExchange.pump) and only the last step is the tail
+    assert line['meshes_verified'] is True and line['exchange_steps_sent_inside_the_next_frame_per_rank'] == [1]
+    assert 0 <= line['exchange_tail_ms'] < 1000 and len(line['exchange_tail_ms_per_rank']) == 1
+
+
+@pytest.mark.gpu
+def test_mesh_exchange_on_rccl_side_stream_single_rank():
+    """parallel.MeshExchange on the HIP device through RCCL (one rank, `force`): counts through pinned buffers on the side stream, payload broadcasts
+    issued from it by pump() while the compute stream is BUSY (a long matmul chain stands in for the query), meshes bit-identical afterwards and the
+    checksums agree; a damaged slot is reported."""
+    import os
+    import torch.distributed as dist
+    from avatarcap_amd import parallel
+    dev = torch.device('cuda', 0)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ['MASTER_PORT'] = str(parallel.free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        g = torch.Generator().manual_seed(5)
+        meshes = [{'v': torch.randn(1000 + 37 * k, 3, generator=g).to(dev), 'vn': torch.randn(1000 + 37 * k, 3, generator=g).to(dev),
+                   'f': torch.randint(0, 1000, (1500 + k, 3), generator=g, dtype=torch.int32).to(dev)} for k in range(4)]
+        a = torch.randn(2048, 2048, device=dev)
+        ex = parallel.MeshExchange(4, force=True)
+        for k in range(4):
+            for _ in range(20):
+                a = torch.tanh(a @ a * 1e-3)                           # "frame k" on the compute stream
+            ex.pump()                                                  # must not wait for it
+            ex.submit(meshes[k])
+        assert ex.pumped_early == 3
+        out = ex.finish()
+        torch.cuda.synchronize()
+        for k in range(4):
+            assert all(torch.equal(out[k][key], meshes[k][key]) for key in ('v', 'vn', 'f'))
+        assert parallel.verify_gathered_meshes(out, dict(enumerate(meshes)), force=True) == []
+        out[2]['f'][5, 1] += 1
+        bad = parallel.verify_gathered_meshes(out, dict(enumerate(meshes)), force=True)
+        assert len(bad) == 1 and bad[0].startswith('frame 2')
+    finally:
+        dist.destroy_process_group()
