@@ -78,6 +78,7 @@ struct avc_ctx {
     // staged host-side effective weights until both halves of the avatar net have arrived
     struct Staged { std::vector<std::vector<double>> W; std::vector<std::vector<double>> b; std::vector<int> cout, cin; };
     Staged warp_st, tmpl_st;
+    int warp_pe = 0, tmpl_pe = 10;       // model.warping_field.pos_encoding / model.cano_template.pos_encoding of the packed weights (0 .. 10 each)
     float *pose_feat_hwc = nullptr; int pose_C = 0, pose_H = 0, pose_W = 0;
     float *img_feat_hwc = nullptr;  int img_C = 0, img_H = 0, img_W = 0;
     // scratch for meshing
@@ -97,6 +98,7 @@ struct avc_ctx {
     void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
     void *col_scratch = nullptr; size_t col_scratch_bytes = 0;     // per-column terms of a column-folded dense query (512 floats per column)
     void *rcol_scratch = nullptr; size_t rcol_scratch_bytes = 0;   // ... of a column-folded recon query (896 floats per column)
+    void *band_scratch = nullptr; size_t band_scratch_bytes = 0;   // subset launches of the recon query: [left-over tile count | column flags | tile flags | tile list]
     avc::Timing timing;
     avc::Options opt;
     int check_range = 0;                 // avc_set_range_check

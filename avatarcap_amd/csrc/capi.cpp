@@ -58,6 +58,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->render_scratch) hipFree(ctx->render_scratch);
     if (ctx->col_scratch) hipFree(ctx->col_scratch);
     if (ctx->rcol_scratch) hipFree(ctx->rcol_scratch);
+    if (ctx->band_scratch) hipFree(ctx->band_scratch);
     if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
     for (void *p : ctx->retired_scratch) hipFree(p);
     enc::release_encoder(ctx);
@@ -81,12 +82,14 @@ static int check_shape(const avc_dense &d, int cout, int cin, const char *what, 
 int avc_pack_warp_weights(avc_ctx *ctx, const avc_dense conv[7], const avc_bn bn[7], const avc_dense *out_affine, int pos_encoding)
 {
     AVC_REQUIRE(ctx && conv && bn && out_affine, AVC_ERR_ARG, "avc_pack_warp_weights: NULL argument");
-    AVC_REQUIRE(pos_encoding == 0, AVC_ERR_ARG, "avc_pack_warp_weights: only model.warping_field.pos_encoding == 0 is supported (got %d)", pos_encoding);
+    AVC_REQUIRE(pos_encoding >= 0 && pos_encoding <= 10, AVC_ERR_ARG, "avc_pack_warp_weights: model.warping_field.pos_encoding must be 0 .. 10 (the kernels "
+                "evaluate ten octaves; got %d)", pos_encoding);
     AVC_HIP(hipSetDevice(ctx->device));
     auto &st = ctx->warp_st;
     st.W.assign(8, {}); st.b.assign(8, {});
     for (int i = 0; i < 7; ++i) {
-        const int cin = i == 0 ? 67 : (i == 4 ? 323 : 256);
+        const int D = 3 + 6 * pos_encoding + 64;                 // [posenc(xyz) | pose_feat(64)] (arch_avatar.py:97-100,136)
+        const int cin = i == 0 ? D : (i == 4 ? D + 256 : 256);
         int rc = check_shape(conv[i], 256, cin, "warp conv", i + 1);
         if (rc) return rc;
         AVC_REQUIRE(bn[i].gamma && bn[i].beta && bn[i].mean && bn[i].var, AVC_ERR_ARG, "warp bn%d: NULL pointer", i + 1);
@@ -98,19 +101,22 @@ int avc_pack_warp_weights(avc_ctx *ctx, const avc_dense conv[7], const avc_bn bn
     rc = effective(*out_affine, nullptr, st.W[7], st.b[7]);
     if (rc) return rc;
     ctx->warp_set = true;
+    ctx->warp_pe = pos_encoding;
     return pack_avatar(ctx);
 }
 
 int avc_pack_template_weights(avc_ctx *ctx, const avc_dense shared[7], const avc_dense geo[2], const avc_dense *clr, int pos_encoding)
 {
     AVC_REQUIRE(ctx && shared && geo, AVC_ERR_ARG, "avc_pack_template_weights: NULL argument");
-    AVC_REQUIRE(pos_encoding == 10, AVC_ERR_ARG, "avc_pack_template_weights: only model.cano_template.pos_encoding == 10 is supported (got %d)", pos_encoding);
+    AVC_REQUIRE(pos_encoding >= 0 && pos_encoding <= 10, AVC_ERR_ARG, "avc_pack_template_weights: model.cano_template.pos_encoding must be 0 .. 10 (the kernels "
+                "evaluate ten octaves; got %d)", pos_encoding);
     AVC_HIP(hipSetDevice(ctx->device));
     auto &st = ctx->tmpl_st;
     const int n = clr ? 12 : 9;
     st.W.assign(n, {}); st.b.assign(n, {});
     for (int i = 0; i < 7; ++i) {
-        const int cin = i == 0 ? 63 : (i == 4 ? 319 : 256);
+        const int P = 3 + 6 * pos_encoding;                      // get_embedder(L): [x | sin, cos of 2^0 .. 2^(L-1) x] (net_util.py:40-55)
+        const int cin = i == 0 ? P : (i == 4 ? 256 + P : 256);
         int rc = check_shape(shared[i], 256, cin, "shared_mlp", i);
         if (rc) return rc;
         rc = effective(shared[i], nullptr, st.W[i], st.b[i]);
@@ -131,6 +137,7 @@ int avc_pack_template_weights(avc_ctx *ctx, const avc_dense shared[7], const avc
             if (rc) return rc;
         }
     ctx->tmpl_set = true;
+    ctx->tmpl_pe = pos_encoding;
     return pack_avatar(ctx);
 }
 

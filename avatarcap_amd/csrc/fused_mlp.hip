@@ -116,8 +116,22 @@ struct QueryParams {
     unsigned *range_flag;    // AVC_CHECK_RANGE builds: set to 1 when a value left the fp16 range
     const float *colterms;   // column-folded dense launches: per (x, y) column 512 floats [conv1 | conv5] (column_terms_kernel), else null
     long long *clk;          // timed launches (avc_timing_enable): workgroup 0 stores its s_memtime at entry and exit here, else null
+    // subset launches of the reconstruction query (band_prepass_kernel): the folded kernel leaves the tiles flagged in tile_skip (a wavefront with more than
+    // two runs of columns) to the point-by-point kernel, which then runs on tile_list[0 .. *tile_count)
+    const int32_t *tile_skip;
+    const int32_t *tile_list, *tile_count;
 };
 
+// flat grid index of query point pidx (grid modes): the point's own number, or -- a SUBSET launch -- one load from the index list
+__device__ __forceinline__ unsigned load_index(const QueryParams &p, int64_t pidx) { return p.gidx ? (unsigned)p.gidx[pidx] : (unsigned)pidx; }
+// the point of flat grid index i from the three axis tables; returns its (x, y) column
+__device__ __forceinline__ unsigned point_of_index(const QueryParams &p, unsigned i, float pt[3])
+{
+    const unsigned yz = p.gry * p.grz;
+    const unsigned ix = i / yz, r = i - ix * yz, iy = r / p.grz, iz = r - iy * p.grz;
+    pt[0] = p.gx[ix]; pt[1] = p.gy[iy]; pt[2] = p.gz[iz];
+    return ix * p.gry + iy;
+}
 __device__ __forceinline__ unsigned load_point(const QueryParams &p, int64_t pidx, float pt[3])
 {
     // returns the point's (x, y) column of the grid (grid modes), 0 otherwise
@@ -125,11 +139,37 @@ __device__ __forceinline__ unsigned load_point(const QueryParams &p, int64_t pid
         pt[0] = p.pts[pidx * 3 + 0]; pt[1] = p.pts[pidx * 3 + 1]; pt[2] = p.pts[pidx * 3 + 2];
         return 0u;
     }
-    const unsigned i = p.gidx ? (unsigned)p.gidx[pidx] : (unsigned)pidx, yz = p.gry * p.grz;
-    const unsigned ix = i / yz, r = i - ix * yz, iy = r / p.grz, iz = r - iy * p.grz;
-    pt[0] = p.gx[ix]; pt[1] = p.gy[iy]; pt[2] = p.gz[iz];
-    return ix * p.gry + iy;
+    return point_of_index(p, load_index(p, pidx), pt);
 }
+// A subset launch reads its points through TWO dependent loads (index list -> axis tables).  Fetched one tile ahead in one go, the second waits for the first
+// at the top of every tile -- a full memory latency with nothing else to issue (round 4: the band launches ran 8 % (avatar) and 15 % (recon) more cycles per
+// tile than the dense ones).  PointAhead keeps the chain two tiles deep: the INDEX of the tile after next is requested while the point of the next tile is
+// built from the index requested a tile ago.
+struct PointAhead {
+    unsigned idx_next;           // flat grid index of this lane's point in the tile after next
+    __device__ __forceinline__ int64_t lane_point(const QueryParams &p, int64_t tile, int wave, int j) const
+    {
+        const int64_t i = tile * TILE_PTS + wave * 32 + j;
+        return i < p.n ? i : p.n - 1;
+    }
+    // before the loop: -> point of the first tile, index of the second requested
+    __device__ __forceinline__ unsigned start(const QueryParams &p, int64_t tile0, int64_t stride, int wave, int j, float pt_next[3])
+    {
+        const unsigned i0 = load_index(p, lane_point(p, tile0, wave, j));
+        const int64_t t1 = tile0 + stride < p.ntiles ? tile0 + stride : tile0;
+        idx_next = load_index(p, lane_point(p, t1, wave, j));
+        return point_of_index(p, i0, pt_next);
+    }
+    // top of tile `tile`: -> point of tile + stride (its index arrived during the previous tile), index of tile + 2 stride requested
+    __device__ __forceinline__ unsigned advance(const QueryParams &p, int64_t tile, int64_t stride, int wave, int j, float pt_next[3])
+    {
+        const unsigned col = point_of_index(p, idx_next, pt_next);
+        const int64_t t1 = tile + stride < p.ntiles ? tile + stride : tile;
+        const int64_t t2 = t1 + stride < p.ntiles ? t1 + stride : t1;
+        idx_next = load_index(p, lane_point(p, t2, wave, j));
+        return col;
+    }
+};
 
 // running max of the magnitudes that go through an fp16 split (AVC_CHECK_RANGE builds only)
 struct RangeTrack {
@@ -184,6 +224,22 @@ struct ParkIn {
             return r;
         } else {
             return *extra;
+        }
+    }
+};
+struct ParkPeIn {                    // a warping field with a positional encoding in front (pos_encoding > 0): 4 parked feature k-steps + 4 k-steps of posenc(xyz) in registers
+    unsigned base;
+    const Frag *pe;
+    template <int K> __device__ __forceinline__ Frag get() const
+    {
+        extern __shared__ __attribute__((aligned(16))) char smem[];
+        if constexpr (K < 4) {
+            Frag r;
+            r.hi = *reinterpret_cast<const u32x4 *>(smem + base + K * layout::UNIT_BYTES);
+            r.lo = *reinterpret_cast<const u32x4 *>(smem + base + K * layout::UNIT_BYTES + 1024);
+            return r;
+        } else {
+            return pe[K - 4];
         }
     }
 };
@@ -835,9 +891,8 @@ __device__ __forceinline__ void sincos_pow2(float q, float S, float &sn, float &
 // NeRF positional encoding of q (3 floats) into the 4 k-steps of the PE layout (mlp_layout.h):
 // lane-half h evaluates arguments 15h .. 15h+14: coordinate i%3, frequency 2^(5h + i/3) -- exact
 // power-of-two scaling like the reference's x * freq (net_util.py:27-33).
-__device__ __forceinline__ void posenc(const float q[3], int h, unsigned park, RangeTrack &range)
+__device__ __forceinline__ void posenc_values(const float q[3], int h, float v[32])
 {
-    float v[32];
     const float hs = h ? 32.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < 15; ++i) {
@@ -852,12 +907,25 @@ __device__ __forceinline__ void posenc(const float q[3], int h, unsigned park, R
     }
     v[30] = h ? q[2] : q[0];
     v[31] = h ? 0.0f : q[1];
+}
+__device__ __forceinline__ void posenc(const float q[3], int h, unsigned park, RangeTrack &range)
+{
+    float v[32];
+    posenc_values(q, h, v);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         Frag f;
         split8(v + 8 * k, f.hi, f.lo, range);
         park_store(park, k, f);
     }
+}
+// the same four k-steps into registers (the warping field's own positional encoding: its park area holds the sampled features)
+__device__ __forceinline__ void posenc_frags(const float q[3], int h, Frag out[4], RangeTrack &range)
+{
+    float v[32];
+    posenc_values(q, h, v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) split8(v + 8 * k, out[k].hi, out[k].lo, range);
 }
 
 __device__ __forceinline__ Stream stream_init(const QueryParams &p, int wave, int lane, int first_bytes)
@@ -889,6 +957,7 @@ constexpr int B_PE = chunk_bytes(layout::PE_KS, 2);
 constexpr int B_HEAD16 = chunk_bytes(16, 1), B_HEAD8 = chunk_bytes(8, 1);
 constexpr int B_XYZ8 = chunk_bytes(1, 8);        // column-folded launches: conv1 is the xyz k-step alone, all eight tiles in one chunk (wide8)
 constexpr int B_PE8 = chunk_bytes(layout::PE_KS, 8);     // shared.0: four k-steps, all eight tiles in one chunk
+constexpr int B_INPE = chunk_bytes(layout::INPE_KS, 2), B_CONV5PE = first_chunk_bytes(16, layout::INPE_KS);       // warping field with pos_encoding > 0
 constexpr int B_CONV5 = first_chunk_bytes(16, layout::IN67_KS), B_CONV5F = first_chunk_bytes(16, 1), B_SHARED4 = first_chunk_bytes(16, layout::PE_KS);
 
 // ---- column folding of a DENSE launch -----------------------------------------------------------------------------------------------
@@ -972,6 +1041,7 @@ __device__ __forceinline__ ColSegs col_segments(unsigned col, int j, int h)
 // what pass `pass` needs: the B-side ones of this lane (dword d of the fragment: 0x3C003C00 where the lane's run owns pair d of its half) and, per
 // dword, the byte offset of the owning run's column in the table (512 floats per column; runs beyond the last: run 0's column, with no ones)
 struct SegPass { u32x4 ones; unsigned colbyte[4]; };
+template <unsigned COLBYTES = 2048u>          // bytes of one column in the table (avatar: 512 floats, recon: RCOL floats)
 __device__ __forceinline__ SegPass seg_pass(const ColSegs &c, unsigned pass, int h)
 {
     unsigned long long rest = c.first;
@@ -990,7 +1060,7 @@ __device__ __forceinline__ SegPass seg_pass(const ColSegs &c, unsigned pass, int
     for (int d = 0; d < 4; ++d) {
         const unsigned pair = h ? (unsigned)(d + 2) : (d >= 2 ? (unsigned)(d - 2) : 99u);
         sp.ones[d] = (mine == pair) ? 0x3C003C00u : 0u;
-        sp.colbyte[d] = (h ? colr[d + 2] : colr[d >= 2 ? d - 2 : 0]) * 2048u;
+        sp.colbyte[d] = (h ? colr[d + 2] : colr[d >= 2 ? d - 2 : 0]) * COLBYTES;
     }
     return sp;
 }
@@ -1048,14 +1118,17 @@ struct BiasSegs {
 
 // FOLD: 0 = point by point; 1 = column-folded dense grid (every tile in one column: wave-uniform column blocks as accumulator init); 2 = column-folded
 // SUBSET of the grid (p.gidx, the valid band: the 32 points of a wave lie in whatever columns they lie; accumulator init by runs of columns, ColSegs)
-template <bool WARP, bool COLOUR, int FOLD = 0>
+// WPE: model.warping_field.pos_encoding > 0 -- the field's input is [posenc(xyz) | feat] (arch_avatar.py:122,136): eight k-steps, the encoding of the raw point
+// evaluated in front of conv1 and again in front of conv5 (32 registers that are not kept alive across conv2 .. conv4); point-by-point launches only.
+template <bool WARP, bool COLOUR, int FOLD = 0, bool WPE = false>
 __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
 {
     static_assert(!FOLD || (WARP && !COLOUR), "column folding: the geometry-only warped query of a dense grid");
+    static_assert(!WPE || (WARP && FOLD == 0), "a warping field with a positional encoding runs point by point");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    constexpr int B_FIRST = WARP ? (FOLD ? B_XYZ8 : B_IN67) : B_PE8;     // first chunk of a pass (the prefetcher wraps to it)
+    constexpr int B_FIRST = WARP ? (FOLD ? B_XYZ8 : (WPE ? B_INPE : B_IN67)) : B_PE8;     // first chunk of a pass (the prefetcher wraps to it)
 
     const long long tk0 = clock64();
     Stream s = stream_init(p, wave, lane, B_FIRST);
@@ -1065,9 +1138,9 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
     const unsigned tiles_per_col = FOLD == 1 ? p.grz / TILE_PTS : 1u;
     float pt_next[3];                    // FOLD == 2: the next tile's point is loaded a tile ahead
     unsigned col_next = 0;
+    PointAhead ahead{};
     if constexpr (FOLD == 2) {
-        const int64_t i0 = (int64_t)blockIdx.x * TILE_PTS + wave * 32 + j;
-        col_next = load_point(p, i0 < p.n ? i0 : p.n - 1, pt_next);
+        col_next = ahead.start(p, blockIdx.x, gridDim.x, wave, j, pt_next);
         bias.rewind(p.bias + 256);           // conv1's column terms ride its k-step: the queue starts at conv2's block
     } else {
         bias.rewind(FOLD == 1 ? p.colterms + (size_t)(blockIdx.x / tiles_per_col) * 512 : p.bias);
@@ -1091,9 +1164,7 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         unsigned col = 0;
         if constexpr (FOLD == 2) {
             pt[0] = pt_next[0]; pt[1] = pt_next[1]; pt[2] = pt_next[2]; col = col_next;
-            const int64_t nt = tile + gridDim.x < p.ntiles ? tile + gridDim.x : tile;
-            const int64_t in = nt * TILE_PTS + wave * 32 + j;
-            col_next = load_point(p, in < p.n ? in : p.n - 1, pt_next);
+            col_next = ahead.advance(p, tile, gridDim.x, wave, j, pt_next);
         } else {
             load_point(p, pidx, pt);
         }
@@ -1134,6 +1205,9 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
                 for (int t = 0; t < 8; ++t) seg_fetch(sp0, crs, j, 32 * t, c1[t]);
             }
             const ParkIn S{park, &S4};
+            Frag WP[4];                      // WPE: posenc(xyz), k-steps 4..7 of the field's input
+            if constexpr (WPE) posenc_frags(pt, h, WP, s.range);                                                        // arch_avatar.py:122
+            const ParkPeIn SW{park, WP};
             const RegIn RX{X}, RY{Y}, R4{&S4};
 #if AVC_DBG_TIMING
             s.t_pro += clock64() - tp0;
@@ -1160,7 +1234,8 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
                 flush<ACT_SOFTPLUS>(w8, X, s.range);
                 dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, PendWide<ACT_SOFTPLUS>{w8, X, &s.range}, pb);         // conv2 (+ conv1's pairs 1 .. 3)
             } else {
-                dense<8, layout::IN67_KS, 0, ACT_SOFTPLUS, B_MAIN>(s, S, S, X, bias, h, NoSide{}, pa);                   // conv1+bn1
+                if constexpr (WPE) dense<8, layout::INPE_KS, 0, ACT_SOFTPLUS, B_MAIN>(s, SW, SW, X, bias, h, NoSide{}, pa);     // conv1+bn1 on [posenc | feat]
+                else dense<8, layout::IN67_KS, 0, ACT_SOFTPLUS, B_MAIN>(s, S, S, X, bias, h, NoSide{}, pa);              // conv1+bn1
                 dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                    // conv2
             }
             dense<8, 16, 0, ACT_SOFTPLUS, B_MAIN>(s, RY, RY, X, bias, h, SP{pb, Y + 12, &s.range}, pa);                        // conv3
@@ -1174,6 +1249,12 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             } else if constexpr (FOLD == 1) {
                 dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5F>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb, col5);            // conv4
                 dense<8, 16, 1, ACT_SOFTPLUS, B_MAIN>(s, RY, R4, X, bias, h, SP{pb, Y + 12, &s.range}, pa, after5);            // conv5 on [xyz | x4] (+ column term)
+            } else if constexpr (WPE) {
+                dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5PE>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                 // conv4
+                float pr[3] = {pt[0], pt[1], pt[2]};
+                asm volatile("" : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]));      // opaque: evaluated again instead of carried across conv2 .. conv4
+                posenc_frags(pr, h, WP, s.range);
+                dense<8, 16, layout::INPE_KS, ACT_SOFTPLUS, B_MAIN>(s, RY, SW, X, bias, h, SP{pb, Y + 12, &s.range}, pa);      // conv5 on [x0|x4]
             } else {
                 dense<8, 16, 0, ACT_SOFTPLUS, B_CONV5>(s, RX, RX, Y, bias, h, SP{pa, X + 12, &s.range}, pb);                   // conv4
                 dense<8, 16, layout::IN67_KS, ACT_SOFTPLUS, B_MAIN>(s, RY, S, X, bias, h, SP{pb, Y + 12, &s.range}, pa);       // conv5 on [x0|x4]
@@ -1269,7 +1350,10 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
     const long long tk0 = clock64();
     Stream s = stream_init(p, wave, lane, B_IN33);
 
-    for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    // (a launch on a LIST of tiles: what the folded subset launch left over -- see launch_recon)
+    const int64_t ntl = p.tile_list ? (int64_t)*p.tile_count : p.ntiles;
+    for (int64_t it = blockIdx.x; it < ntl; it += gridDim.x) {
+        const int64_t tile = p.tile_list ? (int64_t)p.tile_list[it] : it;
         const int64_t pidx_raw = tile * TILE_PTS + wave * 32 + j;
         const int64_t pidx = pidx_raw < p.n ? pidx_raw : p.n - 1;
         float pt[3];
@@ -1331,9 +1415,10 @@ __global__ __launch_bounds__(256, 1) void recon_kernel(const QueryParams p)
 constexpr int RCOL = 896;                         // floats per column: [fc0 rows 0..511 | fc1 | fc2], biases included
 __global__ __launch_bounds__(256) void recon_column_terms_kernel(const float *__restrict__ feat, int H, int W, const float *__restrict__ gx,
                                                                  const float *__restrict__ gy, int nx, int ny, float cx, float cy,
-                                                                 const float *__restrict__ colw, float *__restrict__ out)
+                                                                 const float *__restrict__ colw, float *__restrict__ out,
+                                                                 const uint8_t *__restrict__ colflag)
 {
-    // colw: [896][32] fp32 weights of the feature columns, then [896] biases
+    // colw: [896][32] fp32 weights of the feature columns, then [896] biases;  colflag (subset launches, else null): the columns the subset touches
     constexpr int CPB = 8;                        // columns per trip
     __shared__ __attribute__((aligned(16))) float f[CPB][32];
     const int o = threadIdx.x;
@@ -1350,6 +1435,7 @@ __global__ __launch_bounds__(256) void recon_column_terms_kernel(const float *__
     }
     const int ncol = nx * ny;
     for (int c0 = blockIdx.x * CPB; c0 < ncol; c0 += gridDim.x * CPB) {
+        if (colflag && *reinterpret_cast<const unsigned long long *>(colflag + c0) == 0ull) continue;      // (CPB == 8 flags, table padded: workgroup-uniform)
         {   // the bilinear sample of arch_recon.py:63-68 as recon_kernel<0> takes it: thread = (column, channel)
             const int q = threadIdx.x >> 5, ch = threadIdx.x & 31, col = min(c0 + q, ncol - 1);
             const Bilinear bl = bilinear_setup<32>(feat, H, W, gx[col / ny] - cx, -(gy[col % ny] - cy), 0);
@@ -1400,11 +1486,60 @@ struct BiasRegsThen {                // BiasRegs whose after-the-barrier slot ru
 
 constexpr int B_Z8 = chunk_bytes(1, 8), B_ZZ8 = chunk_bytes(2, 8), B_FC2F = first_chunk_bytes(16, 1);
 
-// FOLD: 1 = dense grid whose tiles lie in one (x, y) column each; 2 = subset of the grid by flat indices (p.gidx), column blocks gathered per lane
+// FOLD == 2 (a SUBSET of the grid, p.gidx: the valid band): the 32 points of a wave lie in whatever (x, y) columns the band gives them -- along z a band's
+// runs are long, so in one or two.  The wave's points are cut into runs of equal adjacent columns (col_segments, as in avatar_kernel<.., 2>).  Runs 0 and
+// 1 ride the z k-step exactly like the single column of a dense launch: the K slots of a k-step are split between the lane halves (h == 0: slots 0..7,
+// h == 1: slots 8..15), so the patched dword of the lanes h == 0 (slots 2, 3) carries run 0's column term of the lane's row and that of the lanes h == 1
+// (slots 10, 11) run 1's, each against 1.0 in the B operand of exactly the points of its run -- still ONE float per lane and 32-row tile, one 256-byte
+// wave-instruction, whatever the wave's points do.  A tile with a wave of MORE than two runs (band edges, tangential cuts: 0.2 - 1.4 % of the waves of a
+// band) is not evaluated here at all: band_prepass_kernel flags it (p.tile_skip) and the point-by-point recon_kernel runs on the list of flagged tiles
+// afterwards.  (A first cut added the terms of runs 2.. to the zeroed accumulators in place, six runs per MFMA: the code of that rare path cost the kernel
+// 128 registers and 1,340 v_accvgpr moves per tile on the common one -- 12 % more cycles per tile than the dense launch, profiles/r05_band_split.md.)
+constexpr unsigned RCOL_BYTES = RCOL * 4u;
+constexpr int RECON_MAX_RUNS = 2;
+struct ReconRuns {
+    unsigned voff;               // byte offset of (this lane's run column, row j) in the table
+    bool one;                    // this lane's point belongs to the run its lane half carries
+};
+__device__ __forceinline__ ReconRuns recon_runs(unsigned col, int j, int h)
+{
+    const ColSegs c = col_segments(col, j, h);
+    const unsigned long long r1 = c.first & (c.first - 1ull);
+    const int p0 = __builtin_ctzll(c.first | (1ull << 63)), p1 = r1 ? __builtin_ctzll(r1) : p0;
+    const unsigned col0 = (unsigned)__builtin_amdgcn_readlane((int)col, p0), col1 = (unsigned)__builtin_amdgcn_readlane((int)col, p1);
+    ReconRuns r;
+    r.voff = (h ? col1 : col0) * RCOL_BYTES + 4u * (unsigned)j;
+    r.one = c.seg == (unsigned)h;
+    return r;
+}
+
+// One workgroup = one 128-point tile of a subset launch (the lanes beyond n repeat point n - 1, as in the kernels): marks the (x, y) columns the subset
+// touches (colflag: the column pass then skips the others -- a band covers about a third of them), and flags / lists the tiles in which some wavefront's
+// 32 points fall into more than max_runs runs of equal adjacent columns.
+__global__ __launch_bounds__(128) void band_prepass_kernel(const int32_t *__restrict__ gidx, int64_t n, unsigned grz, int max_runs,
+                                                           uint8_t *__restrict__ colflag, int32_t *__restrict__ tile_skip,
+                                                           int32_t *__restrict__ slow_list, int32_t *__restrict__ slow_count)
+{
+    const int64_t tile = blockIdx.x, i = tile * TILE_PTS + threadIdx.x;
+    const unsigned col = (unsigned)gidx[i < n ? i : n - 1] / grz;
+    const int j = threadIdx.x & 31;
+    const unsigned prev = (unsigned)__shfl_up((int)col, 1, 32);
+    const bool first = j == 0 || prev != col;
+    if (first) colflag[col] = 1;
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(first);
+    const int slow = __syncthreads_or(__builtin_popcountll(b & 0xffffffffull) > max_runs || __builtin_popcountll(b >> 32) > max_runs);
+    if (threadIdx.x == 0) {
+        tile_skip[tile] = slow;
+        if (slow) slow_list[atomicAdd(slow_count, 1)] = (int32_t)tile;
+    }
+}
+
+// FOLD: 1 = dense grid whose tiles lie in one (x, y) column each; 2 = subset of the grid by flat indices (p.gidx), the column terms by runs of columns
 #if !AVC_CHECK_RANGE
 template <int FOLD>
 __global__ __launch_bounds__(256, 1) void recon_fold_kernel(const QueryParams p)
 {
+    static_assert(FOLD == 1 || FOLD == 2, "recon_fold_kernel: dense grid or subset");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -1420,8 +1555,7 @@ __global__ __launch_bounds__(256, 1) void recon_fold_kernel(const QueryParams p)
     float pt_next[3];
     unsigned col_next = 0;
     auto col_rsrc = [&](int64_t t) { return bias_rsrc(FOLD == 1 ? p.colterms + (size_t)(t / tiles_per_col) * RCOL : p.colterms); };
-    static_assert(FOLD == 1, "column terms ride the z k-step: one column per tile");
-    auto col_voff = [&](unsigned) { return 4u * j; };
+    auto col_voff = [&](unsigned col) { if constexpr (FOLD == 1) return 4u * (unsigned)j; else return recon_runs(col, j, h).voff; };
     auto fetch8 = [&](float *dst, const i32x4 &rs, unsigned voff, int first_row, int ntiles) {          // row j of `ntiles` consecutive tiles
 #pragma unroll
         for (int t = 0; t < 8; ++t)
@@ -1437,11 +1571,10 @@ __global__ __launch_bounds__(256, 1) void recon_fold_kernel(const QueryParams p)
             }
     };
     float cn[8];                          // fc0 rows 0..255 of the NEXT tile, requested behind the fc3 head of the current one
-    {
-        const int64_t i0 = (int64_t)blockIdx.x * TILE_PTS + wave * 32 + j;
-        col_next = load_point(p, i0 < p.n ? i0 : p.n - 1, pt_next);
-        fetch8(cn, col_rsrc(blockIdx.x), col_voff(col_next), 0, 8);
-    }
+    PointAhead ahead{};
+    col_next = ahead.start(p, blockIdx.x, gridDim.x, wave, j, pt_next);
+    fetch8(cn, col_rsrc(blockIdx.x), col_voff(col_next), 0, 8);
+    int skip_next = FOLD == 2 ? p.tile_skip[blockIdx.x] : 0;
 
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int64_t pidx_raw = tile * TILE_PTS + wave * 32 + j;
@@ -1456,21 +1589,29 @@ __global__ __launch_bounds__(256, 1) void recon_fold_kernel(const QueryParams p)
         float pt[3] = {pt_next[0], pt_next[1], pt_next[2]};
         const unsigned col = col_next;
         const int64_t tile_n = tile + gridDim.x < p.ntiles ? tile + gridDim.x : tile;           // the tile this workgroup runs next (itself: the last one)
-        {
-            const int64_t in = tile_n * TILE_PTS + wave * 32 + j;
-            col_next = load_point(p, in < p.n ? in : p.n - 1, pt_next);
+        col_next = ahead.advance(p, tile, gridDim.x, wave, j, pt_next);
+        if constexpr (FOLD == 2) {
+            const int skip = skip_next;                                                          // (requested a tile ago: a scalar load, never waited for)
+            skip_next = p.tile_skip[tile_n];
+            if (skip) {                                                                          // left to the point-by-point kernel (workgroup-uniform)
+                fetch8(cn, col_rsrc(tile_n), col_voff(col_next), 0, 8);                          // what the skipped body would have requested for the next tile
+                continue;
+            }
         }
         const float *cb = FOLD == 1 ? p.colterms + (size_t)(tile / tiles_per_col) * RCOL : p.colterms;
         asm volatile("" : "+s"(cb));
         const i32x4 crs = bias_rsrc(cb);
-        const unsigned voff = col_voff(col);
+        ReconRuns runs{};
+        if constexpr (FOLD == 2) runs = recon_runs(col, j, h);
+        const unsigned voff = FOLD == 1 ? 4u * (unsigned)j : runs.voff;
         unsigned pd0[8], pdz[16], pd2[4];  // patches: fc0 rows 0..255 | [fc0 rows 256..511, fc1] | fc2
         float cz[16], c2f[4];
         split8p(cn, pd0, 8);
-        Frag Z;                            // the z k-step's B fragment: z in slot 0, 1.0 in slots 2 and 3 (lanes h == 0 hold slots 0..7)
+        Frag Z;                            // the z k-step's B fragment: z in slot 0, 1.0 in the slots of the run this lane half carries (dense: slots 2, 3 of h == 0)
         {
             float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (h == 0) { z[0] = pt[2] - p.cz; z[2] = 1.0f; z[3] = 1.0f; }                       // arch_recon.py:62,69
+            if (h == 0) z[0] = pt[2] - p.cz;                                                      // arch_recon.py:62,69
+            if (FOLD == 1 ? h == 0 : runs.one) { z[2] = 1.0f; z[3] = 1.0f; }
             split8(z, Z.hi, Z.lo, s.range);
         }
         const SameIn RZ{&Z};
@@ -1580,10 +1721,13 @@ static int set_all_lds()
     if (int rc = set_lds(avatar_kernel<false, false, 0>)) return rc;
     if (int rc = set_lds(avatar_kernel<true, true, 0>)) return rc;
     if (int rc = set_lds(avatar_kernel<true, false, 0>)) return rc;
+    if (int rc = set_lds(avatar_kernel<true, true, 0, true>)) return rc;
+    if (int rc = set_lds(avatar_kernel<true, false, 0, true>)) return rc;
 #if !AVC_CHECK_RANGE
     if (int rc = set_lds(avatar_kernel<true, false, 1>)) return rc;
     if (int rc = set_lds(avatar_kernel<true, false, 2>)) return rc;
     if (int rc = set_lds(recon_fold_kernel<1>)) return rc;
+    if (int rc = set_lds(recon_fold_kernel<2>)) return rc;
 #endif
     if (int rc = set_lds(recon_kernel)) return rc;
     done = true;
@@ -1644,8 +1788,9 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
 #if AVC_CHECK_RANGE
     const bool can_fold = false;               // the range-checked flavour (a debugging aid) keeps to the point-by-point kernels: half the build time
 #else
-    const bool can_fold = grid && !template_only && !colour && ctx->warp_tmpl_fold.ready && ctx->opt.column_fold;
+    const bool can_fold = grid && !template_only && !colour && ctx->warp_tmpl_fold.ready && ctx->opt.column_fold && ctx->warp_pe == 0;
 #endif
+    const bool wpe = !template_only && ctx->warp_pe > 0;      // a positional encoding in front of the warping field: the eight-k-step input (avatar_kernel<.., WPE>)
     const int fold = !can_fold ? 0 : (grid->idx ? 2 : (grid->res[2] % TILE_PTS == 0 ? 1 : 0));
     PackedNet &net = template_only ? (colour ? ctx->tmpl_only_clr : ctx->tmpl_only) : (colour ? ctx->warp_tmpl_clr : (fold ? ctx->warp_tmpl_fold : ctx->warp_tmpl));
     AVC_REQUIRE(!colour || net.ready || !(template_only ? ctx->tmpl_only : ctx->warp_tmpl).ready, AVC_ERR_STATE,
@@ -1678,13 +1823,14 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
     if (int rc0 = set_all_lds()) return rc0;
     hipEvent_t e0, e1;
     timing_begin(ctx, 0, s, e0, e1, p);        // (a folded launch is timed with its column pass)
-#define LAUNCH(W_, C_, F_)                                                                              \
+#define LAUNCH(W_, C_, F_, ...)                                                                         \
     do {                                                                                                \
-        rc = set_lds(avatar_kernel<W_, C_, F_>);                                                        \
+        rc = set_lds(avatar_kernel<W_, C_, F_, ##__VA_ARGS__>);                                         \
         if (rc) return rc;                                                                              \
-        hipLaunchKernelGGL((avatar_kernel<W_, C_, F_>), dim3(grid_dim), dim3(256), LDS_BYTES, s, p);   \
+        hipLaunchKernelGGL((avatar_kernel<W_, C_, F_, ##__VA_ARGS__>), dim3(grid_dim), dim3(256), LDS_BYTES, s, p);   \
     } while (0)
     if (template_only) { if (colour) LAUNCH(false, true, 0); else LAUNCH(false, false, 0); }
+    else if (wpe) { if (colour) LAUNCH(true, true, 0, true); else LAUNCH(true, false, 0, true); }
     else if (colour) LAUNCH(true, true, 0);
     else if (fold) {
         const int ncol = grid->res[0] * grid->res[1];
@@ -1703,11 +1849,12 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
 
 int launch_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], float *out, hipStream_t s)
 {
-    // a dense grid launch is column-folded (recon_fold_kernel) when its tiles lie in one (x, y) column each; everything else runs recon_kernel
+    // a dense grid launch is column-folded (recon_fold_kernel<1>) when its tiles lie in one (x, y) column each, a SUBSET of a grid (grid->idx: the valid
+    // band) by runs of columns (recon_fold_kernel<2>); point lists run recon_kernel
 #if AVC_CHECK_RANGE
     const int fold = 0;                    // the range-checked flavour keeps to the point-by-point kernel
 #else
-    const int fold = grid && !grid->idx && grid->res[2] % TILE_PTS == 0 && ctx->recon_fold.ready && ctx->opt.column_fold ? 1 : 0;
+    const int fold = !(grid && ctx->recon_fold.ready && ctx->opt.column_fold) ? 0 : (grid->idx ? 2 : (grid->res[2] % TILE_PTS == 0 ? 1 : 0));
 #endif
     PackedNet &net = fold ? ctx->recon_fold : ctx->recon;
     AVC_REQUIRE(net.ready, AVC_ERR_STATE, "recon query: weights not packed (call avc_pack_recon_weights)");
@@ -1736,17 +1883,59 @@ int launch_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n
         }
         p.colterms = static_cast<const float *>(ctx->rcol_scratch);
     }
+    // a subset launch: flags of the columns the subset touches, of the tiles the folded kernel leaves out, and their list (band_prepass_kernel)
+    uint8_t *colflag = nullptr;
+    int32_t *tile_skip = nullptr, *slow_list = nullptr, *slow_count = nullptr;
+    size_t head_bytes = 0;
+    if (fold == 2) {
+        const size_t ncol = (size_t)grid->res[0] * grid->res[1], ncol_pad = (ncol + 15) / 16 * 16;
+        head_bytes = 16 + ncol_pad;
+        const size_t bytes = head_bytes + (size_t)p.ntiles * 8;
+        if (ctx->band_scratch_bytes < bytes) {
+            if (ctx->band_scratch) { AVC_HIP(hipDeviceSynchronize()); AVC_HIP(hipFree(ctx->band_scratch)); }
+            ctx->band_scratch = nullptr; ctx->band_scratch_bytes = 0;
+            AVC_HIP(hipMalloc(&ctx->band_scratch, bytes));
+            ctx->band_scratch_bytes = bytes;
+        }
+        char *base = static_cast<char *>(ctx->band_scratch);
+        slow_count = reinterpret_cast<int32_t *>(base);
+        colflag = reinterpret_cast<uint8_t *>(base + 16);
+        tile_skip = reinterpret_cast<int32_t *>(base + head_bytes);
+        slow_list = tile_skip + p.ntiles;
+        AVC_REQUIRE(ctx->recon.ready, AVC_ERR_STATE, "recon query: weights not packed (call avc_pack_recon_weights)");
+    }
     if (int rc0 = set_all_lds()) return rc0;
     hipEvent_t e0, e1;
-    timing_begin(ctx, 1, s, e0, e1, p);        // (a folded launch is timed with its column pass)
+    timing_begin(ctx, 1, s, e0, e1, p);        // (a folded launch is timed with its column pass, a subset launch also with its prepass and its left-over tiles)
 #if !AVC_CHECK_RANGE
     if (fold) {
         const int ncol = grid->res[0] * grid->res[1];
+        if (fold == 2) {
+            AVC_HIP(hipMemsetAsync(ctx->band_scratch, 0, head_bytes, s));
+            hipLaunchKernelGGL(band_prepass_kernel, dim3((unsigned)p.ntiles), dim3(TILE_PTS), 0, s, p.gidx, p.n, p.grz, RECON_MAX_RUNS, colflag, tile_skip,
+                               slow_list, slow_count);
+        }
         hipLaunchKernelGGL(recon_column_terms_kernel, dim3(std::min((ncol + 7) / 8, ctx->num_cus * 4)), dim3(256), 0, s, p.feat, p.H, p.W, p.gx, p.gy,
-                           (int)grid->res[0], (int)grid->res[1], p.cx, p.cy, (const float *)net.d_colw, static_cast<float *>(ctx->rcol_scratch));
-        rc = set_lds(recon_fold_kernel<1>);
-        if (rc) return rc;
-        hipLaunchKernelGGL(recon_fold_kernel<1>, dim3(grid_dim), dim3(256), LDS_BYTES, s, p);
+                           (int)grid->res[0], (int)grid->res[1], p.cx, p.cy, (const float *)net.d_colw, static_cast<float *>(ctx->rcol_scratch), colflag);
+        if (fold == 2) {
+            p.tile_skip = tile_skip;
+            rc = set_lds(recon_fold_kernel<2>);
+            if (rc) return rc;
+            hipLaunchKernelGGL(recon_fold_kernel<2>, dim3(grid_dim), dim3(256), LDS_BYTES, s, p);
+            // the tiles it left out (a wavefront with more than two runs of columns), point by point on the generated coordinates
+            QueryParams q = p;
+            q.clk = nullptr; q.colterms = nullptr; q.tile_skip = nullptr;
+            q.tile_list = slow_list; q.tile_count = slow_count;
+            q.wstream = (const char *)ctx->recon.d_stream; q.bias = ctx->recon.d_bias;
+            q.stream_bytes = bytes_until(ctx->recon, ctx->recon.chunks.size());
+            rc = set_lds(recon_kernel);
+            if (rc) return rc;
+            hipLaunchKernelGGL(recon_kernel, dim3(grid_dim), dim3(256), LDS_BYTES, s, q);
+        } else {
+            rc = set_lds(recon_fold_kernel<1>);
+            if (rc) return rc;
+            hipLaunchKernelGGL(recon_fold_kernel<1>, dim3(grid_dim), dim3(256), LDS_BYTES, s, p);
+        }
     } else
 #endif
     {

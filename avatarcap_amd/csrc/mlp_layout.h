@@ -54,6 +54,20 @@ constexpr int pe_column(int slot)     // -> column of the reference's 63-wide em
     return h == 0 ? 1 : -1;
 }
 
+// ---- WarpingField input with model.warping_field.pos_encoding = L > 0: [posenc(xyz) (3 + 6 L) | pose_feat(64)] (arch_avatar.py:122,136), 8 k-steps:
+// k-steps 0..3 the 64 sampled channels as above, k-steps 4..7 the positional encoding of the RAW point in the PE layout (all ten octaves are
+// evaluated; the columns of octaves >= L do not exist in the weights and pack as zeros).  L = 0 is the 5-k-step layout above (xyz alone).
+constexpr int INPE_KS = 4 + PE_KS;
+constexpr int inpe_column(int slot, int L)   // -> column of conv1 / the [input | x4] part of conv5, or -1
+{
+    const int ks = slot >> 4, h = (slot >> 3) & 1, e = slot & 7;
+    if (ks < 4) return 3 + 6 * L + h * 32 + ks * 8 + e;
+    const int c = pe_column(slot - 64);
+    return c >= 0 && c < 3 + 6 * L ? c : -1;
+}
+// the template's embedding with model.cano_template.pos_encoding = L <= 10: the first 3 + 6 L of the 63 columns
+constexpr int pe_column_l(int slot, int L) { const int c = pe_column(slot); return c >= 0 && c < 3 + 6 * L ? c : -1; }
+
 // ---- ReconNetwork decoder input: [img_feat(32) | z] = 33 columns (arch_recon.py:70), 3 k-steps.
 // k-steps 0..1: lane-half h gathers channels 16h..16h+15; k-step 2: z in (h = 0, e = 0).
 constexpr int IN33_KS = 3;

@@ -93,9 +93,13 @@ Seg seg_xyz()       // the xyz k-step of the 67-wide input alone (column-folded 
 {
     return Seg{1, [](int s) { return layout::in67_column(4 * 16 + s); }};
 }
-Seg seg_pe(int col_offset = 0)
+Seg seg_pe(int col_offset = 0, int L = 10)      // the first 3 + 6 L columns of the embedding (cano_template.pos_encoding = L <= 10: net_util.py:40-55)
 {
-    return Seg{layout::PE_KS, [col_offset](int s) { int c = layout::pe_column(s); return c < 0 ? -1 : col_offset + c; }};
+    return Seg{layout::PE_KS, [col_offset, L](int s) { int c = layout::pe_column_l(s, L); return c < 0 ? -1 : col_offset + c; }};
+}
+Seg seg_inpe(int L)       // [posenc_L(xyz) | feat(64)] of a warping field with pos_encoding = L > 0: 8 k-steps (mlp_layout.h)
+{
+    return Seg{layout::INPE_KS, [L](int s) { return layout::inpe_column(s, L); }};
 }
 Seg seg_z33(int col_offset = 0)       // the z k-step of the 33-wide input alone (column-folded recon stream)
 {
@@ -166,7 +170,7 @@ int upload(PackedNet &net)
 // bias are pre-multiplied by log2(e) (the accumulator becomes m) and every consumer of a Softplus output
 // absorbs the missing ln(2) into its weight columns.  For a Softplus layer fed by a Softplus layer the
 // two factors cancel (log2 e * ln 2 = 1): only the bias changes.
-static void add_warp(Builder &B, const avc_ctx::Staged &w, bool fold = false)
+static void add_warp(Builder &B, const avc_ctx::Staged &w, bool fold = false, int L = 0)
 {
     const double LOG2E = 1.4426950408889634074, LN2 = 0.69314718055994530942;
     auto scaled = [](std::vector<double> v, double f, int cin = 0, int c0 = 0, int c1 = -1) {
@@ -176,8 +180,9 @@ static void add_warp(Builder &B, const avc_ctx::Staged &w, bool fold = false)
     };
     // fold: a dense launch whose tiles lie in one (x, y) column gets the 64 pose-feature columns of conv1 / conv5 as a per-column accumulator
     // init (column_terms_kernel, fused_mlp.hip): the stream keeps the xyz k-step only, the fp32 weights of the 64 columns go to net.colw
-    const std::vector<double> W1 = scaled(w.W[0], LOG2E), W5 = scaled(w.W[4], LOG2E, 323, 0, 67);
-    if (fold) {
+    const int D = 3 + 6 * L + 64;          // conv1's input: [posenc_L(xyz) | feat(64)] (arch_avatar.py:100,136); L = 0: [xyz | feat] = 67
+    const std::vector<double> W1 = scaled(w.W[0], LOG2E), W5 = scaled(w.W[4], LOG2E, D + 256, 0, D);
+    if (fold) {           // (L == 0 only: pack_avatar)
         B.net.colw.assign((size_t)2 * 256 * 64, 0.0f);
         for (int o = 0; o < 256; ++o)
             for (int c = 0; c < 64; ++c) {
@@ -185,10 +190,10 @@ static void add_warp(Builder &B, const avc_ctx::Staged &w, bool fold = false)
                 B.net.colw[(size_t)(256 + o) * 64 + c] = (float)W5[(size_t)o * 323 + 3 + c];              // conv5 sees cat([x0, x4]) (mlp.py:106)
             }
     }
-    B.layer(W1, scaled(w.b[0], LOG2E), 256, 67, {fold ? seg_xyz() : seg_in67()}, fold ? 8 : 2, 16);        // conv1 (raw inputs; folded: one wide chunk)
+    const Seg in = L > 0 ? seg_inpe(L) : (fold ? seg_xyz() : seg_in67());
+    B.layer(W1, scaled(w.b[0], LOG2E), 256, D, {in}, fold ? 8 : 2, 16);                                     // conv1 (raw inputs; folded: one wide chunk)
     for (int i = 1; i <= 3; ++i) B.layer(w.W[i], scaled(w.b[i], LOG2E), 256, 256, {seg_d(16)}, 2, 16);      // conv2..4
-    B.layer(W5, scaled(w.b[4], LOG2E), 256, 323,
-            {seg_d(16, 67), fold ? seg_xyz() : seg_in67()}, 2, 16);              // conv5: cat([x0 (raw), x4 (softplus)]) (mlp.py:106)
+    B.layer(W5, scaled(w.b[4], LOG2E), 256, D + 256, {seg_d(16, D), in}, 2, 16);                            // conv5: cat([x0 (raw), x4 (softplus)]) (mlp.py:106)
     for (int i = 5; i <= 6; ++i) B.layer(w.W[i], scaled(w.b[i], LOG2E), 256, 256, {seg_d(16)}, 2, 16);      // conv6..7
     B.layer(scaled(w.W[7], LN2), w.b[7], 3, 256, {seg_d(16)}, 1, 16);             // out_layer_coord_affine (linear consumer)
 }
@@ -196,11 +201,13 @@ static void add_warp(Builder &B, const avc_ctx::Staged &w, bool fold = false)
 // `colour` streams keep shared.6 (its output feeds both heads).  Geometry-only streams fold shared.6
 // (linear, no activation: mlp.py:46,64) into geo.0:  W_g0 (W_6 x + b_6) + b_g0 = (W_g0 W_6) x + (W_g0 b_6 + b_g0),
 // an exact identity that removes 65,536 of the 886,784 MAC per point (and one epilogue).
-static void add_template(Builder &B, const avc_ctx::Staged &t, bool colour, bool warp)
+static void add_template(Builder &B, const avc_ctx::Staged &t, bool colour, bool warp, int L = 10)
 {
-    B.layer(t.W[0], t.b[0], 256, 63, {seg_pe()}, warp && colour ? 2 : 8, 16);    // shared 0: one wide chunk (k-major over all eight tiles); the warped colour kernel keeps tile pairs
+    const int P = 3 + 6 * L;               // embedding width of cano_template.pos_encoding = L (arch_avatar.py:33-36); the kernel evaluates all ten octaves,
+                                           // the columns of octaves >= L pack as zero weights
+    B.layer(t.W[0], t.b[0], 256, P, {seg_pe(0, L)}, warp && colour ? 2 : 8, 16);    // shared 0: one wide chunk (k-major over all eight tiles); the warped colour kernel keeps tile pairs
     for (int i = 1; i <= 3; ++i) B.layer(t.W[i], t.b[i], 256, 256, {seg_d(16)}, 2, 16);
-    B.layer(t.W[4], t.b[4], 256, 319, {seg_d(16), seg_pe(256)}, 2, 16);          // shared 4: cat([x, x0]) (mlp.py:61)
+    B.layer(t.W[4], t.b[4], 256, 256 + P, {seg_d(16), seg_pe(256, L)}, 2, 16);   // shared 4: cat([x, x0]) (mlp.py:61)
     B.layer(t.W[5], t.b[5], 256, 256, {seg_d(16)}, 2, 16);
     if (colour) {
         B.layer(t.W[6], t.b[6], 256, 256, {seg_d(16)}, 2, 16);                   // shared 6 (linear)
@@ -231,8 +238,8 @@ int pack_avatar(avc_ctx *ctx)
     const bool has_clr = ctx->tmpl_st.W.size() == 12;
     auto build = [&](PackedNet &net, bool warp, bool colour, bool fold = false) -> int {
         Builder B(net);
-        if (warp) add_warp(B, ctx->warp_st, fold);
-        add_template(B, ctx->tmpl_st, colour, warp);
+        if (warp) add_warp(B, ctx->warp_st, fold, ctx->warp_pe);
+        add_template(B, ctx->tmpl_st, colour, warp, ctx->tmpl_pe);
         AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
         net.has_colour = colour;
         return upload(net);
@@ -245,7 +252,10 @@ int pack_avatar(avc_ctx *ctx)
     if (ctx->warp_set && ctx->tmpl_set) {
         int rc = build(ctx->warp_tmpl, true, false);
         if (rc) return rc;
-        if ((rc = build(ctx->warp_tmpl_fold, true, false, true))) return rc;
+        // column folding takes the 64 feature columns out of conv1 / conv5 and leaves the xyz k-step: with a positional encoding in front of the warping
+        // field (warp_pe > 0) the launches stay point by point (fused_mlp.hip launch_avatar)
+        if (ctx->warp_pe == 0) { if ((rc = build(ctx->warp_tmpl_fold, true, false, true))) return rc; }
+        else release(ctx->warp_tmpl_fold);
         if (has_clr && (rc = build(ctx->warp_tmpl_clr, true, true))) return rc;
     }
     return AVC_OK;

@@ -74,8 +74,10 @@ def synth_state_dict(shapes: dict, seed: int = SEED, gain: float = 1.6, spectral
                 # also keeps the field smooth at voxel scale so marching cubes sees a surface.
                 # Embedding columns = [xyz, sin f0, cos f0, sin f1, ...] (net_util.py:37); layer 4
                 # sees them after its 256 hidden inputs (mlp.py:61).
-                c0 = shape[1] - 63
-                for f in range(10):
+                # (the embedding is 3 + 6 L wide for cano_template.pos_encoding = L: 63 for the example's 10)
+                pe = shape[1] if key.endswith('fc_list.0.0.weight') else shape[1] - 256
+                c0 = shape[1] - pe
+                for f in range((pe - 3) // 6):
                     w[:, c0 + 3 + 6 * f: c0 + 9 + 6 * f] *= 2.0 ** (-1.35 * f)
             if spectral_decay and key.endswith('out_layer_coord_affine.weight'):
                 w *= 0.05          # non-rigid offsets of a few centimetres, like a trained warping field

@@ -487,7 +487,7 @@ def other_configs(device, frames=3):
                'ms_per_frame': full_ms, 'frames_per_s': 1e3 / full_ms,
                'stage_ms': {'avatar_frame (unet + band query + mc + lbs)': t_av, 'normal maps + fusion': t_fu,
                             'recon_frame (hgfilter + band query + mc + lbs)': t_re, 'of which hgfilter': t_hg, 'of which unet7ds (in avatar_frame)': t_un},
-               'kernel_ms': {'avatar query (band, column-folded)': q[0][0].value, 'recon query (band, point by point on generated coordinates)': q[1][0].value},
+               'kernel_ms': {'avatar query (band, column-folded)': q[0][0].value, 'recon query (band, column-folded)': q[1][0].value},
                'avatar_vertices': int(a['cano_v'].shape[0]), 'recon_vertices': int(r['cano_v'].shape[0])}
         del ds, pipe, items, a, r, obs, fm, it, imgs
         torch.cuda.empty_cache()
@@ -499,7 +499,7 @@ def other_configs(device, frames=3):
     nb = c2['valid_points']
     out['secondary_rooflines'] = {
         'avatar band query (avatar_kernel, column-folded band)': {'bound': 'mfma', 'achieved_tflops': nb * FLOP_PER_POINT / (c2['kernel_ms']['avatar query (band, column-folded)'] * 1e-3) / 1e12},
-        'recon band query (recon_kernel)': {'bound': 'mfma', 'achieved_tflops': nb * 387072 / (c2['kernel_ms']['recon query (band, point by point on generated coordinates)'] * 1e-3) / 1e12},
+        'recon band query (recon_fold_kernel<2>, column-folded band)': {'bound': 'mfma', 'achieved_tflops': nb * 387072 / (c2['kernel_ms']['recon query (band, column-folded)'] * 1e-3) / 1e12},
         'HGFilter encoder (conv_enc.hip, ~70 launches incl. their gaps)': {'bound': 'mfma', 'achieved_tflops': 232.3e9 / (c2['stage_ms']['of which hgfilter'] * 1e-3) / 1e12},
         'UNet7DS (conv_enc.hip, 18 launches; weight-stream bound at its deep levels)': {'bound': 'mfma', 'achieved_tflops': 10.35e9 / (c2['stage_ms']['of which unet7ds (in avatar_frame)'] * 1e-3) / 1e12},
     }

@@ -57,13 +57,17 @@ typedef struct { const float *gamma, *beta, *mean, *var; float eps; } avc_bn;
 
 /* WarpingField.mlp (OffsetDecoder conv1..7 + bn1..7) and out_layer_coord_affine
  * (network/arch_avatar.py:100-105; network/mlp.py:75-112).  BatchNorm is folded at pack time.
- * pos_encoding is cfg['model']['warping_field']['pos_encoding'] (only 0 is supported: that is
- * the value configs/example.yaml ships and the only one the 67-wide checkpoints fit). */
+ * pos_encoding = cfg['model']['warping_field']['pos_encoding'] = L, 0 .. 10 (network/arch_avatar.py:97-100): conv1 is (256, 3 + 6 L + 64), conv5
+ * (256, 3 + 6 L + 64 + 256) -- the field's input is [get_embedder(L)(xyz) | pose_feat(64)] (:122,136; utils/net_util.py:40-55).  L = 0 is what
+ * configs/example.yaml ships (67-wide checkpoints): grid launches are then column-folded.  With L > 0 the encoding of the raw point is evaluated in the
+ * kernel (all ten octaves; the columns of octaves >= L pack as zeros) and every launch runs point by point.  L > 10 -> AVC_ERR_ARG. */
 int avc_pack_warp_weights(avc_ctx *ctx, const avc_dense conv[7], const avc_bn bn[7],
                           const avc_dense *out_affine, int pos_encoding);
 
 /* DoubleTNet shared_mlp (7 layers, res @4), geo_mlp (2), clr_mlp (3, may be NULL)
- * (network/arch_avatar.py:37-58).  pos_encoding must be 10 (63-wide checkpoints). */
+ * (network/arch_avatar.py:37-58).  pos_encoding = cfg['model']['cano_template']['pos_encoding'] = L, 0 .. 10 (:33-36): shared[0] is (256, 3 + 6 L),
+ * shared[4] (256, 256 + 3 + 6 L) (res layer, mlp.py:61); 10 = the example's 63-wide checkpoints.  The kernels evaluate ten octaves whatever L is;
+ * the columns of octaves >= L do not exist in the checkpoint and pack as zero weights (same speed for every L).  L > 10 -> AVC_ERR_ARG. */
 int avc_pack_template_weights(avc_ctx *ctx, const avc_dense shared[7], const avc_dense geo[2],
                               const avc_dense *clr /* [3] or NULL */, int pos_encoding);
 
@@ -233,8 +237,12 @@ int avc_recon_query(avc_ctx *ctx, const float *pts_dev, int64_t n, const float c
  * (arch_recon.py:63-70) and feeds fc0, fc1 and fc2 (res_layers).  A DENSE grid whose R_z is a multiple of 128 is column-folded: what the three layers do
  * with the 32 feature channels is one fp32 vector of 896 values per (x, y) column (3.5 KB per column of scratch in the context), which enters the
  * accumulators through free K slots of the z k-step; only the z column stays a per-point product: 14 % fewer MFMAs, no per-point gather, 13.2 instead of
- * 17.6 ms at 256^3.  Same algebra as avc_recon_query, other rounding: ~1e-6 from it.  Every other launch -- another R_z, a subset, or
- * avc_set_option "column_fold" 0 -- runs the point-by-point kernel on the generated points: bit-identical to avc_recon_query. */
+ * 17.6 ms at 256^3.  A SUBSET (the valid band) is column-folded whatever its shape (round 5): the 32 points of a wavefront are cut into runs of equal
+ * adjacent (x, y) columns; the first two runs ride the z k-step like the single column of a dense launch (one run per lane half), further runs -- rare
+ * in a band, whose runs along z are long -- are added to the zeroed accumulators first.  Same algebra as avc_recon_query, other rounding: ~1e-6 from it;
+ * bit-reproducible from call to call, and a point's value depends on which points share its wavefront only through the rounding of ONE fp32 addition
+ * (measured: tests/test_gpu_query.py::test_recon_grid_subset_query).  Every other launch -- a dense grid with another R_z, or avc_set_option
+ * "column_fold" 0 -- runs the point-by-point kernel on the generated points: bit-identical to avc_recon_query. */
 int avc_recon_query_grid(avc_ctx *ctx, const float *axis_x_dev, const float *axis_y_dev, const float *axis_z_dev,
                          const int32_t res[3], const float center[3], float *out_dev, avc_stream stream);
 int avc_recon_query_grid_subset(avc_ctx *ctx, const float *axis_x_dev, const float *axis_y_dev, const float *axis_z_dev,

@@ -26,6 +26,21 @@ def geotex_sd(seed=gi.SEED_NET):
 
 
 @functools.lru_cache(maxsize=None)
+def geotex_sd_posenc(lt, lw, seed=gi.SEED_NET):
+    """The synthetic state dict of a GeoTexAvatar built with model.cano_template.pos_encoding = lt and model.warping_field.pos_encoding = lw (first
+    layers and res-concat layers sized by the keys, arch_avatar.py:33-36, 97-100); the global config is restored."""
+    _cfg()
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar
+    keep = (config.cfg['model']['cano_template']['pos_encoding'], config.cfg['model']['warping_field']['pos_encoding'])
+    config.cfg['model']['cano_template']['pos_encoding'], config.cfg['model']['warping_field']['pos_encoding'] = int(lt), int(lw)
+    try:
+        net = GeoTexAvatar(base_weight_volume=gi.blend_weight_volume())
+    finally:
+        config.cfg['model']['cano_template']['pos_encoding'], config.cfg['model']['warping_field']['pos_encoding'] = keep
+    return syn.synth_state_dict(syn.module_shapes(net), seed)
+
+
+@functools.lru_cache(maxsize=None)
 def geotex_sd_with_density(seed=gi.SEED_NET, sigma_bias=20.0):
     """geotex_sd with the density head's bias raised: with the plain recipe relu(geo[1]) is zero everywhere, the NeRF compositing
     of main.py:464-477 returns black and a comparison of vertex colours is vacuous.  sigma ~ 20 gives an accumulated opacity of

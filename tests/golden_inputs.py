@@ -139,3 +139,7 @@ def ply_mesh():
     v = rs.randn(7, 3).astype(np.float32); n = unit_vectors(15, 7)
     f = rs.randint(0, 7, (5, 3)).astype(np.int32); c = rs.rand(7, 3).astype(np.float32) * 0.99
     return v, f, n, c
+
+
+# (cano_template.pos_encoding, warping_field.pos_encoding) pairs of tests/golden/make_golden_posenc.py -- none of them configs/example.yaml's (10, 0)
+POSENC_VARIANTS = [(6, 4), (0, 0), (10, 10), (3, 1)]

@@ -381,7 +381,9 @@ def test_normal_fusion_step_in_the_frame_loop(pipe64):
     other = dict(items); other['cano_pts'] = items['cano_pts'].clone()
     assert pipe64._grid_items(other) is None
     r3 = pipe64.recon_frame({**other, 'front_normal': front, 'back_normal': back})
-    assert torch.equal(r3['occ_volume'], r['occ_volume'])                     # (a band launch of the recon query is bit-identical to the point query)
+    # (since round 5 the band launch of the recon query is column-folded like the avatar's: ~1e-6 from the point query, the filled part identical)
+    d3 = float((r3['occ_volume'] - r['occ_volume']).abs().max())
+    assert 0 < d3 < 2e-5 and torch.equal(r3['occ_volume'][pipe64.ds.valid_u8 == 0], r['occ_volume'][pipe64.ds.valid_u8 == 0])
 
 
 def test_latency_mode_single_rank_equals_throughput_mode(pipe64):

@@ -63,6 +63,27 @@ def test_G4_G5_avatar_query(golden):
     assert maxabs(orc.occupancy_query(gpts, fmap, c, sd)['cano_pts_ov'], golden['G5_grid64_sel_occ']) < 1e-4
 
 
+@pytest.mark.parametrize('variant', range(len(gi.POSENC_VARIANTS)))
+def test_posenc_variants_of_the_avatar_query(variant):
+    """model.cano_template.pos_encoding / model.warping_field.pos_encoding other than the example's (10, 0): the oracle against the imported reference built
+    with those keys (tests/golden/make_golden_posenc.py; arch_avatar.py:33-36, 97-100, 122)."""
+    import os
+    from common import geotex_sd_posenc
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'posenc_golden.npz'))
+    lt, lw = gi.POSENC_VARIANTS[variant]
+    assert g['variants'].tolist()[variant] == [lt, lw]
+    tag = f'T{lt}_W{lw}'
+    sd, fmap, pts, c = geotex_sd_posenc(lt, lw), gi.pose_feat_map(), gi.query_points(130 + variant, 1024), gi.center()
+    assert sd['cano_template.shared_mlp.fc_list.0.0.weight'].shape[1] == 3 + 6 * lt and sd['warping_field.mlp.conv1.weight'].shape[1] == 3 + 6 * lw + 64
+    off = orc.warping_query(pts, fmap, c, sd, pos_encoding=lw)
+    assert maxabs(off, g[tag + '_offset']) < 2e-5 * max(1.0, float(np.abs(g[tag + '_offset']).max()))
+    o = orc.occupancy_query(pts, fmap, c, sd, 'sdf', tmpl_pos_encoding=lt, warp_pos_encoding=lw)
+    assert np.abs(g[tag + '_occ']).max() > 0.05, 'vacuous fixture'
+    assert maxabs(o['cano_pts_ov'], g[tag + '_occ']) < 1e-4
+    rgb, alpha, occ = orc.double_tnet(pts, sd, pos_encoding=lt)
+    assert maxabs(rgb, g[tag + '_tmpl_rgb']) < 1e-4 and maxabs(alpha, g[tag + '_tmpl_alpha']) < 1e-4 and maxabs(occ, g[tag + '_tmpl_occ']) < 1e-4
+
+
 def test_G6_recon_decoder(golden):
     y = orc.recon_infer(gi.query_points(104, 2048), gi.img_feat_map(), gi.center(), recon_sd())
     assert maxabs(y, golden['G6_decoder']) < 2e-5

@@ -23,15 +23,22 @@ cw = torch.cat([cols, cols[-1:].expand(pad)]).reshape(-1, 32)
 per_wave = ((cw[:, 1:] != cw[:, :-1]).sum(1) + 1)
 print(f'band: {n} points, {runs} runs along z (mean length {n / runs:.1f}); runs per wave: mean {per_wave.float().mean():.2f}, max {int(per_wave.max())}, '
       f'waves with > 6 runs: {100.0 * (per_wave > 6).float().mean():.2f} %')
-for fold in (1, 0):
-    _lib.set_option('column_fold', fold)
-    q.query_grid(items, ds.grid_axes, [256] * 3, index=ds.valid_idx); torch.cuda.synchronize()
-    _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
-    for _ in range(10): q.query_grid(items, ds.grid_axes, [256] * 3, index=ds.valid_idx)
-    torch.cuda.synchronize()
-    ms, nl, cyc = C.c_double(), C.c_int64(), C.c_double()
-    _lib.check(_lib.lib().avc_timing_read(ctx, 0, C.byref(ms), C.byref(nl), 1))
-    _lib.check(_lib.lib().avc_timing_read_cycles(ctx, 0, C.byref(cyc), C.byref(nl)))
-    _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
-    print(f'band query {"folded" if fold else "point-by-point"}: {ms.value:.3f} ms  {ms.value / n * 1e6:.3f} ns/pt  {cyc.value / ms.value / 1e3:.0f} MHz', flush=True)
+cus = torch.cuda.get_device_properties(0).multi_processor_count
+for what, index, npts, reps in (('band', ds.valid_idx, n, 10), ('dense', None, 256 ** 3, 3)):
+    for fold in (1, 0):
+        if index is None and not fold:
+            continue
+        _lib.set_option('column_fold', fold)
+        q.query_grid(items, ds.grid_axes, [256] * 3, index=index); torch.cuda.synchronize()
+        _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
+        for _ in range(reps): q.query_grid(items, ds.grid_axes, [256] * 3, index=index)
+        torch.cuda.synchronize()
+        ms, nl, cyc = C.c_double(), C.c_int64(), C.c_double()
+        _lib.check(_lib.lib().avc_timing_read(ctx, 0, C.byref(ms), C.byref(nl), 1))
+        _lib.check(_lib.lib().avc_timing_read_cycles(ctx, 0, C.byref(cyc), C.byref(nl)))
+        _lib.check(_lib.lib().avc_timing_enable(ctx, 0))
+        tiles = (npts + 127) // 128
+        tiles_wg0 = (tiles - 1) // cus + 1             # tiles of workgroup 0, whose s_memtime stamps `cyc` is
+        print(f'{what} query {"folded" if fold else "point-by-point"}: {ms.value:.3f} ms (with its column pass)  {ms.value / npts * 1e6:.3f} ns/pt  '
+              f'kernel {cyc.value:.4e} shader cycles = {cyc.value / tiles_wg0:.0f} per tile of workgroup 0 ({tiles_wg0} tiles; mean {tiles / cus:.2f} per workgroup)', flush=True)
 _lib.set_option('column_fold', 1)
