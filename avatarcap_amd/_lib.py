@@ -99,6 +99,9 @@ _SIGNATURES = {
     'avc_merge_normal_images_cover': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'avc_knn': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_calculate_lbs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'avc_lbs_prepare': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'avc_calculate_lbs_bound': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'avc_lbs_bound_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'avc_skinning': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_timing_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'avc_timing_read': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),

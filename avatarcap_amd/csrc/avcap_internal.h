@@ -59,6 +59,7 @@ struct Options {
     int enc_graph = 1;        // the image encoder's launches replayed as a hipGraph
     int enc_ksplit = 1;       // convolutions with few workgroups split K over several (partial sums in HBM, added in a fixed order by the last to arrive)
     int enc_fork = 1;         // the hourglass' upper branches (b1_k) run on a second stream beside the lower ones
+    int lbs_reach_mm = 140;   // avc_lbs_prepare: cells whose centre lies within this distance of its 4th nearest vertex get a candidate list (0: no lists)
     int mc_walk = 1;          // marching cubes: the classify pass that walks z inside a workgroup, where the volume's shape allows it (0: the general one)
 };
 
@@ -96,6 +97,7 @@ struct avc_ctx {
     void *scatter_scratch = nullptr; size_t scatter_scratch_bytes = 0;   // block counts of avc_scatter_volume
     void *render_scratch = nullptr; size_t render_scratch_bytes = 0;   // per-sample buffers of avc_render_rays_cano
     void *knn_scratch = nullptr; size_t knn_scratch_bytes = 0;     // uniform grid over the KNN reference points
+    void *lbs_bound = nullptr;                                     // avc_lbs_prepare: the sequence's canonical SMPL vertices, their grid and per-cell candidate lists (knn_lbs.hip)
     void *col_scratch = nullptr; size_t col_scratch_bytes = 0;     // per-column terms of a column-folded dense query (512 floats per column)
     void *rcol_scratch = nullptr; size_t rcol_scratch_bytes = 0;   // ... of a column-folded recon query (896 floats per column)
     void *band_scratch = nullptr; size_t band_scratch_bytes = 0;   // subset launches of the recon query: [left-over tile count | column flags | tile flags | tile list]
@@ -162,5 +164,9 @@ int knn(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, 
 // out[i] = 0 if some reference point has cand d2 < thr2, +inf otherwise (the K = 1 search's d2 < thr2, without the search for the nearest)
 int near_flags(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32_t nr, float thr2, float *out, hipStream_t s);
 int calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s);
+int lbs_prepare(avc_ctx *ctx, const float *cano_v, int32_t nv, hipStream_t s);
+int calculate_lbs_bound(avc_ctx *ctx, const float *pts, int64_t n, const float *skin_w, float *lbs, hipStream_t s);
+int lbs_bound_stats(avc_ctx *ctx, int64_t out[4]);
+void release_lbs_bound(avc_ctx *ctx);
 int skinning(const float *pts, const float *nrm, int64_t n, const float *lbs, const float *jm, float *po, float *no, float *mo, hipStream_t s);
 }  // namespace avc

@@ -59,6 +59,7 @@ int avc_ctx_destroy(avc_ctx *ctx)
     if (ctx->col_scratch) hipFree(ctx->col_scratch);
     if (ctx->rcol_scratch) hipFree(ctx->rcol_scratch);
     if (ctx->band_scratch) hipFree(ctx->band_scratch);
+    release_lbs_bound(ctx);
     if (ctx->gn_scratch) hipFree(ctx->gn_scratch);
     for (void *p : ctx->retired_scratch) hipFree(p);
     enc::release_encoder(ctx);
@@ -372,6 +373,26 @@ int avc_calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *ca
     return calculate_lbs(ctx, pts, n, cano_v, skin_w, nv, lbs, (hipStream_t)stream);
 }
 
+int avc_lbs_prepare(avc_ctx *ctx, const float *cano_v, int32_t nv, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && cano_v && nv >= 4, AVC_ERR_ARG, "avc_lbs_prepare: NULL argument or fewer than four vertices");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return lbs_prepare(ctx, cano_v, nv, (hipStream_t)stream);
+}
+
+int avc_calculate_lbs_bound(avc_ctx *ctx, const float *pts, int64_t n, const float *skin_w, float *lbs, avc_stream stream)
+{
+    AVC_REQUIRE(ctx && n >= 0 && (n == 0 || (pts && lbs)) && skin_w, AVC_ERR_ARG, "avc_calculate_lbs_bound: NULL argument");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return calculate_lbs_bound(ctx, pts, n, skin_w, lbs, (hipStream_t)stream);
+}
+
+int avc_lbs_bound_stats(avc_ctx *ctx, int64_t out[4])
+{
+    AVC_REQUIRE(ctx && out, AVC_ERR_ARG, "avc_lbs_bound_stats: NULL argument");
+    return lbs_bound_stats(ctx, out);
+}
+
 int avc_skinning(avc_ctx *ctx, const float *pts, const float *nrm, int64_t n, const float *lbs, const float *jm,
                  float *po, float *no, float *mo, avc_stream stream)
 {
@@ -428,6 +449,7 @@ int avc_set_option(avc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "enc_graph")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: enc_graph is 0 or 1"); ctx->opt.enc_graph = value; }
     else if (!strcmp(name, "enc_ksplit")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: enc_ksplit is 0 or 1"); ctx->opt.enc_ksplit = value; }
     else if (!strcmp(name, "mc_walk")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: mc_walk is 0 or 1"); ctx->opt.mc_walk = value; }
+    else if (!strcmp(name, "lbs_reach_mm")) { AVC_REQUIRE(value >= 0 && value <= 1000, AVC_ERR_ARG, "avc_set_option: lbs_reach_mm is 0 .. 1000"); ctx->opt.lbs_reach_mm = value; }
     else if (!strcmp(name, "enc_fork")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: enc_fork is 0 or 1"); ctx->opt.enc_fork = value; }
     else AVC_REQUIRE(false, AVC_ERR_ARG, "avc_set_option: unknown option '%s'", name);
     return AVC_OK;

@@ -1408,6 +1408,10 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
         AVC_HIP(ee);
         e->graph = g;
         AVC_HIP(hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
+    } else {
+        // plain launches on the caller's stream: the null-stream zero-fills of the ticket counters / part2 tables must have landed first -- a non-blocking
+        // stream does not wait for them, and a ticket that starts non-zero never reaches its count (the GroupNorm partials would never fold)
+        AVC_HIP(hipDeviceSynchronize());
     }
     return AVC_OK;
 }

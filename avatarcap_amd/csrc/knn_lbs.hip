@@ -20,6 +20,7 @@
 #include <string.h>
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "avcap_internal.h"
 
@@ -349,25 +350,61 @@ __device__ __forceinline__ bool knn_lane_ring1(const GridHdr *__restrict__ hdr, 
 
 struct GridView { const GridHdr *hdr; const int *start; const float4 *sorted; int lane_box; };   // hdr == nullptr: brute force
 
-// GRID = true: the grid search.  A coherent wave searches cooperatively (candidates through scalar loads, shared by the lanes); a wave whose
-// box-plus-one-ring holds more than `lane_box` cells lets every lane look around itself first, and only the lanes that stay unsettled (far from
-// every reference point) go on cooperatively.  (An exhaustive-scan escape for workgroups of scattered queries inside this kernel was tried:
-// its 32 KiB of LDS cut the occupancy and cost the common cases 50 %; uniformly scattered queries, which the frame loop never issues, are
-// the one case where the exhaustive scan would be faster, 4.4 against 8.2 ms for 1.9 M.)  GRID = false: the exhaustive LDS-tiled scan, for reference sets too small
-// for a grid (and AVC_KNN_BRUTE=1, which the tests use to hold the grid search to it bit for bit).
+// ---- per-cell candidate lists of a BOUND reference set (avc_lbs_prepare: the canonical SMPL vertices of a sequence) -------------------------------
+// The vertices a frame's marching-cubes output is skinned with are the same 6890 points for the whole sequence (main.py:335), and the queries lie on
+// the body's surface.  The space within the reach (avc_set_option "lbs_reach_mm") of the vertices is cut into cells of edge h (2 cm); for the cell with centre c the list holds every
+// vertex v with |v - c| <= d_K(c) + diag(cell) (+ a rounding allowance), d_K(c) the distance of c's K-th nearest vertex.  That list contains the K nearest
+// of EVERY point q of the cell: |q - c| <= diag / 2, so d_K(q) <= d_K(c) + diag / 2 (c's K nearest are that close to q), and a vertex among q's K nearest
+// -- ties included -- has |v - c| <= |v - q| + |q - c| <= d_K(c) + diag.  A lane therefore reads ONE range and scans some 40 - 100 candidates with the
+// same cand_d2 / (distance, index) insertion as the grid search: same bits as the exhaustive scan, without the dependent chain of 27 cell ranges of
+// knn_lane_ring1 (round 4: 317 us for the 190 k vertices of a band frame, three waves per SIMD waiting on memory).  Cells farther than the reach (avc_set_option "lbs_reach_mm", 140 by default) from
+// every vertex, and points outside the cells' box, have no list: their lanes go on with the grid search.
+struct CandView { const int *cstart; const float4 *cand; float ox, oy, oz, inv_h; int nx, ny, nz; };      // cstart == nullptr: no lists
+constexpr float LIST_CELL = 0.02f, LIST_MARGIN = 0.16f;       // (the reach -- how far from the vertices cells still get a list -- is Options::lbs_reach_mm)
+
+template <int K>
+__device__ __forceinline__ bool knn_lane_list(const CandView &cv, float qx, float qy, float qz, float (&bd)[K], int (&bi)[K])
+{
+    const float fx = (qx - cv.ox) * cv.inv_h, fy = (qy - cv.oy) * cv.inv_h, fz = (qz - cv.oz) * cv.inv_h;
+    const bool inside = fx >= 0.f && fy >= 0.f && fz >= 0.f && fx < (float)cv.nx && fy < (float)cv.ny && fz < (float)cv.nz;     // (false for NaN)
+    const int c = inside ? ((int)fx * cv.ny + (int)fy) * cv.nz + (int)fz : 0;
+    const int s = cv.cstart[c], e = inside ? cv.cstart[c + 1] : s;
+    // (Per lane: a wave-level rule -- lists only when every lane has one -- was tried for the dense stress frame, whose surface fills the volume; it left
+    // that frame's LBS unchanged and sent 86 % of a band frame's waves, each with a lane or two at the band's edge, back to the search: 165 -> 326 us.)
+    if (e <= s) return false;
+    for (int j = s; j < e; j += 4) {                       // four loads in flight; the tail repeats the last candidate (a listed index is skipped on insertion)
+        float4 c4[4]; float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c4[u] = cv.cand[min(j + u, e - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = cand_d2(c4[u], qx, qy, qz);
+        const float m = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+        if (m <= bd[K - 1]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) knn_insert_lex<K>(d[u], __float_as_int(c4[u].w), bd, bi);
+        }
+    }
+    return true;
+}
 template <int K, bool GRID>
 __device__ __forceinline__ void knn_any(const float *__restrict__ ref, int nr, const GridView &g, float qx, float qy, float qz,
-                                        float (&bd)[K], int (&bi)[K])
+                                        float (&bd)[K], int (&bi)[K], const CandView &cv = CandView{})
 {
     if constexpr (GRID) {
         const GridHdr *hdr = g.hdr;
-        const int cx = cell_coord(qx, hdr->ox, hdr->inv_h, hdr->nx), cy = cell_coord(qy, hdr->oy, hdr->inv_h, hdr->ny),
-                  cz = cell_coord(qz, hdr->oz, hdr->inv_h, hdr->nz);
-        const int bx = wave_maxi(cx) - wave_mini(cx) + 1, by = wave_maxi(cy) - wave_mini(cy) + 1, bz = wave_maxi(cz) - wave_mini(cz) + 1;
 #pragma unroll
         for (int k = 0; k < K; ++k) { bd[k] = __builtin_inff(); bi[k] = 0x7fffffff; }
         bool settled = false;
-        if ((bx + 2) * (by + 2) * (bz + 2) > g.lane_box) settled = knn_lane_ring1<K>(hdr, g.start, g.sorted, qx, qy, qz, bd, bi);
+        if (cv.cstart) {                                   // a bound reference set: one candidate list per lane (knn_lane_list)
+            settled = knn_lane_list<K>(cv, qx, qy, qz, bd, bi);
+            if (__all(settled)) return;
+        }
+        const int cx = cell_coord(qx, hdr->ox, hdr->inv_h, hdr->nx), cy = cell_coord(qy, hdr->oy, hdr->inv_h, hdr->ny),
+                  cz = cell_coord(qz, hdr->oz, hdr->inv_h, hdr->nz);
+        const int big = 0x3fffffff;                        // the lanes that still search shape the box
+        const int bx = wave_maxi(settled ? -big : cx) - wave_mini(settled ? big : cx) + 1, by = wave_maxi(settled ? -big : cy) - wave_mini(settled ? big : cy) + 1,
+                  bz = wave_maxi(settled ? -big : cz) - wave_mini(settled ? big : cz) + 1;
+        if ((long long)(bx + 2) * (by + 2) * (bz + 2) > g.lane_box && !settled) settled = knn_lane_ring1<K>(hdr, g.start, g.sorted, qx, qy, qz, bd, bi);
         if (__all(settled)) return;
         knn_grid_scan<K>(hdr, g.start, g.sorted, qx, qy, qz, bd, bi, settled);
     } else {
@@ -392,12 +429,12 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ q, i
 
 template <bool GRID>
 __global__ __launch_bounds__(256) void lbs_kernel(const float *__restrict__ pts, int64_t n, const float *__restrict__ cano_v,
-                                                  const float *__restrict__ skin_w, int nv, GridView g, float *__restrict__ lbs)
+                                                  const float *__restrict__ skin_w, int nv, GridView g, CandView cv, float *__restrict__ lbs)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t ii = i < n ? i : n - 1;
     float bd[4]; int bi[4];
-    knn_any<4, GRID>(cano_v, nv, g, pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2], bd, bi);
+    knn_any<4, GRID>(cano_v, nv, g, pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2], bd, bi, cv);
     if (i >= n) return;
     // weights = exp(-dists / (2 r^2)), r = 0.05; weights /= sum + 1e-16     (smpl_util.py:34-36)
     const float denom = (float)(2 * 0.05 * 0.05);
@@ -490,11 +527,82 @@ __global__ __launch_bounds__(256) void near_flag_kernel(const float *__restrict_
     out[i] = hit ? 0.0f : __builtin_inff();
 }
 
+// ---- building the candidate lists (once per bound reference set) ------------------------------------------------------------------------------
+struct CandGrid { float ox, oy, oz, h, inv_h; int nx, ny, nz; };
+
+// radius[c] = d_K(centre of cell c) + diag + allowance, or -1 when the centre is farther than `reach` from its K-th nearest vertex (no list)
+template <int K>
+__global__ __launch_bounds__(256) void cand_radius_kernel(CandGrid cg, const float *__restrict__ ref, int nr, GridView g, float reach, float *__restrict__ radius)
+{
+    const int ncell = cg.nx * cg.ny * cg.nz;
+    const int c = blockIdx.x * 256 + threadIdx.x, cc = min(c, ncell - 1);
+    const int x = cc / (cg.ny * cg.nz), y = (cc / cg.nz) % cg.ny, z = cc % cg.nz;
+    const float qx = cg.ox + ((float)x + 0.5f) * cg.h, qy = cg.oy + ((float)y + 0.5f) * cg.h, qz = cg.oz + ((float)z + 0.5f) * cg.h;
+    float bd[K]; int bi[K];
+    knn_any<K, true>(ref, nr, g, qx, qy, qz, bd, bi);
+    if (c >= ncell) return;
+    const float dk = sqrtf(bd[K - 1]);
+    // allowance: the rounding of the cell assignment and of the centre (a few ulp of coordinates of order 1) -- 1e-5 m is a thousand times that
+    radius[c] = dk <= reach ? (dk + 1.7320508f * cg.h) * 1.00001f + 1e-5f : -1.0f;
+}
+
+// FILL == false: count[c] = number of vertices within radius[c] of the centre of cell c;  FILL == true: writes them, in index order, at cstart[c]
+template <bool FILL>
+__global__ __launch_bounds__(256) void cand_list_kernel(CandGrid cg, const float *__restrict__ ref, int nr, const float *__restrict__ radius,
+                                                        int *__restrict__ count, const int *__restrict__ cstart, float4 *__restrict__ cand)
+{
+    __shared__ float4 lds[REF_TILE];
+    const int ncell = cg.nx * cg.ny * cg.nz;
+    const int c = blockIdx.x * 256 + threadIdx.x, cc = min(c, ncell - 1);
+    const int x = cc / (cg.ny * cg.nz), y = (cc / cg.nz) % cg.ny, z = cc % cg.nz;
+    const float qx = cg.ox + ((float)x + 0.5f) * cg.h, qy = cg.oy + ((float)y + 0.5f) * cg.h, qz = cg.oz + ((float)z + 0.5f) * cg.h;
+    const float r = c < ncell ? radius[cc] : -1.0f, r2 = r * r;
+    // a workgroup of far cells has nothing to list
+    if (!__syncthreads_or(r >= 0.f)) { if (!FILL && c < ncell) count[c] = 0; return; }
+    int n = 0, w = FILL && c < ncell ? cstart[cc] : 0;
+    for (int r0 = 0; r0 < nr; r0 += REF_TILE) {
+        const int cnt = min(REF_TILE, nr - r0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 256) lds[i] = make_float4(ref[(size_t)(r0 + i) * 3], ref[(size_t)(r0 + i) * 3 + 1], ref[(size_t)(r0 + i) * 3 + 2], __int_as_float(r0 + i));
+        __syncthreads();
+        if (r >= 0.f)
+            for (int i = 0; i < cnt; ++i) {
+                const float4 v = lds[i];
+                if (cand_d2(v, qx, qy, qz) <= r2) {
+                    if constexpr (FILL) cand[w++] = v;
+                    else ++n;
+                }
+            }
+    }
+    if (!FILL && c < ncell) count[c] = n;
+}
+
+// exclusive scan of count[0 .. n) in place into cstart[0 .. n] (one workgroup; once per sequence)
+__global__ __launch_bounds__(1024) void cand_scan_kernel(int *__restrict__ a, int n)
+{
+    __shared__ int part[1024];
+    const int per = (n + 1023) / 1024, lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += a[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int i = lo; i < hi; ++i) { const int v = a[i]; a[i] = run; run += v; }
+    if (threadIdx.x == 1023) a[n] = part[1023];
+}
+
 }  // namespace
 
 // Builds the grid over `ref` in the context's scratch (stream-ordered; no host synchronisation).
-static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, GridView &g, hipStream_t s)
+static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, GridView &g, hipStream_t s, void **scratch = nullptr, size_t *scratch_bytes = nullptr)
 {
+    if (!scratch) { scratch = &ctx->knn_scratch; scratch_bytes = &ctx->knn_scratch_bytes; }       // (a bound reference set keeps its grid in memory of its own)
     g = GridView{nullptr, nullptr, nullptr, 0};
     if (nr < GRID_MIN_REFS || ctx->opt.knn_search == 3) return AVC_OK;
     // cells per axis: about one occupied cell per few reference points for surface-like sets (6890 -> 32, 1e6 -> 128)
@@ -502,13 +610,13 @@ static int make_grid(avc_ctx *ctx, const float *ref, int32_t nr, int64_t nq, Gri
     const size_t ncell = (size_t)axis * axis * axis;
     const size_t cells = (ncell + 64 + 1) & ~(size_t)1;      // even: the two int arrays together stay a multiple of 16 bytes, so `sorted` (float4) is aligned
     const size_t bytes = 256 + 2 * sizeof(int) * cells + sizeof(float4) * ((size_t)nr + 8);
-    if (ctx->knn_scratch_bytes < bytes) {
-        if (ctx->knn_scratch) AVC_HIP(hipFree(ctx->knn_scratch));
-        ctx->knn_scratch = nullptr; ctx->knn_scratch_bytes = 0;
-        AVC_HIP(hipMalloc(&ctx->knn_scratch, bytes));
-        ctx->knn_scratch_bytes = bytes;
+    if (*scratch_bytes < bytes) {
+        if (*scratch) AVC_HIP(hipFree(*scratch));
+        *scratch = nullptr; *scratch_bytes = 0;
+        AVC_HIP(hipMalloc(scratch, bytes));
+        *scratch_bytes = bytes;
     }
-    char *base = static_cast<char *>(ctx->knn_scratch);
+    char *base = static_cast<char *>(*scratch);
     GridHdr *hdr = reinterpret_cast<GridHdr *>(base);
     unsigned *keys = reinterpret_cast<unsigned *>(base + 128);
     int *start = reinterpret_cast<int *>(base + 256);
@@ -563,9 +671,110 @@ int calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v
     GridView g;
     if (int rc = make_grid(ctx, cano_v, nv, n, g, s)) return rc;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (g.hdr) hipLaunchKernelGGL(lbs_kernel<true>, grid, block, 0, s, pts, n, cano_v, skin_w, nv, g, lbs);
-    else hipLaunchKernelGGL(lbs_kernel<false>, grid, block, 0, s, pts, n, cano_v, skin_w, nv, g, lbs);
+    if (g.hdr) hipLaunchKernelGGL(lbs_kernel<true>, grid, block, 0, s, pts, n, cano_v, skin_w, nv, g, CandView{}, lbs);
+    else hipLaunchKernelGGL(lbs_kernel<false>, grid, block, 0, s, pts, n, cano_v, skin_w, nv, g, CandView{}, lbs);
     AVC_HIP(hipGetLastError());
+    return AVC_OK;
+}
+
+// ---- a bound reference set: SmplUtil.set_cano_smpl_vertices (utils/smpl_util.py:21) -----------------------------------------------------------------
+struct LbsBound {
+    float *ref = nullptr; int32_t nr = 0;                 // the context's own copy of the vertices (nr x 3)
+    void *grid_mem = nullptr; size_t grid_bytes = 0;      // the uniform grid over them (GridView: what lanes without a list search)
+    GridView grid{nullptr, nullptr, nullptr, 0};
+    void *list_mem = nullptr; size_t list_bytes = 0;      // [radius (ncell floats) | cstart (ncell + 1 ints)]
+    float4 *cand = nullptr; size_t cand_cap = 0;
+    CandView cv{};
+    int64_t ncand = 0; int ncell = 0, nlisted = 0;
+};
+
+void release_lbs_bound(avc_ctx *ctx)
+{
+    LbsBound *b = static_cast<LbsBound *>(ctx->lbs_bound);
+    if (!b) return;
+    if (b->ref) hipFree(b->ref);
+    if (b->grid_mem) hipFree(b->grid_mem);
+    if (b->list_mem) hipFree(b->list_mem);
+    if (b->cand) hipFree(b->cand);
+    delete b;
+    ctx->lbs_bound = nullptr;
+}
+
+int lbs_prepare(avc_ctx *ctx, const float *cano_v, int32_t nv, hipStream_t s)
+{
+    if (!ctx->lbs_bound) ctx->lbs_bound = new LbsBound();
+    LbsBound *b = static_cast<LbsBound *>(ctx->lbs_bound);
+    b->cv = CandView{}; b->grid = GridView{nullptr, nullptr, nullptr, 0};
+    if (b->nr < nv) { if (b->ref) AVC_HIP(hipFree(b->ref)); b->ref = nullptr; AVC_HIP(hipMalloc((void **)&b->ref, sizeof(float) * 3 * (size_t)nv)); }
+    b->nr = nv;
+    std::vector<float> host((size_t)nv * 3);
+    AVC_HIP(hipMemcpyAsync(b->ref, cano_v, sizeof(float) * 3 * (size_t)nv, hipMemcpyDeviceToDevice, s));
+    AVC_HIP(hipMemcpyAsync(host.data(), cano_v, sizeof(float) * 3 * (size_t)nv, hipMemcpyDeviceToHost, s));
+    AVC_HIP(hipStreamSynchronize(s));                     // once per sequence: the box of the cells is sized on the host
+    if (int rc = make_grid(ctx, b->ref, nv, nv, b->grid, s, &b->grid_mem, &b->grid_bytes)) return rc;
+    if (!b->grid.hdr || ctx->opt.knn_search != 0 || ctx->opt.lbs_reach_mm <= 0) return AVC_OK;      // a handful of vertices, or a forced search path (tests): no lists, the generic search serves
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int32_t i = 0; i < nv; ++i)
+        for (int a = 0; a < 3; ++a) { const float v = host[(size_t)i * 3 + a]; if (v < mn[a]) mn[a] = v; if (v > mx[a]) mx[a] = v; }
+    for (int a = 0; a < 3; ++a) AVC_REQUIRE(std::isfinite(mn[a]) && std::isfinite(mx[a]), AVC_ERR_ARG, "avc_lbs_prepare: the vertices are not finite");
+    float h = LIST_CELL;
+    const float reach = 1e-3f * (float)ctx->opt.lbs_reach_mm, margin = std::max(LIST_MARGIN, reach + 0.04f);
+    CandGrid cg{};
+    for (;; h *= 1.26f) {                                 // (a reference set far larger than a body: coarser cells rather than more than 4 M of them)
+        cg = CandGrid{mn[0] - margin, mn[1] - margin, mn[2] - margin, h, 1.0f / h,
+                      (int)std::ceil((mx[0] - mn[0] + 2 * margin) / h), (int)std::ceil((mx[1] - mn[1] + 2 * margin) / h), (int)std::ceil((mx[2] - mn[2] + 2 * margin) / h)};
+        if ((double)cg.nx * cg.ny * cg.nz <= 4.0e6) break;
+    }
+    const int ncell = cg.nx * cg.ny * cg.nz;
+    const size_t lbytes = sizeof(float) * ((size_t)ncell + 4) + sizeof(int) * ((size_t)ncell + 4);
+    if (b->list_bytes < lbytes) {
+        if (b->list_mem) AVC_HIP(hipFree(b->list_mem));
+        b->list_mem = nullptr; b->list_bytes = 0;
+        AVC_HIP(hipMalloc(&b->list_mem, lbytes));
+        b->list_bytes = lbytes;
+    }
+    float *radius = static_cast<float *>(b->list_mem);
+    int *cstart = reinterpret_cast<int *>(radius + ncell + 4);
+    const dim3 blocks((unsigned)((ncell + 255) / 256)), threads(256);
+    hipLaunchKernelGGL(cand_radius_kernel<4>, blocks, threads, 0, s, cg, b->ref, nv, b->grid, reach, radius);
+    hipLaunchKernelGGL(cand_list_kernel<false>, blocks, threads, 0, s, cg, b->ref, nv, radius, cstart, (const int *)nullptr, (float4 *)nullptr);
+    hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(1024), 0, s, cstart, ncell);
+    int total = 0;
+    AVC_HIP(hipMemcpyAsync(&total, cstart + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
+    AVC_HIP(hipStreamSynchronize(s));
+    AVC_HIP(hipGetLastError());
+    if (b->cand_cap < (size_t)total + 8) {
+        if (b->cand) AVC_HIP(hipFree(b->cand));
+        b->cand = nullptr; b->cand_cap = 0;
+        AVC_HIP(hipMalloc((void **)&b->cand, sizeof(float4) * ((size_t)total + 8)));
+        b->cand_cap = (size_t)total + 8;
+    }
+    hipLaunchKernelGGL(cand_list_kernel<true>, blocks, threads, 0, s, cg, b->ref, nv, radius, (int *)nullptr, cstart, b->cand);
+    AVC_HIP(hipGetLastError());
+    b->cv = CandView{cstart, b->cand, cg.ox, cg.oy, cg.oz, cg.inv_h, cg.nx, cg.ny, cg.nz};
+    b->ncand = total; b->ncell = ncell;
+    return AVC_OK;
+}
+
+int calculate_lbs_bound(avc_ctx *ctx, const float *pts, int64_t n, const float *skin_w, float *lbs, hipStream_t s)
+{
+    LbsBound *b = static_cast<LbsBound *>(ctx->lbs_bound);
+    AVC_REQUIRE(b && b->nr >= 4, AVC_ERR_STATE, "Canonical smpl vertices are invalid!");      // smpl_util.py:31 (avc_lbs_prepare was not called)
+    if (n == 0) return AVC_OK;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    GridView g = b->grid;
+    if (g.hdr) g.lane_box = ctx->opt.knn_search == 1 ? 0 : (ctx->opt.knn_search == 2 ? 0x7fffffff : LANE_BOX);
+    const bool brute = ctx->opt.knn_search == 3 || !g.hdr;
+    if (!brute) hipLaunchKernelGGL(lbs_kernel<true>, grid, block, 0, s, pts, n, b->ref, skin_w, b->nr, g, ctx->opt.knn_search == 0 ? b->cv : CandView{}, lbs);
+    else hipLaunchKernelGGL(lbs_kernel<false>, grid, block, 0, s, pts, n, b->ref, skin_w, b->nr, g, CandView{}, lbs);
+    AVC_HIP(hipGetLastError());
+    return AVC_OK;
+}
+
+int lbs_bound_stats(avc_ctx *ctx, int64_t out[4])
+{
+    LbsBound *b = static_cast<LbsBound *>(ctx->lbs_bound);
+    out[0] = b ? b->nr : 0; out[1] = b ? b->ncell : 0; out[2] = b ? b->ncand : 0; out[3] = b && b->cv.cstart ? 1 : 0;
     return AVC_OK;
 }
 

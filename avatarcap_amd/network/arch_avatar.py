@@ -278,13 +278,21 @@ class NerfRenderer:
                     'depth_map': depth_map.view(n_batch, n_pixel), 'raw': raw.view(n_batch, -1, 4)})
         return ret
 
-    def render(self, batch, pts_space='posed', near_dist=0.05, far_dist=0.05, chunk=1 << 16):
+    def render(self, batch, pts_space='posed', near_dist=0.05, far_dist=0.05, chunk=1 << 16, want_raw=False):
         """batch keys: ray_o, ray_d (B,P,3), near, far, occupancy, depth (B,P).  The reference walks the rays 2048 at a time (:330); the fused kernel
-        has no activation tensors to bound, so the chunk is only a cap on the per-sample buffers.
+        has no activation tensors to bound, so `chunk` only caps the per-sample buffers of the posed / temp branches (the device path of 'cano' sizes its
+        own scratch and ignores it).
         pts_space == 'cano' (what main.py:475 runs for the vertex colours): `avc_render_rays_cano` -- sample points, the fused query with the colour
-        head, the near / inside masks, alpha and raw2outputs on the device, nothing per sample in PyTorch.  Returns rgb_map, acc_map, depth_map, raw."""
+        head, the near / inside masks, alpha and raw2outputs on the device, nothing per sample in PyTorch.  It returns rgb_map, acc_map, depth_map and, with
+        want_raw=True, 'raw' (B, P*S, 4); the per-sample 'occ' / 'nonrigid_offset' the reference's dict also carries (:311-318) are not materialised --
+        asking the returned dict for them raises a KeyError that says so (GeoTexAvatar.forward returns them).  batch['near'] / batch['far'] are updated in
+        place for the rays with depth > 1e-6, as the reference does (:287-290)."""
         if pts_space == 'cano' and batch['ray_o'].is_cuda:
-            return self._render_cano(batch, near_dist, far_dist)
+            out = self._render_cano(batch, near_dist, far_dist, want_raw)
+            valid = batch['depth'] > 1e-6                                                  # the reference's side effect on the caller's tensors (:288-290)
+            batch['near'][valid] = batch['depth'][valid] - near_dist
+            batch['far'][valid] = batch['depth'][valid] + far_dist
+            return out
         n_pixel = batch['ray_o'].shape[1]
         rets = []
         for i in range(0, n_pixel, chunk):
@@ -320,10 +328,22 @@ class NerfRenderer:
                 t_vals.data_ptr(), P, S, _lib.f3(batch['cano_smpl_center'][b]), _lib.f3(batch['cano_bounds'][b]), _lib.dev_ptr(smpl_v, name='cano_smpl_vertices'),
                 smpl_v.shape[0], 1 if config.if_type == 'occupancy' else 0, rgb[b].data_ptr(), acc[b].data_ptr(), dep[b].data_ptr(), None, None,
                 raw[b].data_ptr() if want_raw else None, _lib.stream_ptr(dev)))
-        out = {'rgb_map': rgb, 'acc_map': acc, 'depth_map': dep}
+        out = _DeviceRenderDict({'rgb_map': rgb, 'acc_map': acc, 'depth_map': dep})
         if want_raw:
             out['raw'] = raw
         return out
+
+
+class _DeviceRenderDict(dict):
+    """What NerfRenderer.render(pts_space='cano') returns on the device: a dict whose missing reference keys explain themselves."""
+
+    def __missing__(self, key):
+        if key == 'raw':
+            raise KeyError("'raw': the device path of NerfRenderer.render(pts_space='cano') materialises it only with want_raw=True")
+        if key in ('occ', 'nonrigid_offset'):
+            raise KeyError(f"'{key}': not materialised by the device path of NerfRenderer.render(pts_space='cano') (per-sample tensors of the fused kernel); "
+                           "GeoTexAvatar.forward(..., pts_space='cano') returns it")
+        raise KeyError(key)
 
 
 class OccupancyNet:

@@ -217,7 +217,11 @@ class FramePipeline:
         front_image, _ = canonicalize_normal_map_device(avatar['cano_v'], avatar['live_v'], avatar['f'], observed_normal, avatar['vert_mats'],
                                                         np.asarray(w2c_RT, np.float32), cam['fx'], cam['fy'], cam['cx'], cam['cy'], center)   # :413-415
         if integrate_manner == 'merge':
-            neck_vert = smpl_util.cano_smpl_vertices[3068].cpu().numpy() - np.asarray(center, np.float32)                               # :418
+            cv = smpl_util.cano_smpl_vertices
+            key = (cv.data_ptr(), cv._version)
+            if getattr(self, '_neck', (None,))[0] != key:          # per sequence, not per frame: the read drains the stream
+                self._neck = (key, cv[3068].cpu().numpy())
+            neck_vert = self._neck[1] - np.asarray(center, np.float32)                                                                  # :418
             neck_y = int((1. - neck_vert[1]) / 2. * 512)                                                                                # :419
             neck_x = int((neck_vert[0] - 1) / 2. * 512)                                                                                 # :420 (negative: wraps, like the reference's slice)
             front = merge_normal_images_device(front_avatar, front_image, iter_num, (neck_x, neck_y))                                   # :421

@@ -30,7 +30,22 @@ class SmplUtil:
         self.smpl_skinning_weights = w.to(torch.float32).to(config.device).contiguous()
 
     def set_cano_smpl_vertices(self, cano_smpl_vertices: torch.Tensor):
+        """smpl_util.py:21.  On the HIP device the vertices are also BOUND to the context (avc_lbs_prepare: their search grid and the per-cell candidate
+        lists are built once per sequence, not once per calculate_lbs call)."""
         self.cano_smpl_vertices = cano_smpl_vertices.to(torch.float32).to(config.device).contiguous()
+        if self.cano_smpl_vertices.is_cuda:
+            self._bind(self.cano_smpl_vertices.device)
+
+    def _bind(self, device):
+        """The device context holds ONE bound vertex set; whoever calculates next checks that it is still its own (another SmplUtil, or these vertices
+        edited in place, rebinds)."""
+        v = self.cano_smpl_vertices
+        key = (id(self), v.data_ptr(), v._version)
+        ctx = _lib.ctx(device)
+        if not _lib.owns(ctx, 'lbs_bound', key):
+            _lib.check(_lib.lib().avc_lbs_prepare(ctx, _lib.dev_ptr(v, name='cano_smpl_vertices'), v.shape[0], _lib.stream_ptr(device)))
+            _lib.set_owner(ctx, 'lbs_bound', key)
+        return ctx
 
     # pytorch3d.ops.knn_points stand-in (squared distances ascending, indices int64)
     def knn_points(self, p1, p2, K=1):
@@ -62,7 +77,17 @@ class SmplUtil:
         """(B,N,3) -> (B,N,24): blend weights of points around canonical SMPL (smpl_util.py:24-39)."""
         if self.cano_smpl_vertices is None:
             raise ValueError('Canonical smpl vertices are invalid!')       # smpl_util.py:30-31
-        return self._lbs(points, self.cano_smpl_vertices)
+        v = self.cano_smpl_vertices
+        if points.is_cuda and v.device == points.device and v.dim() == 2 and v.shape[0] >= 4 and self.smpl_skinning_weights is not None:
+            ctx = self._bind(points.device)
+            B, N, _ = points.shape
+            points = points.contiguous()
+            lbs = torch.empty((B, N, 24), dtype=torch.float32, device=points.device)
+            for b in range(B):
+                _lib.check(_lib.lib().avc_calculate_lbs_bound(ctx, _lib.dev_ptr(points[b], name='points'), N, _lib.dev_ptr(self.smpl_skinning_weights, name='skin_w'),
+                                                              lbs[b].data_ptr(), _lib.stream_ptr(points.device)))
+            return lbs
+        return self._lbs(points, v)
 
     def calculate_lbs2(self, points, smpl_v):
         """Same against given vertices (B,N',3) (smpl_util.py:41-56)."""

@@ -100,56 +100,120 @@ def build_pipeline(res, valid, n_frames, device):
     return FramePipeline(net, ds), sd
 
 
-def cpu_baseline(pipe, sd, frame_out, res, budget_s=24.0):
-    """The CPU restatements of oracle/ on the host cores, bounded sample, scaled to one dense frame: the query on stock
-    PyTorch CPU ops with identical weights and all cores (oracle/torch_cpu.py -- the closest thing to the reference's own
-    CPU path that can travel; its NumPy twin is timed for information), C marching cubes, torch-CPU KNN-4 LBS."""
+def _cpu_info():
+    """(model name, physical cores, sockets, logical CPUs this process may use) of the host, from /proc/cpuinfo ('report core count, model name')."""
+    model, cores, socks = 'unknown', set(), set()
+    try:
+        phys = core = None
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'model name':
+                model = v
+            elif k == 'physical id':
+                phys = v; socks.add(v)
+            elif k == 'core id':
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    return model, (len(cores) or avail), (len(socks) or 1), avail
+
+
+def cpu_baseline(pipe, sd, frame_in, frame_out, res, budget_s=12.0):
+    """The CPU restatements of oracle/ on the host cores, beside the GPU number -- a reported baseline, not a target:
+      * BASELINE configs[0] (64^3 grid) IN FULL, 5 repeats, median: U-Net on the frame's 256^2 position map, the query of all 262,144 grid points, marching
+        cubes, Sobel normals + trilinear fetch at the vertices, KNN-4 LBS + skinning -- stock PyTorch CPU ops with identical weights (oracle/torch_cpu.py) and
+        the C marching cubes (oracle/mc_oracle.c);
+      * the dense 256^3 frame of `value`: the same pieces, the query on >= 4 chunks of 262,144 points scaled to the 64 chunks of the grid (a full CPU frame is
+        minutes), marching cubes and normals on the full volume the GPU frame produced (checked elsewhere to be the oracle's), LBS on a vertex sample."""
     from oracle import avatarcap_oracle as orc, mc as omc, torch_cpu
     from avatarcap_amd import synthetic as syn
+    from avatarcap_amd.grid import generate_volume_points_np
     ds = pipe.ds
     N = res ** 3
-    fmap = pipe.network.warping_field.pose_feat_map[0].cpu().numpy()
-    pts = ds.infer_pts[:: max(1, ds.infer_pts.shape[0] // (1 << 20))].cpu().numpy()
-    # -- stock PyTorch on the CPU, every core
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    model, phys, socks, avail = _cpu_info()
     tsd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items() if v.dtype == np.float32}
-    tp, tf, tc = torch.from_numpy(pts), torch.from_numpy(fmap), torch.from_numpy(np.asarray(ds.cano_smpl_center, np.float32))
+    tc = torch.from_numpy(np.asarray(ds.cano_smpl_center, np.float32))
+    tv, tw = torch.from_numpy(ds.body['cano_smpl_v']), torch.from_numpy(ds.body['skin_weights'])
+    pos_map = frame_in['smpl_pos_map'].detach().cpu().float()
+    jm = frame_in['cano2live_jnt_mats'][0].detach().cpu().numpy()
+    bounds = np.asarray(ds.cano_bounds, np.float32)
+
+    def timed(fn):
+        t = time.perf_counter(); r = fn(); return time.perf_counter() - t, r
+
+    # -- thread count: more threads is not always faster here; pick the best of a sweep that includes the physical core count
+    pts_all = ds.infer_pts.cpu()
+    tf = torch_cpu.unet7ds(tsd, pos_map)[0]                                          # (64,256,256): the pose feature map, on the CPU
     n0 = 65536
-    best = None                                                                      # more threads is not always faster here: pick the best count
-    for th in sorted({min(c, avail) for c in (8, 16, 32, 64, 128, avail)}):
+    best = None
+    for th in sorted({min(c, avail) for c in (8, 16, 32, 64, phys, avail)}):
         torch.set_num_threads(th)
-        torch_cpu.occupancy_query(tp[:8192], tf, tc, tsd)                            # warm the thread pool / oneDNN
-        t = time.perf_counter(); torch_cpu.occupancy_query(tp[:n0], tf, tc, tsd); dt_ = time.perf_counter() - t
+        torch_cpu.occupancy_query(pts_all[:8192], tf, tc, tsd)                       # warm the thread pool / oneDNN
+        dt_, _ = timed(lambda: torch_cpu.occupancy_query(pts_all[:n0], tf, tc, tsd))
         if best is None or dt_ < best[0]:
             best = (dt_, th)
-        if dt_ > 3.0:
+        if dt_ > 2.0:
             break
-    t0, threads = best
+    threads = best[1]
     torch.set_num_threads(threads)
-    n1 = int(min(len(pts), max(n0, (budget_s * 0.5) / (t0 / n0))))
-    t = time.perf_counter(); torch_cpu.occupancy_query(tp[:n1], tf, tc, tsd); t1 = time.perf_counter() - t
-    per_pt = t1 / n1
-    # -- the NumPy oracle, for information
+
+    def mesh_stage(vol, r3, iso=0.0):
+        """marching cubes (C, one thread) + normals (torch) + LBS + skinning of what comes out; -> seconds by piece, vertex count"""
+        voxel = ((bounds[1] - bounds[0]) / np.asarray(r3, np.float32)).astype(np.float32)
+        t_mc, (v, f) = timed(lambda: omc.marching_cubes(np.ascontiguousarray(vol.reshape(r3)), iso, voxel))
+        V = v.shape[0]
+        if V == 0:
+            return {'mc': t_mc, 'normals': 0.0, 'lbs': 0.0}, 0
+        verts = (v + bounds[0] + np.float32(0.5) * voxel).astype(np.float32)
+        gridp = (2 * (verts - bounds[0]) / (bounds[1] - bounds[0]) - 1.0).astype(np.float32)
+        t_n, _ = timed(lambda: torch_cpu.vertex_normals(torch.from_numpy(np.ascontiguousarray(vol.reshape(r3))), voxel, torch.from_numpy(gridp)))
+        nv = min(V, 65536)
+        vv = verts[:: max(1, V // nv)][:nv]
+        t_l, _ = timed(lambda: orc.skinning(vv, torch_cpu.calculate_lbs(torch.from_numpy(vv), tv, tw).numpy(), jm))
+        return {'mc': t_mc, 'normals': t_n, 'lbs': t_l * V / len(vv)}, V
+
+    # -- (A) 64^3 in full, 5 repeats, median
+    r64 = [64, 64, 64]
+    p64 = torch.from_numpy(generate_volume_points_np(bounds, r64))
+    runs = []
+    for _ in range(5):
+        t_u, fm = timed(lambda: torch_cpu.unet7ds(tsd, pos_map)[0])
+        t_q, (occ, _) = timed(lambda: torch_cpu.occupancy_query(p64, fm, tc, tsd))
+        st, V64 = mesh_stage(occ[:, 0].numpy(), r64)
+        runs.append({'unet': t_u, 'query': t_q, **st})
+        if sum(sum(r.values()) for r in runs) > 3 * budget_s:                        # a very slow host: fewer repeats, said so below
+            break
+    tot64 = sorted(sum(r.values()) for r in runs)
+    med64 = tot64[len(tot64) // 2]
+    rmed = sorted(runs, key=lambda r: sum(r.values()))[len(runs) // 2]
+    # -- (B) the dense frame of `value`
+    per0 = best[0] / n0
+    n1 = int(min(N, max(4 * 262144, (budget_s / max(per0, 1e-9)) // 262144 * 262144)))
+    t_q, _ = timed(lambda: torch_cpu.occupancy_query(pts_all[:: N // n1][:n1], tf, tc, tsd))
+    per_pt = t_q / n1
+    t_u, _ = timed(lambda: torch_cpu.unet7ds(tsd, pos_map))
+    st, V = mesh_stage(frame_out['occ_volume'].reshape(res, res, res).cpu().numpy(), [res] * 3)
+    frame_s = t_u + per_pt * N + st['mc'] + st['normals'] + st['lbs']
     m0 = 16384
-    t = time.perf_counter(); orc.occupancy_query(pts[:m0], fmap, ds.cano_smpl_center, sd, dt=np.float32); per_pt_np = (time.perf_counter() - t) / m0
-    vol = frame_out['occ_volume'].reshape(res, res, res).cpu().numpy()
-    voxel = ((ds.cano_bounds[1] - ds.cano_bounds[0]) / res).astype(np.float32)
-    t = time.perf_counter(); v, f = omc.marching_cubes(vol, 0.0, voxel); t_mc = time.perf_counter() - t
-    V = max(1, v.shape[0])
-    nv = min(V, 65536)
-    vv = (v[:: max(1, V // nv)][:nv] + ds.cano_bounds[0] + 0.5 * voxel).astype(np.float32)
-    tv, tw = torch.from_numpy(ds.body['cano_smpl_v']), torch.from_numpy(ds.body['skin_weights'])
-    torch_cpu.calculate_lbs(torch.from_numpy(vv[:4096]), tv, tw)
-    t = time.perf_counter()
-    lbs = torch_cpu.calculate_lbs(torch.from_numpy(vv), tv, tw).numpy()
-    orc.skinning(vv, lbs, syn.random_pose_jnt_mats(1))
-    t_lbs = (time.perf_counter() - t) / len(vv)
-    frame_s = per_pt * N + t_mc + t_lbs * V
+    t_np, _ = timed(lambda: orc.occupancy_query(pts_all[:m0].numpy(), tf.numpy(), ds.cano_smpl_center, sd, dt=np.float32))
     return {'value': 1.0 / frame_s, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
-            'sample': f'stock PyTorch-CPU restatement (oracle/torch_cpu.py, {threads} threads): query {n1} of {N} grid points ({t1:.1f} s, '
-                      f'{per_pt*1e6:.2f} us/pt) scaled to {N}; C marching cubes on the full {res}^3 volume ({t_mc:.2f} s, 1 thread); torch-CPU KNN-4 LBS on '
-                      f'{len(vv)} of {V} vertices ({t_lbs*1e6:.1f} us/vertex) scaled; Sobel normals and the 10 GFLOP U-Net not included',
-            'seconds_per_frame': frame_s, 'numpy_port_us_per_point': per_pt_np * 1e6, 'torch_cpu_us_per_point': per_pt * 1e6}
+            'cpu_model': model, 'physical_cores': phys, 'sockets': socks, 'logical_cpus_available': avail,
+            'sample': f'stock PyTorch-CPU restatement (oracle/torch_cpu.py) on {threads} threads of {phys} physical cores ({model}): U-Net in full ({t_u:.2f} s); query '
+                      f'{n1} of {N} grid points = {n1 // 262144} chunks of 262,144 ({t_q:.1f} s, {per_pt*1e6:.2f} us/pt) scaled to {N}; C marching cubes on the full '
+                      f'{res}^3 volume ({st["mc"]:.2f} s, 1 thread); Sobel normals (torch conv3d) + fetch at the {V} vertices ({st["normals"]:.2f} s); torch-CPU KNN-4 '
+                      f'LBS + skinning on a 65,536-vertex sample scaled to {V} ({st["lbs"]:.2f} s)',
+            'seconds_per_frame': frame_s,
+            'seconds_per_frame_by_piece': {'unet7ds': t_u, 'query (scaled)': per_pt * N, 'marching cubes': st['mc'], 'normals': st['normals'], 'lbs + skinning (scaled)': st['lbs']},
+            'config0_64cube_full': {'workload': 'BASELINE configs[0]: 64^3 grid (262,144 points), one frame in full on the CPU: U-Net, query, marching cubes, normals, LBS',
+                                    'repeats': len(runs), 'median_seconds_per_frame': med64, 'frames_per_s': 1.0 / med64, 'all_seconds': tot64,
+                                    'median_run_by_piece': rmed, 'vertices': V64},
+            'numpy_port_us_per_point': t_np / m0 * 1e6, 'torch_cpu_us_per_point': per_pt * 1e6}
 
 
 def _free_port():
@@ -415,7 +479,7 @@ def main():
             except Exception as e:       # informational leg only
                 line['masked'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(pipe, sd, out, res)
+            line['cpu_baseline'] = cpu_baseline(pipe, sd, my[-1], out, res)
         if world == 1 and not args.no_configs:
             del pipe, my
             torch.cuda.empty_cache()

@@ -334,6 +334,18 @@ int avc_knn(avc_ctx *ctx, const float *query_dev, int64_t nq, const float *ref_d
 int avc_calculate_lbs(avc_ctx *ctx, const float *pts_dev, int64_t n, const float *cano_v_dev,
                       const float *skin_w_dev, int32_t nv, float *lbs_out_dev, avc_stream stream);
 
+/* SmplUtil.set_cano_smpl_vertices (utils/smpl_util.py:21; main.py:335: once per sequence) and calculate_lbs against what it set (:24-39).
+ * avc_lbs_prepare copies the (nv,3) vertices into the context and builds, once: the uniform grid of the KNN search and, for every 2 cm cell of the space
+ * within 0.14 m of the vertices (avc_set_option "lbs_reach_mm"), the list of the vertices that can be among the four nearest of ANY point of the cell (all v with
+ * |v - centre| <= d_4(centre) + cell diagonal).  avc_calculate_lbs_bound then reads one list per point instead of searching: bit-identical to
+ * avc_calculate_lbs on the same vertices (same squared distances, same (distance, index) order; points without a list -- farther than that from the body,
+ * outside the cells' box -- take the grid search), and without the per-call grid construction.  Host-synchronous (sizes its tables); a second call replaces
+ * the first.  avc_calculate_lbs_bound before avc_lbs_prepare -> AVC_ERR_STATE ("Canonical smpl vertices are invalid!", smpl_util.py:31).
+ * avc_lbs_bound_stats: out = {vertices bound, cells, list entries, 1 if lists exist}. */
+int avc_lbs_prepare(avc_ctx *ctx, const float *cano_v_dev, int32_t nv, avc_stream stream);
+int avc_calculate_lbs_bound(avc_ctx *ctx, const float *pts_dev, int64_t n, const float *skin_w_dev, float *lbs_out_dev, avc_stream stream);
+int avc_lbs_bound_stats(avc_ctx *ctx, int64_t out[4]);
+
 /* SmplUtil.skinning / skinning_normal (utils/smpl_util.py:58-81): M = sum_j lbs_j * J_j;
  * p' = M[:3,:3] p + M[:3,3]; n' = M[:3,:3] n (no renormalisation).
  * jnt_mats_dev (24,4,4).  nrm_dev/nrm_out_dev/mats_out_dev may be NULL.  mats_out_dev (n,4,4). */
@@ -358,6 +370,9 @@ int avc_timing_read_cycles(avc_ctx *ctx, int which, double *avg_cycles_out, int6
  *                                    point queries instead of ~1e-6 from them
  *   "mlp_blocks"   0 (default: one persistent workgroup per CU) | n
  *   "knn_search"   0 (default: per wave) | 1 per-lane grid search | 2 cooperative grid search | 3 exhaustive scan -- all four return the same bits
+ *                  (with 1, 2 or 3 avc_calculate_lbs_bound leaves its candidate lists alone and searches that way too)
+ *   "lbs_reach_mm" 140 (default) | 0 .. 1000   read by avc_lbs_prepare: cells whose centre lies within this distance of its 4th nearest bound vertex
+ *                  get a candidate list (0: no lists, avc_calculate_lbs_bound searches the grid); same bits whatever the value
  *   "fusion_graph" 1 (default: the fusion iterations replay a hipGraph) | 0 plain launches
  *   "enc_graph"    1 (default: avc_hgfilter_forward replays a hipGraph) | 0 plain launches -- same kernels, same bits
  *   "enc_ksplit"   1 (default: a convolution that would run on fewer than half the CUs splits its input channels over several workgroups per

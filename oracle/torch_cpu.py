@@ -79,3 +79,58 @@ def calculate_lbs(points, cano_smpl_v, skin_weights, chunk=16384):
         w = w / (w.sum(-1, keepdim=True) + 1e-16)
         out.append((skin_weights[idx] * w[..., None]).sum(-2))
     return torch.cat(out)
+
+
+@torch.no_grad()
+def unet7ds(sd, x, prefix='warping_field.unet'):
+    """UnetNoCond7DS.forward (network/unets.py:201-229; blocks :10-60) over the reference-shaped state dict: x (1,6,H,W) -> (1,64,H,W).
+    Down blocks: LeakyReLU(0.2) before every convolution but the first, Conv2d(k4, s2, p1, no bias), BatchNorm2d(affine=False, eval) on conv2..6
+    (:175-181).  Up blocks: ReLU, ConvTranspose2d(k4, s2, p1, no bias) + BatchNorm (upconv1..3) or bilinear x2 (align_corners=False) + Conv2d(k3, p1)
+    (upconvC5..C7; C7 without BatchNorm), then the skip concatenation (:42-60).  upconv3 is applied twice and upconv4 never (:213-214).
+    (The reference's in-place LeakyReLU also rewrites the tensors it later concatenates as skips; every consumer of a skip applies ReLU first and
+    relu(leaky_relu(d)) == relu(d), so the outputs are the same.)"""
+    def bn(name, y):
+        return F.batch_norm(y, sd[f'{prefix}.{name}.bn.running_mean'], sd[f'{prefix}.{name}.bn.running_var'], None, None, False, 0.0, 1e-5)
+
+    def down(i, y):
+        if i > 1:
+            y = F.leaky_relu(y, 0.2)
+        y = F.conv2d(y, sd[f'{prefix}.conv{i}.conv.weight'], None, stride=2, padding=1)
+        return bn(f'conv{i}', y) if 2 <= i <= 6 else y
+
+    def up(name, y, skip=None, transposed=True, norm=True):
+        y = F.relu(y)
+        if transposed:
+            y = F.conv_transpose2d(y, sd[f'{prefix}.{name}.up.weight'], None, stride=2, padding=1)
+        else:
+            y = F.interpolate(y, scale_factor=2, mode='bilinear', align_corners=False)
+            y = F.conv2d(y, sd[f'{prefix}.{name}.up.1.weight'], sd[f'{prefix}.{name}.up.1.bias'], padding=1)
+        if norm:
+            y = bn(name, y)
+        return y if skip is None else torch.cat([y, skip], 1)
+
+    d = [x]
+    for i in range(1, 8):
+        d.append(down(i, d[-1]))
+    u = up('upconv1', d[7], d[6])
+    u = up('upconv2', u, d[5])
+    u = up('upconv3', u, d[4])
+    u = up('upconv3', u, d[3])
+    u = up('upconvC5', u, d[2], transposed=False)
+    u = up('upconvC6', u, d[1], transposed=False)
+    return up('upconvC7', u, None, transposed=False, norm=False)
+
+
+@torch.no_grad()
+def vertex_normals(vol, voxel, grid_pts):
+    """utils/recon_util.py:9-48 with torch CPU ops: the three 3x3x3 Sobel kernels as ONE conv3d (zero padding 1), each axis divided by 32 * voxel, then
+    the trilinear fetch at the vertices (F.grid_sample: border, align_corners=True, xyz -> zyx) and n / ||n||.
+    vol (X,Y,Z) f32, voxel (3,), grid_pts (V,3) in [-1,1]^3 -> (V,3)."""
+    s, dd = torch.tensor([1.0, 2.0, 1.0]), torch.tensor([-1.0, 0.0, 1.0])
+    k = torch.stack([dd[:, None, None] * s[None, :, None] * s[None, None, :], s[:, None, None] * dd[None, :, None] * s[None, None, :],
+                     s[:, None, None] * s[None, :, None] * dd[None, None, :]])                                   # :10-21
+    k = k / (32.0 * torch.as_tensor(voxel, dtype=torch.float32))[:, None, None, None]
+    nv = F.conv3d(vol[None, None], k[:, None], padding=1)                                                         # (1,3,X,Y,Z)   :24-29
+    g = grid_pts[:, [2, 1, 0]][None, :, None, None, :]                                                            # :41
+    n = F.grid_sample(nv, g, 'bilinear', 'border', True)[0, :, :, 0, 0].T                                         # :42-45
+    return n / n.norm(dim=1, keepdim=True)                                                                        # :46-47

@@ -72,6 +72,13 @@ def test_knn_lbs_skinning_stay_inside(nq, nr):
         _lib.check(L.avc_calculate_lbs(ctx, q.ptr, nq, ref.ptr, sw.ptr, nr, lbs.ptr, None))
         _lib.check(L.avc_skinning(ctx, q.ptr, q.ptr, nq, lbs.ptr, jm.ptr, po.ptr, no.ptr, mo.ptr, None))
         _ok(lbs, po, no, mo, q, ref, sw, jm, finite=(lbs, po, no, mo))
+        # the bound form (round 5: avc_lbs_prepare builds the vertices' grid and per-cell candidate lists once): same outputs, nothing written elsewhere
+        lbs2 = Guarded(nq * 24)
+        _lib.check(L.avc_lbs_prepare(ctx, ref.ptr, nr, None))
+        _lib.set_owner(ctx, 'lbs_bound', None)                             # (whatever SmplUtil bound before is gone)
+        _lib.check(L.avc_calculate_lbs_bound(ctx, q.ptr, nq, sw.ptr, lbs2.ptr, None))
+        _ok(lbs2, q, ref, sw, finite=(lbs2,))
+        assert torch.equal(lbs2.t, lbs.t)
 
 
 @pytest.mark.parametrize('N', [1, 1023, 1024, 1025, 70001])

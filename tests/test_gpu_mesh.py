@@ -206,6 +206,48 @@ def test_lbs_skinning_matches_reference_golden(golden, body):
     assert float(far.abs().max()) == 0.0
 
 
+def test_bound_lbs_equals_the_exhaustive_scan(body):
+    """avc_lbs_prepare / avc_calculate_lbs_bound (round 5): one candidate list per 2 cm cell around the bound vertices instead of a search.  Held bit for
+    bit to the exhaustive scan of avc_calculate_lbs on: points on and around the body (the lists), the vertices themselves and duplicated vertices (zero
+    distances, ties -> lower index), points exactly on cell faces, points far from the body and outside the cells' box (no list: the grid search), and the
+    points of a whole coarse grid over the canonical bounds."""
+    import ctypes as C
+    from avatarcap_amd.utils.smpl_util import SmplUtil
+    from avatarcap_amd.grid import generate_volume_points_np
+    rs = np.random.RandomState(11)
+    ref = body['cano_smpl_v'].copy()
+    ref[100:110] = ref[90:100]                                            # duplicated reference points
+    su = SmplUtil(body['skin_weights'])
+    su.set_cano_smpl_vertices(_t(ref))
+    st = (C.c_int64 * 4)()
+    _lib.check(_lib.lib().avc_lbs_bound_stats(_lib.ctx(0), st))
+    assert st[0] == ref.shape[0] and st[3] == 1 and st[1] > 10000 and 20 * st[1] > st[2] > st[1] // 10, list(st)
+    print(f'bound LBS: {st[1]} cells, {st[2]} list entries ({st[2] / st[1]:.1f} per cell over all cells)')
+    surf = gi.surface_points(1234, 5000, body)
+    lo = ref.min(0) - 0.16
+    faces = lo + 0.02 * rs.randint(0, 40, (3000, 3)).astype(np.float32)   # on the faces / edges / corners of the 2 cm cells
+    q = np.concatenate([surf, surf + 0.05 * rs.randn(*surf.shape).astype(np.float32), ref[:2000], ref[90:110], faces,
+                        rs.uniform(-3, 3, (3000, 3)).astype(np.float32), np.full((3, 3), 50.0, np.float32),
+                        generate_volume_points_np(syn.CANO_BOUNDS, (24, 24, 12))]).astype(np.float32)
+    got = su.calculate_lbs(_t(q[None]))
+    _lib.set_option('knn_search', 3)
+    try:
+        want = su._lbs(_t(q[None]), su.cano_smpl_vertices)                # avc_calculate_lbs, exhaustive scan
+        want_b = su.calculate_lbs(_t(q[None]))                            # the bound entry with the same switch: the exhaustive scan of its own copy
+    finally:
+        _lib.set_option('knn_search', 0)
+    assert torch.equal(got, want) and torch.equal(want_b, want)
+    assert float(got[0, :5000].sum(1).min()) > 0.99                      # (points on the body: real weights, not the underflowed rows of far points)
+    # another SmplUtil binding its own vertices takes the context's slot; the first one notices and rebinds
+    su2 = SmplUtil(body['skin_weights'])
+    su2.set_cano_smpl_vertices(_t(ref[::2].copy()))
+    assert torch.equal(su.calculate_lbs(_t(q[None])), want)
+    # in-place edits of the bound tensor are seen too (tensor version)
+    su.cano_smpl_vertices += 0.01
+    moved = su.calculate_lbs(_t(q[None]))
+    assert not torch.equal(moved, want) and torch.equal(moved, su._lbs(_t(q[None]), su.cano_smpl_vertices))
+
+
 def test_scatter_volume():
     from avatarcap_amd import _lib
     N = 100003

@@ -265,6 +265,16 @@ def test_render_rays_on_device_equals_the_stepwise_chain(pipe64, n_rays, n_sampl
         b['occupancy'] = b['depth'].clone()
         r = NerfRenderer(pipe64.network)
         got = r._render_cano(b, 0.02, 0.05, want_raw=True)
+        # the public entry: same maps, the reference's in-place near / far update (arch_avatar.py:287-290), and a reduced dict that says what it lacks
+        b2 = dict(b); b2['near'], b2['far'] = b['near'].clone(), b['far'].clone()
+        pub = r.render(b2, pts_space='cano', near_dist=0.02, far_dist=0.05)
+        assert torch.equal(pub['rgb_map'], got['rgb_map']) and torch.equal(pub['depth_map'], got['depth_map'])
+        has = b['depth'] > 1e-6
+        assert torch.equal(b2['near'][has], b['depth'][has] - 0.02) and torch.equal(b2['far'][~has], b['far'][~has])
+        with pytest.raises(KeyError, match='want_raw=True'):
+            pub['raw']
+        with pytest.raises(KeyError, match='GeoTexAvatar.forward'):
+            pub['occ']
         ref = r.get_pixel_value(b['ray_o'], b['ray_d'], b['near'], b['far'], b['occupancy'], b['depth'], b, 'cano', 0.02, 0.05)
     finally:
         config.N_samples = old_s

@@ -162,3 +162,20 @@ def test_torch_cpu_restatement_matches_numpy_oracle():
     vp = gi.surface_points(105, 500, body)
     lbs = torch_cpu.calculate_lbs(torch.from_numpy(vp), torch.from_numpy(body['cano_smpl_v']), torch.from_numpy(body['skin_weights']))
     assert np.abs(lbs.numpy() - orc.calculate_lbs(vp, body['cano_smpl_v'], body['skin_weights'])).max() < 1e-6
+
+
+def test_torch_cpu_unet_and_normals_match_the_goldens(golden):
+    """oracle/torch_cpu.py's U-Net and vertex normals (what bench.py's cpu_baseline times since round 5) against the reference's own outputs:
+    G7 (UnetNoCond7DS at 128^2, sampled pixels) and G9 (extract_normal_from_volume on an analytic SDF volume)."""
+    import torch
+    from oracle import torch_cpu
+    from avatarcap_amd.network.unets import UnetNoCond7DS
+    shapes = syn.module_shapes(UnetNoCond7DS(input_nc=6, output_nc=64, nf=32))                 # the stand-alone module of the golden: its own key names
+    sd = {'u.' + k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in syn.synth_state_dict(shapes, gi.SEED_NET).items()}
+    y = torch_cpu.unet7ds(sd, torch.from_numpy(gi.pos_map(128)[None]), prefix='u').numpy()[0]
+    assert y.shape == (64, 128, 128)
+    assert maxabs(y[:, gi.PIX[:, 0] % 128, gi.PIX[:, 1] % 128], golden['G7_unet_samples']) < 2e-5
+    vol, voxel = gi.sdf_volume(32)
+    gp = gi.grid_points_m11(107, 400)
+    n = torch_cpu.vertex_normals(torch.from_numpy(vol), voxel, torch.from_numpy(gp)).numpy()
+    assert maxabs(n, golden['G9_normals']) < 2e-5
