@@ -15,6 +15,11 @@ from .. import config
 from .. import _lib
 
 
+import itertools
+
+_bind_tokens = itertools.count(1)
+
+
 class SmplUtil:
     def __init__(self, smpl_skinning_weights=None):
         self.smpl_skinning_weights = None
@@ -33,18 +38,22 @@ class SmplUtil:
         """smpl_util.py:21.  On the HIP device the vertices are also BOUND to the context (avc_lbs_prepare: their search grid and the per-cell candidate
         lists are built once per sequence, not once per calculate_lbs call)."""
         self.cano_smpl_vertices = cano_smpl_vertices.to(torch.float32).to(config.device).contiguous()
+        self._bound = None
         if self.cano_smpl_vertices.is_cuda:
             self._bind(self.cano_smpl_vertices.device)
 
     def _bind(self, device):
-        """The device context holds ONE bound vertex set; whoever calculates next checks that it is still its own (another SmplUtil, or these vertices
-        edited in place, rebinds)."""
+        """The device context holds ONE bound vertex set.  The binder keeps a token of its own (a process-wide counter: neither `id()` nor a device address,
+        both of which are recycled) together with the tensor version it bound; whoever calculates next rebinds when the context's slot carries another
+        token (another SmplUtil has bound since) or the vertices were edited in place."""
         v = self.cano_smpl_vertices
-        key = (id(self), v.data_ptr(), v._version)
         ctx = _lib.ctx(device)
-        if not _lib.owns(ctx, 'lbs_bound', key):
+        b = getattr(self, '_bound', None)
+        if b is None or b[1] is not v or b[2] != v._version or not _lib.owns(ctx, 'lbs_bound', b[0]):
             _lib.check(_lib.lib().avc_lbs_prepare(ctx, _lib.dev_ptr(v, name='cano_smpl_vertices'), v.shape[0], _lib.stream_ptr(device)))
-            _lib.set_owner(ctx, 'lbs_bound', key)
+            token = next(_bind_tokens)
+            _lib.set_owner(ctx, 'lbs_bound', token)
+            self._bound = (token, v, v._version)
         return ctx
 
     # pytorch3d.ops.knn_points stand-in (squared distances ascending, indices int64)

@@ -75,7 +75,7 @@ def test_knn_lbs_skinning_stay_inside(nq, nr):
         # the bound form (round 5: avc_lbs_prepare builds the vertices' grid and per-cell candidate lists once): same outputs, nothing written elsewhere
         lbs2 = Guarded(nq * 24)
         _lib.check(L.avc_lbs_prepare(ctx, ref.ptr, nr, None))
-        _lib.set_owner(ctx, 'lbs_bound', None)                             # (whatever SmplUtil bound before is gone)
+        _lib.set_owner(ctx, 'lbs_bound', None)                             # (whatever SmplUtil bound before is gone: its token no longer owns the slot)
         _lib.check(L.avc_calculate_lbs_bound(ctx, q.ptr, nq, sw.ptr, lbs2.ptr, None))
         _ok(lbs2, q, ref, sw, finite=(lbs2,))
         assert torch.equal(lbs2.t, lbs.t)
