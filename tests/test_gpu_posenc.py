@@ -60,6 +60,16 @@ def test_avatar_query_with_other_positional_encodings(variant):
     sd = geotex_sd_posenc(lt, lw)
     ref = orc.occupancy_query(p2, fmap, gi.center(), sd, tmpl_pos_encoding=lt, warp_pos_encoding=lw)
     assert maxabs(o2['cano_pts_ov'][0].cpu().numpy(), ref['cano_pts_ov']) < TOL and maxabs(o2['nonrigid_offset'][0].cpu().numpy(), ref['nonrigid_offset']) < TOL
+    # the warped query WITH the colour head (avatar_kernel<true, true, 0, WPE>: what the colour path launches): offsets against the oracle's, the template's three heads
+    # against the oracle evaluated at the points the GPU warped to (the template is steep in its input; cf. test_avatar_query_large_preactivations)
+    occ3, off3, rgba3 = net._avatar_query(_t(p2[None]), {'cano_smpl_center': _t(gi.center()[None])}, want_offset=True, want_rgba=True)
+    # (same warp arithmetic as the geometry kernel: same offsets; its occupancy goes through shared.6 unfolded, cf. pack.cpp: other rounding)
+    assert torch.equal(off3, o2['nonrigid_offset']) and float((occ3 - o2['cano_pts_ov']).abs().max()) < 2e-5
+    q3 = (p2.astype(np.float64) + off3[0].cpu().numpy().astype(np.float64)).astype(np.float32)
+    rgb_o, alpha_o, occ_o = orc.double_tnet(q3, sd, pos_encoding=lt)
+    e_c = max(maxabs(rgba3[0, :, :3].cpu().numpy(), rgb_o), maxabs(rgba3[0, :, 3:].cpu().numpy(), alpha_o), maxabs(occ3[0].cpu().numpy(), occ_o))
+    print(f'pos_encoding template {lt} / warp {lw}: warped colour query (rgb, sigma, occ) {e_c:.2e} from the oracle')
+    assert e_c < TOL
     # the grid entry points: a warping field with an encoding stays point by point (bit-identical to the point query on the materialised points);
     # without one (lw == 0) the launch is column-folded whatever the template's encoding (~1e-6)
     res = (6, 5, 128)
