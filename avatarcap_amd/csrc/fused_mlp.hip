@@ -972,8 +972,10 @@ constexpr int B_CONV5 = first_chunk_bytes(16, layout::IN67_KS), B_CONV5F = first
 __global__ __launch_bounds__(256) void column_terms_kernel(const float *__restrict__ feat, int H, int W, const float *__restrict__ gx,
                                                            const float *__restrict__ gy, int nx, int ny, float cx, float cy,
                                                            const float *__restrict__ colw, const float *__restrict__ bias1,
-                                                           const float *__restrict__ bias5, float *__restrict__ out)
+                                                           const float *__restrict__ bias5, float *__restrict__ out,
+                                                           const uint8_t *__restrict__ colflag)
 {
+    // colflag (subset launches, else null): one byte per column, set for the columns the subset touches (band_prepass_kernel); the others are skipped
     constexpr int CPB = 4;                       // columns per trip
     __shared__ __attribute__((aligned(16))) float f[CPB][64];
     const int o = threadIdx.x;
@@ -987,6 +989,7 @@ __global__ __launch_bounds__(256) void column_terms_kernel(const float *__restri
     const float b1 = bias1[o], b5 = bias5[o];
     const int ncol = nx * ny;
     for (int c0 = blockIdx.x * CPB; c0 < ncol; c0 += gridDim.x * CPB) {
+        if (colflag && *reinterpret_cast<const unsigned *>(colflag + c0) == 0u) continue;       // (CPB == 4 flags, table padded: workgroup-uniform)
         {   // the bilinear sample of arch_avatar.py:125-133, as the point-by-point kernel takes it: thread = (column, channel)
             const int q = threadIdx.x >> 6, ch = threadIdx.x & 63, col = min(c0 + q, ncol - 1);
             const Bilinear bl = bilinear_setup<64>(feat, H, W, gx[col / ny] - cx, -(gy[col % ny] - cy), 0);
@@ -1820,9 +1823,26 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
         }
         p.colterms = static_cast<const float *>(ctx->col_scratch);
     }
+    uint8_t *colflag = nullptr;
+#if !AVC_CHECK_RANGE
+    size_t band_head = 0;
+    if (fold == 2) {
+        // the columns the subset touches (band_prepass_kernel; no tile is left out here: this kernel takes any number of runs per wave)
+        const size_t ncol = (size_t)grid->res[0] * grid->res[1], ncol_pad = (ncol + 15) / 16 * 16;
+        band_head = 16 + ncol_pad;
+        const size_t bytes = band_head + (size_t)p.ntiles * 8;
+        if (ctx->band_scratch_bytes < bytes) {
+            if (ctx->band_scratch) { AVC_HIP(hipDeviceSynchronize()); AVC_HIP(hipFree(ctx->band_scratch)); }
+            ctx->band_scratch = nullptr; ctx->band_scratch_bytes = 0;
+            AVC_HIP(hipMalloc(&ctx->band_scratch, bytes));
+            ctx->band_scratch_bytes = bytes;
+        }
+        colflag = reinterpret_cast<uint8_t *>(static_cast<char *>(ctx->band_scratch) + 16);
+    }
+#endif
     if (int rc0 = set_all_lds()) return rc0;
     hipEvent_t e0, e1;
-    timing_begin(ctx, 0, s, e0, e1, p);        // (a folded launch is timed with its column pass)
+    timing_begin(ctx, 0, s, e0, e1, p);        // (a folded launch is timed with its column pass, a subset launch also with its prepass)
 #define LAUNCH(W_, C_, F_, ...)                                                                         \
     do {                                                                                                \
         rc = set_lds(avatar_kernel<W_, C_, F_, ##__VA_ARGS__>);                                         \
@@ -1834,9 +1854,18 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
     else if (colour) LAUNCH(true, true, 0);
     else if (fold) {
         const int ncol = grid->res[0] * grid->res[1];
+#if !AVC_CHECK_RANGE
+        if (fold == 2) {
+            char *base = static_cast<char *>(ctx->band_scratch);
+            int32_t *tile_flag = reinterpret_cast<int32_t *>(base + band_head);
+            AVC_HIP(hipMemsetAsync(ctx->band_scratch, 0, band_head, s));
+            hipLaunchKernelGGL(band_prepass_kernel, dim3((unsigned)p.ntiles), dim3(TILE_PTS), 0, s, p.gidx, p.n, p.grz, 64, colflag, tile_flag,
+                               tile_flag + p.ntiles, reinterpret_cast<int32_t *>(base));
+        }
+#endif
         hipLaunchKernelGGL(column_terms_kernel, dim3(std::min((ncol + 3) / 4, ctx->num_cus * 4)), dim3(256), 0, s, p.feat, p.H, p.W, p.gx, p.gy,
                            (int)grid->res[0], (int)grid->res[1], p.cx, p.cy, (const float *)net.d_colw, p.bias, p.bias + 4 * 256,
-                           static_cast<float *>(ctx->col_scratch));
+                           static_cast<float *>(ctx->col_scratch), colflag);
 #if !AVC_CHECK_RANGE
         if (fold == 2) LAUNCH(true, false, 2); else LAUNCH(true, false, 1);
 #endif
