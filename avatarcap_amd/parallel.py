@@ -9,9 +9,9 @@ and overlapped with the frames that follow (MeshExchange):
   1. submit(mesh) packs the frame's mesh into one buffer and starts an asynchronous all-gather of the step's (V, F) counts (16 bytes per
      rank) from a side stream: pinned host buffers in and out, an event behind the copy -- the compute stream is never drained for it;
   2. pump() -- called by FramePipeline.avatar_frame right behind the NEXT frame's query launch, while the host has nothing to do -- waits
-     for that event and issues the step's meshes as `world` asynchronous broadcasts of EXACTLY 6 V + 3 F 32-bit words each ([verts |
-     normals] and the faces in one buffer) from the side stream, so RCCL moves step k - 1 over xGMI while frame k computes; no padding to
-     the largest rank.  A caller that never pumps still gets the same collectives in the same order (submit(k) sends step k - 1 first);
+     for that event and issues the step's meshes -- EXACTLY 6 V + 3 F 32-bit words each ([verts | normals] and the faces in one buffer), no
+     padding to the largest rank -- from the side stream as ONE batched group of point-to-point sends and receives: every rank sends its
+     buffer to each peer over the link the two share (the node's xGMI is fully connected), so RCCL moves step k - 1 while frame k computes.  A caller that never pumps still gets the same collectives in the same order (submit(k) sends step k - 1 first);
   3. finish() sends what has not travelled -- with pump() in the frame loop: the LAST step only, i.e. each rank's last mesh --, makes the
      caller's stream wait for everything in flight and returns all meshes in frame order on every rank.
 verify_gathered_meshes() is the exchange's self-check (per-frame integer checksums from the owners against what arrived, slot by slot).
@@ -71,8 +71,16 @@ class MeshExchange:
     AG(1), B(1) x world, ... -- because submit(k) pumps step k - 1 itself before it starts AG(k).
     `force` runs the collectives even with one rank (the single-GPU RCCL test)."""
 
-    def __init__(self, n_frames: int, group=None, device=None, force: bool = False):
+    def __init__(self, n_frames: int, group=None, device=None, force: bool = False, mode: str | None = None):
+        import os
         self.n_frames, self.group, self.force = int(n_frames), group, force
+        # how a step's meshes travel: 'p2p' (default) -- every rank SENDS its buffer to each peer and receives each peer's, one batched group of
+        # point-to-point operations: on the node's fully connected xGMI every pair has a link of its own (7 x ~77 GB/s inbound per GPU), where a ring
+        # broadcast or all-gather is bound by ONE link for all eight meshes (~9x the time at N = 8); 'broadcast' -- `world` broadcasts (round 4's form,
+        # kept for A/B on the 8-GPU box: AVC_EXCHANGE=broadcast)
+        self.mode = mode or os.environ.get('AVC_EXCHANGE', 'p2p')
+        if self.mode not in ('p2p', 'broadcast'):
+            raise ValueError(f"MeshExchange: mode is 'p2p' or 'broadcast', not {self.mode!r}")
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.active = self.world > 1 or force
@@ -165,6 +173,7 @@ class MeshExchange:
         with (torch.cuda.stream(self._comm) if on_side else contextlib.nullcontext()):
             if on_side:
                 self._comm.wait_event(c['ready'])                              # this rank's packed buffer of step j
+            ops = []
             for r in range(self.world):
                 f = j * self.world + r
                 if f >= self.n_frames:
@@ -179,9 +188,18 @@ class MeshExchange:
                     self.bytes_received += 4 * buf.numel()
                     self._foreign.append(buf)
                 if buf.numel():
-                    self._works.append(dist.broadcast(buf, src=self._src(r), group=self.group, async_op=True))
+                    if self.mode == 'broadcast':
+                        self._works.append(dist.broadcast(buf, src=self._src(r), group=self.group, async_op=True))
+                    elif r != self.rank:
+                        ops.append(dist.P2POp(dist.irecv, buf, self._src(r), self.group))
                 vn = buf[:6 * V].view(torch.float32).reshape(V, 6)
                 self.out[f] = {'v': vn[:, :3], 'vn': vn[:, 3:], 'f': buf[6 * V:].reshape(F, 3)}
+            if self.mode == 'p2p':
+                mine = self._mine[j]
+                if mine.numel():                                               # (an empty mesh -- a failed frame, a rank without a frame -- is neither sent nor received: both ends know from the counts)
+                    ops += [dist.P2POp(dist.isend, mine, self._src(r), self.group) for r in range(self.world) if r != self.rank]
+                if ops:
+                    self._works += dist.batch_isend_irecv(ops)                 # one group: RCCL pairs the sends and receives whatever their order in the list
         self._sent = j + 1
 
     def finish(self) -> list:
@@ -313,6 +331,25 @@ def init_process_group(backend: str, rank: int, world: int, device=None, timeout
     except Exception as e:      # noqa: BLE001 -- a torch without the hook: one bound governs both (say so once)
         if rank == 0:
             print(f'# parallel: could not raise the collective timeout ({type(e).__name__}: {e}); rendezvous and collectives share {timeout_s:.0f} s', flush=True)
+
+
+def leave_cus_for_the_exchange(device, spare: int = 8, log=None) -> int:
+    """Multi-rank runs: the persistent query kernels take `CUs - spare` workgroups instead of one per CU (avc_set_option "mlp_blocks").  The fused queries
+    hold a whole CU each (160 KB of LDS, every VGPR): a launch on ALL CUs leaves RCCL's copy kernels nowhere to run until it ends -- the exchange then
+    lands on the frame's tail and, worse, on the NEXT query's launch, whose workgroups that find their CU taken start late and, tiles being assigned
+    statically, end the launch that much later.  With a few CUs left free the exchange runs beside the query (`MeshExchange.pump`) and is gone before the
+    next launch.  Cost on one GPU: +0.6 % query time for 8 CUs (profiles/r03_overlap_experiment.md; the launch is power-bound, the clock rises as CUs
+    idle).  AVC_MLP_BLOCKS, when set, wins.  Returns the number of workgroups now used (0: unchanged)."""
+    import os
+    from . import _lib
+    if os.environ.get('AVC_MLP_BLOCKS') or spare <= 0:
+        return 0
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    n = max(1, cus - spare)
+    _lib.set_option('mlp_blocks', n, device)
+    if log:
+        log(f'# fused queries on {n} of {cus} CUs: {spare} left to RCCL\'s copy kernels')
+    return n
 
 
 def pin_to_gpu_numa(device_index: int, local_world: int = 1, log=None) -> dict:

@@ -285,6 +285,7 @@ def main():
     ap.add_argument('--no-masked', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help='skip the BASELINE configs[2] / configs[3] legs of the line')
     ap.add_argument('--dist-timeout', type=float, default=180.0, help='seconds after which a rendezvous / collective that does not complete ends the job')
+    ap.add_argument('--spare-cus', type=int, default=8, help='N > 1: CUs the persistent query kernels leave to the exchange (0: none; AVC_MLP_BLOCKS wins)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -319,8 +320,11 @@ def main():
     from avatarcap_amd import _lib
     from avatarcap_amd.dataset import to_cuda
     from avatarcap_amd.parallel import MeshExchange, all_gather_meshes, pin_to_gpu_numa
+    query_wgs = 0
     if world > 1:
         pin_to_gpu_numa(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))       # each rank on the cores of its GPU's NUMA node
+        from avatarcap_amd.parallel import leave_cus_for_the_exchange
+        query_wgs = leave_cus_for_the_exchange(device, args.spare_cus)                    # RCCL's copy kernels need somewhere to run beside the query
     K, W, res = args.steps, args.warmup, args.res
     n_frames = world * (K + W)
     pipe, sd = build_pipeline(res, 'dense', n_frames, device)
@@ -419,7 +423,8 @@ def main():
                        'grid': [res] * 3, 'points_per_frame': N, 'vertices_last_frame': int(out['cano_v'].shape[0]),
                        'faces_last_frame': int(out['f'].shape[0]), 'parallelism': f'frame-sharded x{world}',
                        'frames_in_batch': world * K, 'meshes_all_gathered': bool(world > 1 or force_dist),
-                       'mesh_exchange': 'exact-size broadcasts per step, issued from a side stream behind the NEXT frame\'s query launch (parallel.MeshExchange.pump): '
+                       'query_workgroups': query_wgs or 'one per CU', 'exchange_transport': os.environ.get('AVC_EXCHANGE', 'p2p') if (world > 1 or force_dist) else None,
+                       'mesh_exchange': 'exact-size point-to-point sends per step (every pair of GPUs over its own xGMI link), issued from a side stream behind the NEXT frame\'s query launch (parallel.MeshExchange.pump): '
                                         'K - 1 of a rank\'s K steps travel beside compute, the last one is `exchange_tail_ms`; `meshes_verified`: per-frame integer checksums '
                                         'of every received mesh against its owner\'s, checked on every rank outside the timed region',
                        'semantics': '`value` is the DENSE stress variant BASELINE configs[1] names (every one of the 256^3 grid points evaluated); the reference itself '
@@ -432,7 +437,7 @@ def main():
                                                            '0.087 GB algorithmic); not measurable from inside this process, hence null here',
                          'kernel': 'avc::avatar_kernel<true,false,1> (+ its column_terms_kernel pass, timed together)', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
                          'shader_cycles_per_launch': avg_cyc.value, 'clock_mhz': (avg_cyc.value / (avg_ms.value * 1e3)) if avg_ms.value > 0 else 0.0,
-                         'cycles_per_mfma': avg_cyc.value / (4728 * (N / 128 / min(N // 128, torch.cuda.get_device_properties(device).multi_processor_count))) if avg_cyc.value > 0 else 0.0,
+                         'cycles_per_mfma': avg_cyc.value / (4728 * -(-(N // 128) // min(N // 128, query_wgs or torch.cuda.get_device_properties(device).multi_processor_count))) if avg_cyc.value > 0 else 0.0,
                          'algorithmic_flop_per_launch': N * FLOP_PER_POINT,
                          'mfma_issued_tflops': N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0,
                          'mfma_util': (N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 / PEAK_F16_TFLOPS) if avg_ms.value > 0 else 0.0,

@@ -315,6 +315,8 @@ def main(argv=None):
                                     timeout_s=args.dist_timeout, collective_timeout_s=args.collective_timeout)
         if not args.dry_run:
             parallel.pin_to_gpu_numa(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)), log=print if rank == 0 else None)
+            if args.gather_meshes:
+                parallel.leave_cus_for_the_exchange(config.device, log=print if rank == 0 else None)
     try:
         n_failed = run_avatarcap(w_recon=True, save_avatar_mesh=args.save_ply, save_final_mesh=args.save_ply, w_nerf=args.nerf,
                                  synthetic=args.synthetic, n_frames=args.frames, valid=args.valid, integrate_manner=args.integrate,
