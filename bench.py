@@ -343,15 +343,17 @@ def main():
     out = None
     for s in range(W):
         out = pipe.avatar_frame(my[s], next_items=my[s + 1] if s + 1 < W else None)
-    if world > 1 or force_dist:   # warm the collective too
+    if world > 1 or force_dist:   # warm the exchange too (RCCL sets its point-to-point connections up on first use)
+        warm = ({'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']} if out is not None and out.get('live_v') is not None else       # --warmup 0: a token mesh
+                {'v': torch.zeros((3, 3), device=device), 'vn': torch.zeros((3, 3), device=device), 'f': torch.zeros((1, 3), dtype=torch.int32, device=device)})
         with _stdout_to_stderr():
-            all_gather_meshes([{'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']}], world, force=force_dist)
+            all_gather_meshes([warm], world, force=force_dist)
             torch.cuda.synchronize()
     barrier('start of the timed region')
     _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
     t0 = time.perf_counter()
     # the batch's meshes are exchanged step by step WHILE the following frames compute (parallel.MeshExchange: exact sizes, asynchronous
-    # broadcasts on RCCL's stream); what is left behind the last frame is that frame's own mesh
+    # point-to-point sends on RCCL's stream); what is left behind the last frame is that frame's own mesh
     ex = MeshExchange(world * K, force=force_dist) if (world > 1 or force_dist) else None
     pipe.exchange = ex                              # avatar_frame pumps it behind its query launch: step s - 1 travels while frame s computes
     for s in range(W, W + K):
