@@ -435,7 +435,7 @@ def main():
                        'dense_points': 'generated from the grid index (avc_avatar_query_grid), offsets not written'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_TFLOPS,
-                         'traffic': None, 'traffic_note': 'HBM bytes are PMC counters of a separate rocprofv3 --pmc pass (profiles/r04_pmc_avatar.md, same kernel binary: 0.52 GB per launch, '
+                         'traffic': None, 'traffic_note': 'HBM bytes are PMC counters of a separate rocprofv3 --pmc pass (profiles/r05_pmc_avatar.md: 0.52 GB per launch, '
                                                            '0.087 GB algorithmic); not measurable from inside this process, hence null here',
                          'kernel': 'avc::avatar_kernel<true,false,1> (+ its column_terms_kernel pass, timed together)', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
                          'shader_cycles_per_launch': avg_cyc.value, 'clock_mhz': (avg_cyc.value / (avg_ms.value * 1e3)) if avg_ms.value > 0 else 0.0,
