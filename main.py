@@ -65,7 +65,7 @@ class _StandInPipeline:
 
 def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w_nerf=False, frame_idx=None, view_idx=0, interval=1,
                   synthetic=False, n_frames=2, valid='band', integrate_manner='merge', rank=0, world=1, gather_meshes=False, gather_batch=8,
-                  dry_run=False, dry_fail=(), max_failure_streak=3):
+                  dry_run=False, dry_fail=(), max_failure_streak=3, force_dist=False):
     from avatarcap_amd import config, parallel
     cfg = config.cfg
     out_dir = cfg['testing']['output_dir']
@@ -211,7 +211,7 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
         b0 = (k // gather_batch) * gather_batch               # first step of this batch
         if gather['ex'] is None:
             lo, hi = b0 * world, min(len(frames), (b0 + gather_batch) * world)
-            gather['ex'] = (parallel.MeshExchange(hi - lo, device=dev), lo, hi)
+            gather['ex'] = (parallel.MeshExchange(hi - lo, device=dev, force=force_dist), lo, hi)
             pipe.exchange = gather['ex'][0]                   # avatar_frame pumps it: step k - 1 travels while frame k computes
         ex, lo, hi = gather['ex']
         has_frame = k * world + rank < len(frames)
@@ -310,7 +310,11 @@ def main(argv=None):
             raise SystemExit('main.py -m test needs an MI355X: no HIP device visible (there is no CPU fallback for the hot path)')
         torch.cuda.set_device(local_rank)
         config.device = torch.device('cuda', local_rank)
-    if world > 1:
+    # AVC_FORCE_DIST=1 (tests): one rank, but the process group is RCCL and --gather-meshes runs the exchange's collectives -- the N > 1 code path on one GPU
+    force_dist = world == 1 and not args.dry_run and os.environ.get('AVC_FORCE_DIST') == '1'
+    if force_dist:
+        os.environ.setdefault('MASTER_PORT', str(parallel.free_port()))
+    if world > 1 or force_dist:
         parallel.init_process_group('gloo' if args.dry_run else 'nccl', rank, world, None if args.dry_run else config.device,
                                     timeout_s=args.dist_timeout, collective_timeout_s=args.collective_timeout)
         if not args.dry_run:
@@ -321,9 +325,9 @@ def main(argv=None):
         n_failed = run_avatarcap(w_recon=True, save_avatar_mesh=args.save_ply, save_final_mesh=args.save_ply, w_nerf=args.nerf,
                                  synthetic=args.synthetic, n_frames=args.frames, valid=args.valid, integrate_manner=args.integrate,
                                  rank=rank, world=world, gather_meshes=args.gather_meshes, gather_batch=max(1, args.gather_batch), dry_run=args.dry_run,
-                                 dry_fail=args.dry_fail, max_failure_streak=args.max_failure_streak)
+                                 dry_fail=args.dry_fail, max_failure_streak=args.max_failure_streak, force_dist=force_dist)
     finally:
-        if world > 1:
+        if world > 1 or force_dist:
             import torch.distributed as dist
             if dist.is_initialized():
                 dist.destroy_process_group()

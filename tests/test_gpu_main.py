@@ -104,3 +104,27 @@ def test_main_refuses_a_checkpoint_that_leaves_the_fp16_range(tmp_path):
     assert r.returncode != 0, r.stdout[-2000:]
     assert 'AVC_ERR_RANGE' in r.stdout and 'status -5' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert 'not attempted' in r.stdout and not list(out.glob('*_mesh.npz'))       # nothing was written; frames 1, 2 were not run on weights known to be bad
+
+
+def test_main_gathers_meshes_through_rccl_on_one_gpu(tmp_path):
+    """`main.py --synthetic --gather-meshes` with AVC_FORCE_DIST=1: one rank, but the process group is RCCL and the product loop drives the exchange as an
+    8-GPU run does -- `FramePipeline.avatar_frame` pumps it behind its query launch, steps are submitted frame by frame, batches of `--gather-batch` steps
+    are finished and moved to the host -- on the real pipeline's device tensors.  What rank 0 writes must be, frame for frame, what the frames' own files hold."""
+    out = tmp_path / 'out'
+    env = dict(os.environ, AVC_FORCE_DIST='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1')
+    env.pop('MASTER_PORT', None)
+    cfg = {'training': {'training_data_dir': None},
+           'testing': {'vol_res': [48, 64, 32], 'recon_net_ckpt': None, 'net_ckpt': None, 'net_ckpt_finetuned': None, 'testing_data_dir': None, 'output_dir': str(out)},
+           'model': {'cano_template': {'pos_encoding': 10}, 'warping_field': {'pos_encoding': 0}}}
+    with open(tmp_path / 'cfg.yaml', 'w') as fh:
+        yaml.safe_dump(cfg, fh)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '-c', str(tmp_path / 'cfg.yaml'), '-m', 'test', '--synthetic', '--frames', '5', '--gather-meshes',
+                        '--gather-batch', '2'], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert '# gathered 5 meshes' in r.stdout and '5 of 5 frames done on 1 rank(s)' in r.stdout
+    allm = np.load(str(out / 'all_avatar_meshes.npz'))
+    assert allm['frames'].tolist() == list(range(5))
+    for f in range(5):
+        m = np.load(str(out / ('%04d_mesh.npz' % f)))
+        assert m['live_v'].shape[0] > 50
+        assert np.array_equal(allm['v_%04d' % f], m['live_v']) and np.array_equal(allm['vn_%04d' % f], m['live_vn']) and np.array_equal(allm['f_%04d' % f], m['f'])
