@@ -57,7 +57,7 @@ def test_geotex_forward_posed_matches_reference(net, golden, body):
     o = net.forward(_t(wl[None]), None, _t(np.full((1, 500, 1), 0.0016, np.float32)), b3, pts_space='posed')
     # Two inverse-skinning stages in fp32 sit upstream of the network here and the template is steep in its input (2^9 positional
     # frequency): the golden is ONE float32 realisation of the path (the reference's), the device another.  What float32 itself loses
-    # on this path is measured, not guessed: float32 oracle vs float64 oracle; two float32 realisations may differ by twice that.
+    # on this path is measured and printed (float32 oracle vs float64 oracle); the assertions are north_star's flat 1e-4.
     from oracle import avatarcap_oracle as orc
     args = (wl, np.full((500, 1), 0.0016, np.float32), gi.pose_feat_map(), gi.center(), syn.CANO_BOUNDS, live_v, body['skin_weights'],
             gi.blend_weight_volume(), jm, geotex_sd())
@@ -67,8 +67,29 @@ def test_geotex_forward_posed_matches_reference(net, golden, body):
         got = o[name][0].cpu().numpy()
         e_gold, e_64 = maxabs(got, golden['G13_' + name]), maxabs(got, r64[k])
         print(f'G13 {name}: vs reference golden {e_gold:.3e}, vs fp64 oracle {e_64:.3e}, fp32-oracle slack {slack:.3e}')
-        assert e_gold < 1e-4 + 2 * slack and e_64 < 1e-4 + slack
+        assert e_gold < 1e-4 and e_64 < 1e-4                                    # the flat bar (measured 9e-6; the slack is printed for information: round 4 allowed 1e-4 + 2 x slack)
     assert maxabs(o['nonrigid_offset'][0].cpu().numpy(), golden['G13_off']) < 1e-4
+    # The same path held to the FLAT bar in two stages (round 5): (a) the canonical points the two inverse-skinning stages arrive at -- the product's own
+    # calls, in forward()'s order -- against the fp64 oracle's, and (b) the network + masks + alpha in fp64 AT those points against what forward() returned.
+    # Neither stage needs the slack; the end-to-end excess above is the template's steepness applied to (a)'s fp32 rounding.
+    wl_t, lv_t = _t(wl[None]), _t(live_v[None])
+    d2, idx = smpl_util.knn_points(wl_t, lv_t, K=1)
+    l2c = torch.linalg.inv(_t(jm[None]))
+    c0 = smpl_util.skinning(wl_t, smpl_util.smpl_skinning_weights[idx[:, :, 0]], l2c)
+    lo, hi = _t(syn.CANO_BOUNDS[0]), _t(syn.CANO_BOUNDS[1])
+    w = net.cano_weight_volume.forward((c0 - lo) / (hi - lo))
+    cano_gpu = smpl_util.skinning(wl_t, w.contiguous(), l2c)[0].cpu().numpy()
+    e_a = maxabs(cano_gpu, r64[3])
+    off = orc.warping_query(cano_gpu, gi.pose_feat_map(), gi.center(), geotex_sd())
+    q = cano_gpu.astype(np.float64) + off
+    rgb, alpha, occ = orc.double_tnet(q, geotex_sd(), with_colour=True)
+    inside = np.all((q > syn.CANO_BOUNDS[0]) & (q < syn.CANO_BOUNDS[1]), -1)
+    near = d2[0, :, 0].cpu().numpy() < np.float32(0.08 * 0.08)
+    alpha = np.where((inside & near)[:, None], alpha, 0.0)
+    raw_b = np.concatenate([rgb, 1.0 - np.exp(-alpha * 0.0016)], -1)
+    e_b = max(maxabs(o['raw'][0].cpu().numpy(), raw_b), maxabs(o['occ'][0].cpu().numpy(), occ), maxabs(o['nonrigid_offset'][0].cpu().numpy(), off))
+    print(f'G13 staged: canonical points vs fp64 oracle {e_a:.3e}; network at the device\'s canonical points vs fp64 oracle {e_b:.3e}')
+    assert e_a < 1e-5 and e_b < 1e-4
 
 
 @pytest.fixture(scope='module')
