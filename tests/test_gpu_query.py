@@ -524,3 +524,35 @@ def test_context_options_and_launch_clock(net):
     print(f'launch clock: {cyc.value:.3e} cycles / {ms.value:.3f} ms = {mhz:.0f} MHz')
     assert 500 < mhz < 3000                                 # (the column pass is inside the event pair, not inside the cycle count: a lower bound of the clock)
     assert torch.equal(full['cano_pts_ov'], few['cano_pts_ov'])
+
+
+@pytest.mark.parametrize('blocks', [248, 5])
+def test_queries_do_not_depend_on_the_workgroup_count(net, blocks):
+    """Multi-rank runs give the persistent query kernels `CUs - 8` workgroups (parallel.leave_cus_for_the_exchange; avc_set_option "mlp_blocks"), which
+    does not divide the tile count: every launch form -- dense and band, avatar and recon, folded -- must return the bits of the default launch."""
+    from avatarcap_amd.network.arch_avatar import OccupancyNet
+    from avatarcap_amd.network.arch_recon import ReconNetwork
+    from avatarcap_amd.grid import volume_axes
+    config.if_type = 'sdf'
+    net.warping_field.pose_feat_map = _t(gi.pose_feat_map(seed=77)[None])
+    net.warping_field._map_on_device = None
+    rn = ReconNetwork().to('cuda').eval()
+    rn.load_state_dict({k: torch.from_numpy(v) for k, v in recon_sd().items()})
+    imap = _t(gi.img_feat_map(seed=78)[None])
+    res = (9, 7, 256)                                                              # 126 tiles
+    ax = volume_axes(syn.CANO_BOUNDS, res, 'cuda')
+    idx = torch.from_numpy(_band_like_indices(res, 6000, 5)).cuda()
+    items = {'cano_smpl_center': _t(gi.center()[None])}
+
+    def run():
+        q = OccupancyNet(net)
+        return (q.query_grid(items, ax, list(res))['cano_pts_ov'], q.query_grid(items, ax, list(res), index=idx)['cano_pts_ov'],
+                rn.decode_grid(ax, res, imap, items['cano_smpl_center']), rn.decode_grid(ax, res, imap, items['cano_smpl_center'], index=idx))
+    want = run()
+    _lib.set_option('mlp_blocks', blocks)
+    try:
+        got = run()
+    finally:
+        _lib.set_option('mlp_blocks', 0)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
