@@ -5,6 +5,8 @@ image-observed normals, reconstruction, vertex colours (SURVEY.md section 8(a) a
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -60,6 +62,8 @@ class FramePipeline:
         self.ds = dataset
         self.vol_res = list(dataset.vol_res)
         self.exchange = None          # a parallel.MeshExchange while a sharded batch is running: avatar_frame pumps it behind its query launch
+        self.lookahead_on_side_stream = os.environ.get('AVC_LOOKAHEAD_SIDE', '1') == '1'     # the next frame's U-Net beside this frame's tail (avatar_frame)
+        self._side = None
         smpl_util.set_smpl_skinning_weights(dataset.body['skin_weights'])
         smpl_util.set_cano_smpl_vertices(dataset.cano_smpl_v)                 # main.py:335
 
@@ -87,6 +91,10 @@ class FramePipeline:
         wf = self.network.warping_field
         pre, self._next_map = getattr(self, '_next_map', None), None
         if pre is not None and pre[0] is items['smpl_pos_map']:
+            if pre[2] is not None:                                           # computed on the side stream: this stream takes it over
+                cur = torch.cuda.current_stream(pre[1].device)
+                cur.wait_event(pre[2])
+                pre[1].record_stream(cur)
             wf.pose_feat_map, wf._map_on_device = pre[1], None
         else:
             with _stage('avc/unet7ds'):
@@ -95,7 +103,22 @@ class FramePipeline:
             out = self._avatar_query(items)
         if next_items is not None:
             with _stage('avc/unet7ds (next frame)'):
-                self._next_map = (next_items['smpl_pos_map'], wf.unet(next_items['smpl_pos_map']).contiguous())
+                x = next_items['smpl_pos_map']
+                if self.lookahead_on_side_stream and x.is_cuda:
+                    # behind the query on a stream of its own: its 18 small launches then run BESIDE this frame's marching cubes / LBS (small launches
+                    # too) instead of in front of them; the next call waits for the event
+                    if self._side is None:
+                        self._side = torch.cuda.Stream(x.device)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(x.device))           # = the query has finished
+                    with torch.cuda.stream(self._side):
+                        self._side.wait_event(ev)
+                        m = wf.unet(x).contiguous()
+                        done = torch.cuda.Event()
+                        done.record(self._side)
+                    self._next_map = (x, m, done)
+                else:
+                    self._next_map = (x, wf.unet(x).contiguous(), None)
         if self.exchange is not None:
             # the query is enqueued and the host is idle until marching cubes' wait: the PREVIOUS frame's mesh goes out now, beside this frame's
             # kernels (parallel.MeshExchange.pump -- waits for the peers' counts of that step, never for this stream)
