@@ -91,22 +91,19 @@ class FramePipeline:
         wf = self.network.warping_field
         pre, self._next_map = getattr(self, '_next_map', None), None
         if pre is not None and pre[0] is items['smpl_pos_map']:
-            if pre[2] is not None:                                           # computed on the side stream: this stream takes it over
-                cur = torch.cuda.current_stream(pre[1].device)
-                cur.wait_event(pre[2])
-                pre[1].record_stream(cur)
             wf.pose_feat_map, wf._map_on_device = pre[1], None
         else:
             with _stage('avc/unet7ds'):
                 wf.precompute_conv(items)                                    # :359
         with _stage('avc/avatar_query'):
             out = self._avatar_query(items)
+        side_done = None
         if next_items is not None:
             with _stage('avc/unet7ds (next frame)'):
                 x = next_items['smpl_pos_map']
                 if self.lookahead_on_side_stream and x.is_cuda:
                     # behind the query on a stream of its own: its 18 small launches then run BESIDE this frame's marching cubes / LBS (small launches
-                    # too) instead of in front of them; the next call waits for the event
+                    # too) instead of in front of them; this call's stream joins it before it returns
                     if self._side is None:
                         self._side = torch.cuda.Stream(x.device)
                     ev = torch.cuda.Event()
@@ -116,24 +113,33 @@ class FramePipeline:
                         m = wf.unet(x).contiguous()
                         done = torch.cuda.Event()
                         done.record(self._side)
-                    self._next_map = (x, m, done)
+                    self._next_map = (x, m)
+                    side_done = done
                 else:
-                    self._next_map = (x, wf.unet(x).contiguous(), None)
+                    self._next_map = (x, wf.unet(x).contiguous())
         if self.exchange is not None:
             # the query is enqueued and the host is idle until marching cubes' wait: the PREVIOUS frame's mesh goes out now, beside this frame's
             # kernels (parallel.MeshExchange.pump -- waits for the peers' counts of that step, never for this stream)
             with _stage('avc/mesh_exchange pump'):
                 self.exchange.pump()
-        with _stage('avc/marching_cubes'):
-            vol = fill_volume(out['cano_pts_ov'][0, :, 0], self.ds.valid_u8, self.ds.invalid_pts_ov)   # :362-364
-            v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds, iso_value=config.iso_value)   # :367
-        res = {'cano_v': v, 'cano_vn': n, 'f': f, 'occ_volume': vol}
-        if skin and v.shape[0] > 0:
-            with _stage('avc/lbs'):
-                lbs = smpl_util.calculate_lbs(v[None])                       # :385
-                live_v, mats = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'], True)     # :386
-                live_n = smpl_util.skinning_normal(n[None], lbs, items['cano2live_jnt_mats'])          # :389 (einsum with vert_mats[:, :3, :3])
-            res.update({'live_v': live_v[0], 'live_vn': live_n[0], 'vert_mats': mats[0]})
+        try:
+            with _stage('avc/marching_cubes'):
+                vol = fill_volume(out['cano_pts_ov'][0, :, 0], self.ds.valid_u8, self.ds.invalid_pts_ov)   # :362-364
+                v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds, iso_value=config.iso_value)   # :367
+            res = {'cano_v': v, 'cano_vn': n, 'f': f, 'occ_volume': vol}
+            if skin and v.shape[0] > 0:
+                with _stage('avc/lbs'):
+                    lbs = smpl_util.calculate_lbs(v[None])                       # :385
+                    live_v, mats = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'], True)     # :386
+                    live_n = smpl_util.skinning_normal(n[None], lbs, items['cano2live_jnt_mats'])          # :389 (einsum with vert_mats[:, :3, :3])
+                res.update({'live_v': live_v[0], 'live_vn': live_n[0], 'vert_mats': mats[0]})
+        finally:
+            if side_done is not None:
+                # whatever is enqueued after this call -- the next frame's query on the map, another pass of the U-Net (colour path, a frame that is not
+                # the announced one) on the same launch plan -- comes behind the side stream's work; marching cubes and LBS above are already in the queue
+                cur = torch.cuda.current_stream(self._next_map[1].device)
+                cur.wait_event(side_done)
+                self._next_map[1].record_stream(cur)
         return res
 
     def _avatar_query(self, items: dict):

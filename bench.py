@@ -486,7 +486,10 @@ def main():
             except Exception as e:       # informational leg only
                 line['masked'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(pipe, sd, my[-1], out, res)
+            try:
+                line['cpu_baseline'] = cpu_baseline(pipe, sd, my[-1], out, res)
+            except Exception as e:       # a host without the oracle's build must not cost the run its GPU measurement
+                line['cpu_baseline'] = {'error': repr(e)}
         if world == 1 and not args.no_configs:
             del pipe, my
             torch.cuda.empty_cache()

@@ -227,7 +227,7 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
     def process_and_submit(k, fr, nxt):
         try:
             mesh = process(k, fr, nxt)
-        except BaseException as e:
+        except Exception as e:      # noqa: BLE001 -- re-raised below; run_sharded contains it
             if parallel.device_is_gone(e):
                 # a sticky HIP fault or an out-of-memory error: no collective can be issued on this device any more.  The rank ends the JOB (below) --
                 # under torch.distributed.run the launcher then stops its peers -- instead of leaving them in a collective until the watchdog's timeout.
