@@ -23,7 +23,7 @@ The JSON line also carries:
                   product -- 4,728 MFMAs per 32 points once the 64 pose-feature columns of conv1 / conv5 are folded per
                   grid column, DESIGN.md 2.5 -- so `mfma_util` = 2.73 x frac is the matrix-pipe utilisation; the launch
                   time includes the column pass that feeds the folded kernel; `traffic` is the
-                  HBM byte count of the committed rocprofv3 --pmc pass, profiles/r03_pmc_avatar.md;
+                  HBM byte count of the committed rocprofv3 --pmc passes of this launch, profiles/r05_pmc_avatar.md;
                   `clock_mhz` = s_memtime cycles of the timed launches / their device time = the clock the chip held in THIS run;
                   `sustained_mfma_tflops_measured` is the rate a pure MFMA + LDS-read loop of full-entropy operands holds on this
                   part at its power cap, profiles/r03_power_wall.md -- information, not `peak`).
@@ -56,9 +56,9 @@ PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA (MI355X_MICROA
 SUSTAINED_F16_TFLOPS = 1505.0      # what this part sustains at its power cap on split-fp16 MFMAs of FULL-ENTROPY operands fed from LDS, nothing else in
                                     # the instruction stream (1.47 GHz): tools/ubench/mfma_order.hip, profiles/r03_power_wall.md -- information only
                                     # (round 1's 1673 was measured on low-entropy operands)
-# (roofline.traffic -- HBM bytes per launch -- comes from PMC counters, which only a separate `rocprofv3 --pmc` pass can collect: it is null on the line
-#  and reported under profiles/ (r03_pmc_avatar.md: 0.51 GB per dense 256^3 launch against 0.087 GB algorithmic: the 131 MB per-column table written by the
-#  column pass and read back 2 KB per tile, the feature map per XCD, the share of the weight stream that leaves L2))
+# roofline.traffic -- HBM bytes per launch -- comes from PMC counters, which only a separate `rocprofv3 --pmc` pass can collect (profiles/r05_pmc_avatar.md, the
+# round's final library, the launch this script times): query kernel (2 x 145,889 + 65,536) KB + column pass (2 x 11,670 + 131,072) KB
+PMC_TRAFFIC_BYTES_256 = int((2 * 145889 + 65536 + 2 * 11670.2 + 131072) * 1024)
 
 
 class _stdout_to_stderr:
@@ -435,8 +435,12 @@ def main():
                        'dense_points': 'generated from the grid index (avc_avatar_query_grid), offsets not written'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_TFLOPS,
-                         'traffic': None, 'traffic_note': 'HBM bytes are PMC counters of a separate rocprofv3 --pmc pass (profiles/r05_pmc_avatar.md: 0.52 GB per launch, '
-                                                           '0.087 GB algorithmic); not measurable from inside this process, hence null here',
+                         # HBM-side bytes per launch of the dense 256^3 query + its column pass: PMC counters of separate rocprofv3 --pmc passes over this very launch
+                         # with the round's final library (profiles/r05_pmc_avatar.md: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the guide's gfx950 correction); counters
+                         # cannot be read from inside this process, so the figure is that pass's, not this run's -- null for any other grid
+                         'traffic': PMC_TRAFFIC_BYTES_256 if res == 256 else None, 'traffic_unit': 'bytes per launch',
+                         'traffic_note': 'separate rocprofv3 --pmc passes of the same launch (profiles/r05_pmc_avatar.md): 0.524 GB against 0.087 GB algorithmic -- the 131 MB column '
+                                         'table written and read back, the feature map once per XCD; 0.1 % of the HBM bandwidth (the kernel is MFMA / power bound)',
                          'kernel': 'avc::avatar_kernel<true,false,1> (+ its column_terms_kernel pass, timed together)', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
                          'shader_cycles_per_launch': avg_cyc.value, 'clock_mhz': (avg_cyc.value / (avg_ms.value * 1e3)) if avg_ms.value > 0 else 0.0,
                          'cycles_per_mfma': avg_cyc.value / (4728 * -(-(N // 128) // min(N // 128, query_wgs or torch.cuda.get_device_properties(device).multi_processor_count))) if avg_cyc.value > 0 else 0.0,
