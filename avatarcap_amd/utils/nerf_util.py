@@ -6,16 +6,21 @@ import torch
 
 
 def raw2outputs(raw, z_vals, white_bkgd=False):
-    """raw (R,S,4) = [rgb, alpha], z_vals (R,S) -> rgb_map (R,3), disp_map, acc_map, weights (R,S), depth_map."""
-    rgb = raw[..., :-1]
-    alpha = raw[..., -1]
-    trans = torch.cumprod(torch.cat([torch.ones((alpha.shape[0], 1), dtype=alpha.dtype, device=alpha.device),
-                                     1. - alpha + 1e-10], -1), -1)[:, :-1]
-    weights = alpha * trans
-    rgb_map = torch.sum(weights[..., None] * rgb, -2)
-    depth_map = torch.sum(weights * z_vals, -1)
-    acc_map = torch.sum(weights, -1)
-    disp_map = 1. / torch.max(1e-10 * torch.ones_like(depth_map), depth_map / acc_map)
+    """Front-to-back alpha compositing of S samples per ray (the reference's signature and return order, nerf_util.py:185-212).
+    raw (R,S,4): colour and opacity of every sample; z_vals (R,S): their depths
+    -> rgb_map (R,3), disp_map (R,), acc_map (R,), weights (R,S), depth_map (R,)
+    weight_s = alpha_s * prod_{t < s} (1 - alpha_t + 1e-10): the transmittance in front of a sample is the EXCLUSIVE running product, written here as
+    a shifted inclusive one (multiplying by the leading 1 is exact, so the values are those of the reference's cumprod over [1, 1 - alpha + 1e-10])."""
+    colour, alpha = raw[..., :3], raw[..., 3]
+    through = (1. - alpha) + 1e-10
+    transmittance = torch.ones_like(alpha)
+    transmittance[:, 1:] = torch.cumprod(through[:, :-1], dim=-1)
+    weights = alpha * transmittance
+    acc_map = weights.sum(dim=-1)
+    depth_map = (weights * z_vals).sum(dim=-1)
+    rgb_map = (weights.unsqueeze(-1) * colour).sum(dim=-2)
     if white_bkgd:
-        rgb_map = rgb_map + (1. - acc_map[..., None])
+        rgb_map = rgb_map + (1. - acc_map).unsqueeze(-1)
+    floor = torch.full_like(depth_map, 1e-10)
+    disp_map = 1. / torch.maximum(floor, depth_map / acc_map)
     return rgb_map, disp_map, acc_map, weights, depth_map

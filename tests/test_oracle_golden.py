@@ -179,3 +179,16 @@ def test_torch_cpu_unet_and_normals_match_the_goldens(golden):
     gp = gi.grid_points_m11(107, 400)
     n = torch_cpu.vertex_normals(torch.from_numpy(vol), voxel, torch.from_numpy(gp)).numpy()
     assert maxabs(n, golden['G9_normals']) < 2e-5
+
+
+def test_host_raw2outputs_is_the_references(golden):
+    """avatarcap_amd/utils/nerf_util.py::raw2outputs (the torch compositor of the posed / temp colour branches, and the yardstick of the device compositor):
+    the reference's own outputs G11 (nerf_util.py:185-212), bit for bit -- the exclusive running product is written as a shifted inclusive one, same values."""
+    import torch
+    from avatarcap_amd.utils.nerf_util import raw2outputs
+    raw, zv = gi.raw_and_z(109, 50, 64)
+    out = raw2outputs(torch.from_numpy(raw), torch.from_numpy(zv))
+    for k, v in zip(('rgb_map', 'disp_map', 'acc_map', 'weights', 'depth_map'), out):
+        assert np.array_equal(v.numpy(), golden['G11_' + k]), k
+    white = raw2outputs(torch.from_numpy(raw), torch.from_numpy(zv), white_bkgd=True)[0].numpy()
+    assert np.array_equal(white, golden['G11_rgb_map'] + (1.0 - golden['G11_acc_map'])[:, None])
