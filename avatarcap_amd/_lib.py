@@ -206,6 +206,33 @@ def f3(v) -> C.Array:
     return (C.c_float * len(a))(*a.tolist())
 
 
+def host_f3(batch: dict, key: str, b: int = 0) -> C.Array:
+    """batch[key][b] as C floats.  The reference keeps such per-sequence constants (`cano_smpl_center`, `cano_bounds`) as device tensors of the item dict and
+    the C-ABI takes them by value: reading one back costs a drain of the stream per query.  Item dicts made by this package's loaders carry the host
+    arrays they were uploaded from under '_host' (dataset.to_cuda, frame_io.FramePrefetcher); any other dict takes the `.cpu()`."""
+    a = host_mirror(batch, key)
+    if a is not None and batch[key].shape[0] == 1:                                      # the un-batched host array of a one-frame batch
+        return f3(a)
+    return f3(batch[key][b])
+
+
+def host_mirror(batch, key):
+    """The host array batch[key] was uploaded from, or None: the dict must carry it under '_host' AND batch[key] must still be the very tensor the loader
+    put there ('_host_ids': a caller that replaces an entry of the dict gets its own tensor read, not a stale mirror)."""
+    if not isinstance(batch, dict):
+        return None
+    h, ids = batch.get('_host'), batch.get('_host_ids')
+    if h is None or ids is None or key not in h or ids.get(key) != id(batch.get(key)):
+        return None
+    v = h[key]
+    if isinstance(v, torch.Tensor):
+        if v.is_cuda:
+            return None
+        v = v.detach().numpy()
+    a = np.asarray(v, np.float32)
+    return a if a.size == batch[key].numel() else None
+
+
 # ---- weight marshalling --------------------------------------------------------------------
 def _host(t) -> np.ndarray:
     a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)

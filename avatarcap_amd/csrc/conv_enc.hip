@@ -107,6 +107,11 @@ struct ConvArgs {
     unsigned *kcounter;          // split-K: one ticket per (tile, slice)
     unsigned *range_flag;        // set to 1 when a staged value exceeds the fp16 range of the split (avc_set_range_check reads it)
     OutSpec oa, ob;              // generic outputs (the U-Net's layouts); when oa.ptr != null they replace raw / y and no statistics are produced
+    int xcd_bands;               // 8: workgroup b takes tile (b % 8) (tiles / 8) + b / 8 -- the 8 XCDs (blockIdx round-robins over them) each get a contiguous band of the
+                                 // image, so the halo rows two vertically adjacent tiles share are fetched into ONE L2 once; 0: tile = b (set only when tiles % 8 == 0)
+#ifdef AVC_ENC_PHASES
+    unsigned long long *phases;  // tools/ubench/enc_bench: [workgroup][8] s_memtime stamps (start, prologue done, main loop done, outputs stored, end)
+#endif
     int tap_mode, tap_div;       // TAPS == 4: where the 2 x 2 taps start in the 3 x 3 neighbourhood: 1 = by input parity (chunk / tap_div: stride-2 convolution
                                  // of a space-to-depth tensor, origin (1 - py, 1 - px)), 2 = by output parity (output channel / tap_div: transposed convolution, (a, b))
 };
@@ -224,10 +229,17 @@ struct ConvGeo {
     static_assert(RS >= 3, "no room for the weight ring");
 };
 
+#ifdef AVC_ENC_PHASES
+#define AVC_PHASE(k) do { if (p.phases && threadIdx.x == 0) p.phases[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AVC_PHASE(k) do { } while (0)
+#endif
+
 template <int CT, int PT, int TAPS, int TWC, bool NORM>
 __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    AVC_PHASE(0);
     using Geo = ConvGeo<PT, TAPS, TWC>;
     constexpr int PTR = Geo::PTR, ROWS = Geo::ROWS, PAD = Geo::PAD, RP = Geo::RP, HC = Geo::HC, NPIX = Geo::NPIX, KW = Geo::KW;
     constexpr int LDS_ACT0 = Geo::L_ACT0, LDS_ACT1 = Geo::L_ACT1, LDS_RING = Geo::L_RING, LDS_AB = Geo::L_AB, LDS_FLAG = Geo::L_FLAG;
@@ -238,8 +250,14 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
     const int j = lane & 31, h = lane >> 5;
     const int slices = p.Cout / (32 * CT);
     // blockIdx -> (k slice, channel slice, pixel tile): a workgroup walks the chunks [c0, c1) of the input channels (split-K launches: ksplit > 1)
-    const int ks = blockIdx.x % p.ksplit, wg = blockIdx.x / p.ksplit;
-    const int slice = wg % slices, tile = wg / slices;
+    int ks = blockIdx.x % p.ksplit, wg = blockIdx.x / p.ksplit;
+    int slice = wg % slices, tile = wg / slices;
+    if (p.xcd_bands) {                                     // workgroup b runs on XCD b % 8: that XCD's q-th workgroup takes the q-th (tile, slice, k slice) of ITS band of tiles
+        const int per = p.tiles_x * p.tiles_y / p.xcd_bands, q = blockIdx.x / p.xcd_bands;
+        ks = q % p.ksplit; slice = (q / p.ksplit) % slices;
+        tile = (blockIdx.x % p.xcd_bands) * per + q / (p.ksplit * slices);
+        wg = tile * slices + slice;
+    }
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int y0 = ty * ROWS, x0 = tx * TWC;
     const int cpk = (p.Cin >> 5) / p.ksplit, c0 = ks * cpk, c1 = c0 + cpk;
@@ -377,6 +395,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    AVC_PHASE(1);
     f32x16 acc[PT][CT];
 #pragma unroll
     for (int n = 0; n < PT; ++n)
@@ -446,6 +465,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         });
     }
 
+    AVC_PHASE(2);
     // a staged value beyond 65504 became +-inf in its `hi` half: the launch's output is not to be trusted (avc_set_range_check reports it)
     if (!(amax <= 65504.0f) && p.range_flag) atomicOr(p.range_flag, 1u);
 
@@ -608,6 +628,9 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
     else if (rawp && yp) emit(std::integral_constant<int, 1>{});
     else if (yp) emit(std::integral_constant<int, 2>{});
     else emit(std::integral_constant<int, 3>{});
+#ifdef AVC_ENC_PHASES
+    if (p.phases) { AVC_PHASE(3); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); AVC_PHASE(4); }
+#endif
 
     // ---- statistics: the two pixel halves, then the cpg adjacent channel lanes, then the four waves through LDS
     if (p.st_raw.part2 || p.st_y.part2) {
@@ -644,6 +667,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         const int ntiles = p.tiles_x * p.tiles_y, bs = p.st_raw.part2 ? p.st_raw.bsize : p.st_y.bsize;
         stats_commit(p.st_raw, ra, p.st_y, rb, p.counter + (size_t)(tile / bs) * slices + slice, tile, ntiles, tid, smem + LDS_FLAG);
     }
+    AVC_PHASE(5);
 }
 
 // ---- conv1: 7x7, stride 2, pad 3, 6 -> 64 channels, bias (HGFilters.py:134) -------------------------------------------------

@@ -712,7 +712,7 @@ int lbs_prepare(avc_ctx *ctx, const float *cano_v, int32_t nv, hipStream_t s)
     AVC_HIP(hipMemcpyAsync(host.data(), cano_v, sizeof(float) * 3 * (size_t)nv, hipMemcpyDeviceToHost, s));
     AVC_HIP(hipStreamSynchronize(s));                     // once per sequence: the box of the cells is sized on the host
     if (int rc = make_grid(ctx, b->ref, nv, nv, b->grid, s, &b->grid_mem, &b->grid_bytes)) return rc;
-    if (!b->grid.hdr || ctx->opt.knn_search != 0 || ctx->opt.lbs_reach_mm <= 0) return AVC_OK;      // a handful of vertices, or a forced search path (tests): no lists, the generic search serves
+    if (!b->grid.hdr || ctx->opt.knn_search != 0 || ctx->opt.lbs_reach_mm <= 0) { AVC_HIP(hipStreamSynchronize(s)); return AVC_OK; }      // a handful of vertices, or a forced search path (tests): no lists, the generic search serves
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int32_t i = 0; i < nv; ++i)
         for (int a = 0; a < 3; ++a) { const float v = host[(size_t)i * 3 + a]; if (v < mn[a]) mn[a] = v; if (v > mx[a]) mx[a] = v; }
@@ -751,6 +751,7 @@ int lbs_prepare(avc_ctx *ctx, const float *cano_v, int32_t nv, hipStream_t s)
     }
     hipLaunchKernelGGL(cand_list_kernel<true>, blocks, threads, 0, s, cg, b->ref, nv, radius, (int *)nullptr, cstart, b->cand);
     AVC_HIP(hipGetLastError());
+    AVC_HIP(hipStreamSynchronize(s));                     // the tables belong to the context and are read on whatever stream calculate_lbs_bound is given: complete on return
     b->cv = CandView{cstart, b->cand, cg.ox, cg.oy, cg.oz, cg.inv_h, cg.nx, cg.ny, cg.nz};
     b->ncand = total; b->ncell = ncell;
     return AVC_OK;

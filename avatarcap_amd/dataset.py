@@ -80,9 +80,12 @@ class SyntheticTestDataset:
 
 
 def to_cuda(items: dict, add_batch=False):
-    """dataset/avatarcap_dataset.py:329-346"""
+    """dataset/avatarcap_dataset.py:329-346.  The dict also keeps, under '_host', the items as they came in: the C-ABI takes per-sequence constants
+    (`cano_smpl_center`, ...) by value, and `_lib.host_f3` reads them there instead of back from the device."""
     out = {}
     for key, data in items.items():
+        if key in ('_host', '_host_ids'):
+            continue
         if isinstance(data, torch.Tensor):
             out[key] = data.to(config.device)
         elif isinstance(data, np.ndarray):
@@ -91,6 +94,8 @@ def to_cuda(items: dict, add_batch=False):
             out[key] = data
         if add_batch and isinstance(out[key], torch.Tensor):
             out[key] = out[key].unsqueeze(0)
+    out['_host'] = items.get('_host', items)
+    out['_host_ids'] = {k: id(v) for k, v in out.items() if isinstance(v, torch.Tensor)}
     return out
 
 
@@ -102,16 +107,33 @@ def synthetic_camera(img_size=512, distance=2.6, focal=None):
     return w2c, {'fx': focal, 'fy': focal, 'cx': img_size / 2.0, 'cy': img_size / 2.0, 'img_w': img_size, 'img_h': img_size}
 
 
-def synthetic_observed_normals(live_v, live_vn, faces, w2c, cam, wobble=0.25, seed=0):
+_device_consts = {}
+
+
+def _const(values, device):
+    """A small constant on the device, uploaded once per (value, device): an upload from pageable memory waits for the stream it is queued on."""
+    a = np.ascontiguousarray(values, np.float32)
+    key = (a.tobytes(), a.shape, str(device))
+    if key not in _device_consts:
+        if len(_device_consts) > 64:
+            _device_consts.clear()
+        _device_consts[key] = torch.from_numpy(a).to(device)
+    return _device_consts[key]
+
+
+def synthetic_observed_normals(live_v, live_vn, faces, w2c, cam, wobble=0.25, seed=0, axes=None):
     """What a normal-estimation network would hand over for the posed mesh, synthesised: the posed normals, bent by a smooth
-    random rotation field, in the image convention the reference undoes (camera frame with y and z negated), (H,W,3)."""
+    random rotation field, in the image convention the reference undoes (camera frame with y and z negated), (H,W,3).
+    `axes`: the (3,3) field directions already on the device (main.py's prefetch thread draws them: torch.randn under manual_seed(seed))."""
     from .utils.renderer import gl_perspective_projection_matrix, render_mesh_device
-    g = torch.Generator().manual_seed(seed)
-    ax = torch.randn(3, 3, generator=g).to(live_v.device)
+    if axes is None:
+        g = torch.Generator().manual_seed(seed)
+        axes = torch.randn(3, 3, generator=g).to(live_v.device)
+    ax = axes
     bend = wobble * torch.sin(live_v @ ax * 4.0)                                     # smooth axis-angle field over space
     n = live_vn + torch.cross(bend, live_vn, dim=-1)
     n = n / torch.linalg.norm(n, dim=-1, keepdim=True).clamp_min(1e-12)
-    R = torch.from_numpy(np.asarray(w2c, np.float32)[:3, :3]).to(live_v.device)
-    ncam = (n @ R.T) * torch.tensor([1., -1., -1.], device=live_v.device)
+    R = _const(np.asarray(w2c, np.float32)[:3, :3], live_v.device)
+    ncam = (n @ R.T) * _const([1., -1., -1.], live_v.device)
     mvp = gl_perspective_projection_matrix(cam['fx'], cam['fy'], cam['cx'], cam['cy'], cam['img_w'], cam['img_h']) @ np.asarray(w2c, np.float32)
     return render_mesh_device(live_v, ncam.contiguous(), faces, mvp, cam['img_w'], cam['img_h'])[..., :3].contiguous()

@@ -191,7 +191,7 @@ class GeoTexAvatar(nn.Module):
         for b in range(B):
             self.warping_field.bind_map(ctx, b if self.warping_field.pose_feat_map.shape[0] > 1 else 0)
             _lib.check(_lib.lib().avc_avatar_query(
-                ctx, _lib.dev_ptr(pts[b], name='cano_pts'), N, _lib.f3(batch['cano_smpl_center'][b]), sig,
+                ctx, _lib.dev_ptr(pts[b], name='cano_pts'), N, _lib.host_f3(batch, 'cano_smpl_center', b), sig,
                 occ[b].data_ptr(), off[b].data_ptr() if want_offset else None, rgba[b].data_ptr() if want_rgba else None,
                 _lib.stream_ptr(pts.device)))
         return occ, off, rgba
@@ -290,8 +290,8 @@ class NerfRenderer:
         if pts_space == 'cano' and batch['ray_o'].is_cuda:
             out = self._render_cano(batch, near_dist, far_dist, want_raw)
             valid = batch['depth'] > 1e-6                                                  # the reference's side effect on the caller's tensors (:288-290)
-            batch['near'][valid] = batch['depth'][valid] - near_dist
-            batch['far'][valid] = batch['depth'][valid] + far_dist
+            batch['near'].copy_(torch.where(valid, batch['depth'] - near_dist, batch['near']))   # in place like the reference's masked assignment, without
+            batch['far'].copy_(torch.where(valid, batch['depth'] + far_dist, batch['far']))      # the nonzero() (a stream drain) boolean indexing launches
             return out
         n_pixel = batch['ray_o'].shape[1]
         rets = []
@@ -325,7 +325,7 @@ class NerfRenderer:
             net.warping_field.bind_map(ctx, b if net.warping_field.pose_feat_map.shape[0] > 1 else 0)
             _lib.check(_lib.lib().avc_render_rays_cano(
                 ctx, ray_o[b].data_ptr(), ray_d[b].data_ptr(), near[b].data_ptr(), far[b].data_ptr(), depth[b].data_ptr(), float(near_dist), float(far_dist),
-                t_vals.data_ptr(), P, S, _lib.f3(batch['cano_smpl_center'][b]), _lib.f3(batch['cano_bounds'][b]), _lib.dev_ptr(smpl_v, name='cano_smpl_vertices'),
+                t_vals.data_ptr(), P, S, _lib.host_f3(batch, 'cano_smpl_center', b), _lib.host_f3(batch, 'cano_bounds', b), _lib.dev_ptr(smpl_v, name='cano_smpl_vertices'),
                 smpl_v.shape[0], 1 if config.if_type == 'occupancy' else 0, rgb[b].data_ptr(), acc[b].data_ptr(), dep[b].data_ptr(), None, None,
                 raw[b].data_ptr() if want_raw else None, _lib.stream_ptr(dev)))
         out = _DeviceRenderDict({'rgb_map': rgb, 'acc_map': acc, 'depth_map': dep})
@@ -380,12 +380,12 @@ class OccupancyNet:
         ax = (_lib.dev_ptr(axes[0], name='axis_x'), _lib.dev_ptr(axes[1], name='axis_y'), _lib.dev_ptr(axes[2], name='axis_z'))
         sig = 1 if config.if_type == 'occupancy' else 0
         if index is None:
-            _lib.check(_lib.lib().avc_avatar_query_grid(ctx, *ax, (C.c_int32 * 3)(*res), _lib.f3(batch['cano_smpl_center'][0]), sig,
+            _lib.check(_lib.lib().avc_avatar_query_grid(ctx, *ax, (C.c_int32 * 3)(*res), _lib.host_f3(batch, 'cano_smpl_center', 0), sig,
                                                         occ.data_ptr(), off.data_ptr() if want_offset else None, _lib.stream_ptr(dev)))
         else:
             if index.dtype != torch.int32 or not index.is_contiguous() or index.device != dev:
                 raise TypeError('query_grid: index must be a contiguous int32 tensor on the device of the axis tables')
-            _lib.check(_lib.lib().avc_avatar_query_grid_subset(ctx, *ax, (C.c_int32 * 3)(*res), index.data_ptr(), N, _lib.f3(batch['cano_smpl_center'][0]), sig,
+            _lib.check(_lib.lib().avc_avatar_query_grid_subset(ctx, *ax, (C.c_int32 * 3)(*res), index.data_ptr(), N, _lib.host_f3(batch, 'cano_smpl_center', 0), sig,
                                                                occ.data_ptr(), off.data_ptr() if want_offset else None, _lib.stream_ptr(dev)))
         out = {'cano_pts_ov': occ}
         if want_offset:

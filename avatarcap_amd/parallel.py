@@ -352,6 +352,39 @@ def leave_cus_for_the_exchange(device, spare: int = 8, log=None) -> int:
     return n
 
 
+def set_spare_cus(device, spare: int) -> int:
+    """`leave_cus_for_the_exchange` that can also take the CUs back (spare 0 -> one workgroup per CU again): what the warm-up's A/B switches between."""
+    from . import _lib
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    n = 0 if spare <= 0 else max(1, cus - spare)
+    _lib.set_option('mlp_blocks', n, device)
+    return n
+
+
+def choose_exchange_config(candidates: list, measure, group=None, tolerance: float = 0.02, device=None) -> dict:
+    """The first multi-GPU run tunes itself: `candidates` is an ordered list of hashable configurations -- here (transport,
+    spare CUs) -- and `measure(candidate)` returns this rank's seconds for a few steps under it (the caller brackets it with barriers).  Every
+    candidate's time is the MAX over the ranks (one all-reduce of the whole table, so every rank decides on identical numbers); the choice is the
+    EARLIEST candidate within `tolerance` of the fastest -- the list order is the preference (the documented default first), and a later candidate
+    has to win by more than noise to displace an earlier one.  Deterministic: same table, same order, same answer on every rank.
+    -> {'choice': candidate, 'index': i, 'table_ms': [...], 'ranks': world}."""
+    times = []
+    for c in candidates:
+        times.append(float(measure(c)))
+    t = torch.tensor(times, dtype=torch.float64)
+    world = 1
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        if dist.get_backend(group) == 'nccl':
+            t = t.to(device if device is not None else torch.device('cuda', torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        t = t.cpu()
+    table = t.tolist()
+    best = min(table)
+    index = next(i for i, v in enumerate(table) if v <= best * (1.0 + tolerance))
+    return {'choice': candidates[index], 'index': index, 'table_ms': [v * 1e3 for v in table], 'ranks': world}
+
+
 def pin_to_gpu_numa(device_index: int, local_world: int = 1, log=None) -> dict:
     """CPU affinity of this rank := the cores of its GPU's NUMA node (/sys/bus/pci/devices/<bdf>/numa_node), split evenly among the ranks that share
     the node, and OMP / MKL threads to match: eight Python ranks on one host otherwise migrate across sockets and oversubscribe each other (bench.py's

@@ -50,6 +50,15 @@ def fill_volume(values: torch.Tensor, valid_u8: torch.Tensor, invalid_ov: torch.
     return vol
 
 
+def _host_center(items: dict):
+    """items['cano_smpl_center'] as the (1,3) host array it was uploaded from when the item dict carries it ('_host': dataset.to_cuda,
+    frame_io.FramePrefetcher), else the device tensor (read back by the callee, one stream drain)."""
+    c = _lib.host_mirror(items, 'cano_smpl_center')
+    if c is not None and items['cano_smpl_center'].shape[0] == 1:
+        return c.reshape(1, 3)
+    return items['cano_smpl_center']
+
+
 class FramePipeline:
     """Holds the networks and the per-sequence constants; `avatar_frame` / `recon_frame` are steps
     1 and 3 of main.py's loop body."""
@@ -190,16 +199,17 @@ class FramePipeline:
         """3. reconstruction network (main.py:438-453); items must hold front_normal / back_normal."""
         kind = self._grid_items(items)
         rn = self.recon_net
+        center = _host_center(items)                                                               # by value into the C-ABI: no read-back of a device tensor
         with _stage('avc/hgfilter'):
             imgs = torch.cat([items['front_normal'], items['back_normal']], dim=1)                 # arch_recon.py:51-53
             img_feat_map = rn.bind_feat_map(imgs)                                                  # the encoder's channel-last output IS the decoder's map
         with _stage('avc/recon_query'):
             if kind == 'dense':
-                out = rn.decode_grid(self.ds.grid_axes, self.vol_res, img_feat_map, items['cano_smpl_center'])                      # :440, on the grid (column-folded)
+                out = rn.decode_grid(self.ds.grid_axes, self.vol_res, img_feat_map, center)                      # :440, on the grid (column-folded)
             elif kind == 'band':
-                out = rn.decode_grid(self.ds.grid_axes, self.vol_res, img_feat_map, items['cano_smpl_center'], index=self.ds.valid_idx)
+                out = rn.decode_grid(self.ds.grid_axes, self.vol_res, img_feat_map, center, index=self.ds.valid_idx)
             else:
-                out = rn.decode(items['cano_pts'].contiguous(), img_feat_map, items['cano_smpl_center'])                             # :440
+                out = rn.decode(items['cano_pts'].contiguous(), img_feat_map, center)                             # :440
         with _stage('avc/marching_cubes'):
             vol = fill_volume(out[0], self.ds.valid_u8, self.ds.invalid_pts_ov)                    # :442-443 (output[0])
             v, f, n = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds)         # :444 (iso 0.5)
@@ -247,10 +257,10 @@ class FramePipeline:
                                                         np.asarray(w2c_RT, np.float32), cam['fx'], cam['fy'], cam['cx'], cam['cy'], center)   # :413-415
         if integrate_manner == 'merge':
             cv = smpl_util.cano_smpl_vertices
-            key = (cv.data_ptr(), cv._version)
-            if getattr(self, '_neck', (None,))[0] != key:          # per sequence, not per frame: the read drains the stream
-                self._neck = (key, cv[3068].cpu().numpy())
-            neck_vert = self._neck[1] - np.asarray(center, np.float32)                                                                  # :418
+            nk = getattr(self, '_neck', None)       # per sequence, not per frame (the read drains the stream); keyed on the tensor ITSELF (kept alive here) and its
+            if nk is None or nk[0] is not cv or nk[1] != cv._version:      # version -- a device address is handed out again once the old vertex set is freed
+                self._neck = nk = (cv, cv._version, cv[3068].cpu().numpy())
+            neck_vert = nk[2] - np.asarray(center, np.float32)                                                                  # :418
             neck_y = int((1. - neck_vert[1]) / 2. * 512)                                                                                # :419
             neck_x = int((neck_vert[0] - 1) / 2. * 512)                                                                                 # :420 (negative: wraps, like the reference's slice)
             front = merge_normal_images_device(front_avatar, front_image, iter_num, (neck_x, neck_y))                                   # :421

@@ -6,6 +6,50 @@ from __future__ import annotations
 import numpy as np
 
 
+def ply_header(n_vertices, n_faces, normals=True, colors=False) -> bytes:
+    """The header `save_mesh_as_ply` writes (obj_io.py:225-238)."""
+    header = ['ply', 'format binary_little_endian 1.0', 'element vertex %d' % n_vertices, 'property float x', 'property float y', 'property float z']
+    if normals:
+        header += ['property float nx', 'property float ny', 'property float nz']
+    if colors:
+        header += ['property uchar red', 'property uchar green', 'property uchar blue']
+    header += ['element face %d' % n_faces, 'property list int int vertex_indices', 'end_header']
+    return ('\n'.join(header) + '\n').encode('ascii')
+
+
+def ply_records_device(vertices, faces=None, normals=None, colors=None):
+    """The byte payload of `save_mesh_as_ply` assembled ON THE DEVICE: -> (header bytes, {'vrec': (V, 12|24|15|27) uint8, 'frec': (F, 4) int32}).
+    The per-vertex records `3f [3f] [3B]` and the per-face records `int 3 + 3 int` (obj_io.py:249-268) are two concatenations there; what crosses to
+    the host is the file's own bytes, and the writer thread does nothing but `write` (avatarcap_amd.frame_io.MeshWriter).  The colour rule of :246-248
+    (floats below 1 are scaled by 255, then truncated to bytes) is evaluated without reading the maximum back."""
+    import torch
+    V = int(vertices.shape[0])
+    cols = [vertices.to(torch.float32).contiguous().reshape(-1).view(torch.uint8).view(V, 12)]
+    if normals is not None:
+        cols.append(normals.to(torch.float32).contiguous().reshape(-1).view(torch.uint8).view(V, 12))
+    if colors is not None:
+        c = colors.to(torch.float32)
+        scale = torch.where(c.max() < 1., 255., 1.).to(torch.float32) if V else 1.
+        cols.append((c * scale).to(torch.uint8).contiguous().view(V, 3))
+    out = {'vrec': torch.cat(cols, dim=1) if len(cols) > 1 else cols[0]}
+    F = 0
+    if faces is not None:
+        F = int(faces.shape[0])
+        f = faces.to(torch.int32)
+        out['frec'] = torch.cat([torch.full((F, 1), 3, dtype=torch.int32, device=f.device), f], dim=1)
+    return ply_header(V, F, normals is not None, colors is not None), out
+
+
+def write_ply_records(path, header: bytes, arrays: dict, prefix: str = ''):
+    """Writer-thread half of `ply_records_device`."""
+    with open(path, 'wb') as fp:
+        fp.write(header)
+        for key in ('vrec', 'frec'):
+            a = arrays.get(prefix + key)
+            if a is not None and a.size:
+                fp.write(memoryview(np.ascontiguousarray(a).reshape(-1)).cast('B'))
+
+
 def save_mesh_as_ply(path, vertices, faces=None, normals=None, colors=None):
     vertices = np.asarray(vertices, np.float32)
     fields = [('x', '<f4'), ('y', '<f4'), ('z', '<f4')]

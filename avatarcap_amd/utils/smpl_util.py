@@ -39,8 +39,12 @@ class SmplUtil:
         lists are built once per sequence, not once per calculate_lbs call)."""
         self.cano_smpl_vertices = cano_smpl_vertices.to(torch.float32).to(config.device).contiguous()
         self._bound = None
-        if self.cano_smpl_vertices.is_cuda:
-            self._bind(self.cano_smpl_vertices.device)
+        v = self.cano_smpl_vertices
+        if v.is_cuda and v.dim() == 2 and v.shape[0] >= 4:      # what calculate_lbs binds; anything else stays unbound and takes the search per call,
+            try:                                                  # and the setter never raises (smpl_util.py:21-22): a set that cannot be bound (non-finite
+                self._bind(v.device)                              # vertices) is reported by the calculate_lbs that needs it
+            except _lib.AvcapError:
+                self._bound = None
 
     def _bind(self, device):
         """The device context holds ONE bound vertex set.  The binder keeps a token of its own (a process-wide counter: neither `id()` nor a device address,
@@ -50,6 +54,7 @@ class SmplUtil:
         ctx = _lib.ctx(device)
         b = getattr(self, '_bound', None)
         if b is None or b[1] is not v or b[2] != v._version or not _lib.owns(ctx, 'lbs_bound', b[0]):
+            _lib.set_owner(ctx, 'lbs_bound', None)       # lbs_prepare overwrites the context's tables before it can fail: nobody owns them until it has succeeded
             _lib.check(_lib.lib().avc_lbs_prepare(ctx, _lib.dev_ptr(v, name='cano_smpl_vertices'), v.shape[0], _lib.stream_ptr(device)))
             token = next(_bind_tokens)
             _lib.set_owner(ctx, 'lbs_bound', token)

@@ -285,7 +285,9 @@ def main():
     ap.add_argument('--no-masked', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help='skip the BASELINE configs[2] / configs[3] legs of the line')
     ap.add_argument('--dist-timeout', type=float, default=180.0, help='seconds after which a rendezvous / collective that does not complete ends the job')
-    ap.add_argument('--spare-cus', type=int, default=8, help='N > 1: CUs the persistent query kernels leave to the exchange (0: none; AVC_MLP_BLOCKS wins)')
+    ap.add_argument('--spare-cus', type=int, default=None, help='N > 1: CUs the persistent query kernels leave to the exchange (0: none; AVC_MLP_BLOCKS wins); '
+                                                                'default: chosen by the warm-up A/B (8, 4 or 0)')
+    ap.add_argument('--no-autotune', action='store_true', help='N > 1: no warm-up A/B of the exchange transport / spare CUs (p2p, 8 unless set otherwise)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -324,7 +326,7 @@ def main():
     if world > 1:
         pin_to_gpu_numa(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))       # each rank on the cores of its GPU's NUMA node
         from avatarcap_amd.parallel import leave_cus_for_the_exchange
-        query_wgs = leave_cus_for_the_exchange(device, args.spare_cus)                    # RCCL's copy kernels need somewhere to run beside the query
+        query_wgs = leave_cus_for_the_exchange(device, 8 if args.spare_cus is None else args.spare_cus)   # RCCL's copy kernels need somewhere to run beside the query
     K, W, res = args.steps, args.warmup, args.res
     n_frames = world * (K + W)
     pipe, sd = build_pipeline(res, 'dense', n_frames, device)
@@ -349,12 +351,51 @@ def main():
         with _stdout_to_stderr():
             all_gather_meshes([warm], world, force=force_dist)
             torch.cuda.synchronize()
+    # ---- N > 1: the first run on a multi-GPU box tunes itself.  Nobody has run this path on more than one GPU (no such box was available to the build), so
+    # the transport of the mesh exchange (point-to-point sends, one xGMI link per pair, vs `world` broadcasts) and the CUs the persistent query leaves to
+    # RCCL's copy kernels (8, 4, 0) are not guesses but a warm-up A/B: two frames + their exchange under each setting, MAX over the ranks, the earliest
+    # setting within 2 % of the fastest (parallel.choose_exchange_config).  Untimed; what was chosen and the whole table go on the line.
+    exchange_mode = os.environ.get('AVC_EXCHANGE', 'p2p')
+    autotune = None
+    if (world > 1 or force_dist) and not args.no_autotune:
+        from avatarcap_amd.parallel import choose_exchange_config, set_spare_cus
+        modes = [os.environ['AVC_EXCHANGE']] if os.environ.get('AVC_EXCHANGE') else ['p2p', 'broadcast']
+        spares = [args.spare_cus] if (args.spare_cus is not None or os.environ.get('AVC_MLP_BLOCKS')) else [8, 4, 0]
+        cands = [(m, sp) for m in modes for sp in spares]
+
+        def measure(c, steps=2):
+            mode, spare = c
+            if spare is not None and not os.environ.get('AVC_MLP_BLOCKS'):
+                set_spare_cus(device, spare)
+            ex_ = MeshExchange(world * (steps + 1), force=force_dist, mode=mode)
+            pipe.exchange = ex_
+            t_ = 0.0
+            for s_ in range(steps + 1):                      # one step to settle (the transport's connections, the allocator), then `steps` timed
+                if s_ == 1:
+                    barrier('warm-up A/B')
+                    t_ = time.perf_counter()
+                o_ = pipe.avatar_frame(my[s_ % len(my)])
+                ex_.submit({'v': o_['live_v'], 'vn': o_['live_vn'], 'f': o_['f']})
+            pipe.exchange = None
+            ex_.finish()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t_
+
+        if len(cands) > 1:
+            with _stdout_to_stderr():
+                autotune = choose_exchange_config(cands, measure, device=device)
+            exchange_mode, spare = autotune['choice']
+            autotune = {'candidates': [list(c) for c in cands], 'warmup_ab_ms': autotune['table_ms'], 'choice': [exchange_mode, spare],
+                        'rule': 'two frames + exchange per setting after one settling step, MAX over ranks, earliest setting within 2 % of the fastest'}
+            if not os.environ.get('AVC_MLP_BLOCKS'):
+                query_wgs = set_spare_cus(device, spare)
+        pipe._next_map = None
     barrier('start of the timed region')
     _lib.check(_lib.lib().avc_timing_enable(ctx, 1))
     t0 = time.perf_counter()
     # the batch's meshes are exchanged step by step WHILE the following frames compute (parallel.MeshExchange: exact sizes, asynchronous
     # point-to-point sends on RCCL's stream); what is left behind the last frame is that frame's own mesh
-    ex = MeshExchange(world * K, force=force_dist) if (world > 1 or force_dist) else None
+    ex = MeshExchange(world * K, force=force_dist, mode=exchange_mode) if (world > 1 or force_dist) else None
     pipe.exchange = ex                              # avatar_frame pumps it behind its query launch: step s - 1 travels while frame s computes
     for s in range(W, W + K):
         out = pipe.avatar_frame(my[s], next_items=my[s + 1] if s + 1 < W + K else None)
@@ -425,7 +466,8 @@ def main():
                        'grid': [res] * 3, 'points_per_frame': N, 'vertices_last_frame': int(out['cano_v'].shape[0]),
                        'faces_last_frame': int(out['f'].shape[0]), 'parallelism': f'frame-sharded x{world}',
                        'frames_in_batch': world * K, 'meshes_all_gathered': bool(world > 1 or force_dist),
-                       'query_workgroups': query_wgs or 'one per CU', 'exchange_transport': os.environ.get('AVC_EXCHANGE', 'p2p') if (world > 1 or force_dist) else None,
+                       'query_workgroups': query_wgs or 'one per CU', 'exchange_transport': exchange_mode if (world > 1 or force_dist) else None,
+                       'exchange_autotune': autotune,
                        'mesh_exchange': 'exact-size point-to-point sends per step (every pair of GPUs over its own xGMI link), issued from a side stream behind the NEXT frame\'s query launch (parallel.MeshExchange.pump): '
                                         'K - 1 of a rank\'s K steps travel beside compute, the last one is `exchange_tail_ms`; `meshes_verified`: per-frame integer checksums '
                                         'of every received mesh against its owner\'s, checked on every rank outside the timed region',

@@ -12,6 +12,11 @@
 and writes the meshes as PLY (obj_io.save_mesh_as_ply, :491-498) and .npz.  Not done here: the OpenGL Phong previews written as .jpg
 (:391-399, :500-504 -- visualisation).
 
+The loop is asynchronous on both ends (avatarcap_amd.frame_io): a worker thread loads the item dicts two frames ahead and uploads each with ONE
+non-blocking copy from a pinned staging buffer on a copy stream; the finished meshes leave through pinned slots on the same copy stream and are written by
+writer threads.  The loop thread itself only waits where marching cubes reads its counts.  `--sync-io` is the reference's shape of the loop (blocking
+`to_cuda`, `.cpu()`, files written inline) for comparison; `--timing-json` writes what the loop measured about itself.
+
 Multi-GPU (the reference has none): `--gpus N` (or a torchrun / torch.distributed.run launch) shards the frame list, frame k of it
 on rank k mod N, one process per GPU; every rank writes the files of its own frames (names carry the data index, so ranks never collide);
 `--gather-meshes` additionally all-gathers the batch's live avatar meshes over RCCL and has rank 0 write `<output_dir>/all_avatar_meshes.npz`.
@@ -30,8 +35,9 @@ import numpy as np
 import torch
 
 
-def _observed_normals(ds, data_idx, view_idx, device):
-    """The image-observed normal map of step 2 (main.py:406-411): cv.imread(<...>.exr, IMREAD_UNCHANGED) -> (H, W, 3) on the device."""
+def _observed_normals_host(ds, data_idx, view_idx):
+    """The image-observed normal map of step 2 (main.py:406-411): cv.imread(<...>.exr, IMREAD_UNCHANGED) -> (H, W, 3) float32, on the host (the prefetch
+    thread uploads it with the rest of the frame's item dict)."""
     from avatarcap_amd.utils.exr_io import read_exr
     if ds.data_config['data_type'] == 'synthetic':
         path = ds.data_dir + '/imgs/%03d/normal_view_%03d.exr' % (data_idx, view_idx)
@@ -39,7 +45,7 @@ def _observed_normals(ds, data_idx, view_idx, device):
         path = ds.data_dir + '/imgs/normal/normal_%04d.exr' % data_idx
     else:
         raise ValueError('Invalid data type!')
-    return torch.from_numpy(np.ascontiguousarray(read_exr(path)[..., :3], np.float32)).to(device)
+    return np.ascontiguousarray(read_exr(path)[..., :3], np.float32)
 
 
 class _StandInPipeline:
@@ -65,7 +71,8 @@ class _StandInPipeline:
 
 def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w_nerf=False, frame_idx=None, view_idx=0, interval=1,
                   synthetic=False, n_frames=2, valid='band', integrate_manner='merge', rank=0, world=1, gather_meshes=False, gather_batch=8,
-                  dry_run=False, dry_fail=(), max_failure_streak=3, force_dist=False):
+                  dry_run=False, dry_fail=(), max_failure_streak=3, force_dist=False, save_npz=True, sync_io=False, io_threads=3, io_slots=4,
+                  timing=None):
     from avatarcap_amd import config, parallel
     cfg = config.cfg
     out_dir = cfg['testing']['output_dir']
@@ -77,7 +84,7 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
         pipe, ds, renderer = _StandInPipeline(dry_fail), None, None
         w_recon = w_nerf = False
         img_num_per_pose, start_data_idx, data_num = 1, 0, n_frames
-        load = lambda i: {'data_idx': i}                                          # noqa: E731
+        load_host = lambda i: {'data_idx': i}                                     # noqa: E731
     else:
         from avatarcap_amd import synthetic as syn
         from avatarcap_amd.dataset import SyntheticTestDataset, to_cuda
@@ -112,7 +119,16 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
             print('# Data num: %d' % data_num)
         pipe = FramePipeline(network, ds, recon_net)
         renderer = NerfRenderer(nerf_net) if nerf_net is not None else None
-        load = lambda i: to_cuda(ds[i * img_num_per_pose + view_idx], add_batch=True)     # main.py:349-351   # noqa: E731
+
+        def load_host(i):
+            """Everything of frame i that is read or made on the host (main.py:349-351 and the image-observed normal map of :406-411): runs on the
+            prefetch thread, two frames ahead of the device."""
+            item = dict(ds[i * img_num_per_pose + view_idx])
+            if w_recon and synthetic:       # the stand-in of the captured normal map bends the posed normals by a seeded field (dataset.synthetic_observed_normals)
+                item['observed_bend_axes'] = torch.randn(3, 3, generator=torch.Generator().manual_seed(i)).numpy()
+            elif w_recon:
+                item['observed_normal'] = _observed_normals_host(ds, int(item['data_idx']), view_idx)
+            return item
 
     if frame_idx is None:                                                        # main.py:337-345
         frames = list(range(0, data_num, interval))
@@ -123,13 +139,16 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
     else:
         raise TypeError('Invalid frame_idx!')
 
-    loaded = {}                                                                  # one frame of look-ahead: items of the frame this rank runs next
-
-    def items_of(i):
-        if i not in loaded:
-            loaded.clear()
-            loaded[i] = load(i)
-        return loaded[i]
+    # Host work off the critical path (avatarcap_amd.frame_io): the item dicts of this rank's frames are loaded and uploaded two frames ahead by a worker
+    # thread (one pinned staging buffer, one non-blocking copy per frame), the finished meshes leave through pinned slots to writer threads.
+    import time
+    from avatarcap_amd.frame_io import FramePrefetcher, MeshWriter
+    dev = None if dry_run else config.device
+    mine = [frames[j] for j in parallel.shard_frames(len(frames), rank, world)]
+    prefetch = FramePrefetcher(load_host, mine, dev, depth=1 if sync_io else 2)
+    writer = MeshWriter(dev, slots=io_slots, threads=io_threads)
+    clock = {'start': [], 'bytes_written': 0, 'files': 0}
+    lock = __import__('threading').Lock()
 
     # Weights read from disk have never been through the kernels: the split-fp16 arithmetic of the fused queries is exact only while every feature
     # and activation stays below 65504 (include/avcap.h, "numeric range"), and an overflow is SILENT (a ReLU swallows the NaN).  The first frame
@@ -140,20 +159,21 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
     check = {'user': bool(getattr(config, 'check_range', False)), 'pending': not (synthetic or dry_run)}
 
     def process(k, i, nxt_i):
+        clock['start'].append(time.perf_counter())
         checking = check['user'] or check['pending']
         config.check_range = checking
-        items = items_of(i)
-        nxt = None
-        if nxt_i is not None:
-            try:
-                nxt = load(nxt_i)           # its U-Net is queued behind this frame's query (FramePipeline.avatar_frame)
-            except Exception:               # noqa: BLE001 -- the next frame's own turn will report what is wrong with it
-                nxt = None
+        try:
+            items = prefetch.get(i)
+            if sync_io and dev is not None:
+                torch.cuda.synchronize(dev)                   # the reference's blocking to_cuda
+            nxt = prefetch.peek(nxt_i)      # its U-Net is queued behind this frame's query (FramePipeline.avatar_frame); None: its own turn reports what is wrong
+            return frame(k, i, items, nxt, checking)
+        finally:
+            prefetch.drop(i)
+
+    def frame(k, i, items, nxt, checking):
         data_idx = int(items['data_idx'])
         a = pipe.avatar_frame(items, next_items=nxt)                              # step 1
-        loaded.clear()
-        if nxt is not None:
-            loaded[nxt_i] = nxt
         save = {'cano_v': a['cano_v'], 'cano_vn': a['cano_vn'], 'f': a['f'], 'live_v': a.get('live_v'), 'live_vn': a.get('live_vn')}
         if w_recon:
             # step 2: canonical normal fusion (main.py:405-433)
@@ -161,11 +181,11 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
                 if synthetic:       # the captured image's normal map is synthesised (dataset.synthetic_observed_normals)
                     from avatarcap_amd.dataset import synthetic_camera, synthetic_observed_normals
                     w2c, cam = synthetic_camera()
-                    observed = synthetic_observed_normals(a['live_v'], a['live_vn'], a['f'], w2c, cam, seed=i)
+                    observed = synthetic_observed_normals(a['live_v'], a['live_vn'], a['f'], w2c, cam, seed=i, axes=items['observed_bend_axes'][0])
                 else:
                     cam = ds.data_config['camera']
-                    w2c = items['w2c_RT'][0].cpu().numpy() if isinstance(items['w2c_RT'], torch.Tensor) else np.asarray(items['w2c_RT'], np.float32)
-                    observed = _observed_normals(ds, data_idx, view_idx, config.device)
+                    w2c = np.asarray(items['_host']['w2c_RT'], np.float32)          # as loaded: no read-back of what was just uploaded
+                    observed = items['observed_normal'][0]
                 items['front_normal'], items['back_normal'], _ = pipe.fuse_normals(a, observed, w2c, cam, integrate_manner)
             else:
                 items['front_normal'], items['back_normal'] = pipe.cano_normal_maps(a['cano_v'], a['cano_vn'], a['f'])
@@ -175,17 +195,39 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
             save['live_vc'] = pipe.colour_vertices(items, a['cano_v'], a['cano_vn'], renderer)
             if w_recon and save['recon_cano_v'].shape[0] > 0 and a['cano_v'].shape[0] > 0:        # main.py:478-482
                 save['recon_live_vc'] = pipe.transfer_colours(save['recon_cano_v'], a['cano_v'], save['live_vc'])
+        # ---- outputs (main.py:491-498): the file bytes are assembled on the device (obj_io.ply_records_device), copied out behind the frame's kernels
+        # and written by the writer threads; nothing here waits for the device
+        from avatarcap_amd.utils import obj_io
+        out_t, plys = {}, []
+        if save_npz:
+            out_t.update({k_: v for k_, v in save.items() if v is not None})
         if save_avatar_mesh and a.get('live_v') is not None:                          # main.py:491-493
-            from avatarcap_amd.utils import obj_io
-            obj_io.save_mesh_as_ply('%s/%04d_avatar.ply' % (out_dir, data_idx), a['live_v'].cpu().numpy(), a['f'].cpu().numpy(),
-                                    a['live_vn'].cpu().numpy(), save['live_vc'].cpu().numpy() if w_nerf else None)
-        if w_recon and save_final_mesh and 'recon_live_v' in save:                     # main.py:495-498
-            from avatarcap_amd.utils import obj_io
-            obj_io.save_mesh_as_ply('%s/%04d_recon.ply' % (out_dir, data_idx), save['recon_live_v'].cpu().numpy(),
-                                    save['recon_f'].cpu().numpy(), save['recon_live_vn'].cpu().numpy(),
-                                    save['recon_live_vc'].cpu().numpy() if 'recon_live_vc' in save else None)
-        np.savez(os.path.join(out_dir, '%04d_mesh.npz' % data_idx),
-                 **{k_: v.cpu().numpy() for k_, v in save.items() if v is not None})
+            hdr, rec = obj_io.ply_records_device(a['live_v'], a['f'], a['live_vn'], save['live_vc'] if w_nerf else None)
+            out_t.update({'avatar.' + k_: v for k_, v in rec.items()})
+            plys.append(('%s/%04d_avatar.ply' % (out_dir, data_idx), hdr, 'avatar.'))
+        if w_recon and save_final_mesh and save.get('recon_live_v') is not None:      # main.py:495-498
+            hdr, rec = obj_io.ply_records_device(save['recon_live_v'], save['recon_f'], save['recon_live_vn'], save.get('recon_live_vc'))
+            out_t.update({'recon.' + k_: v for k_, v in rec.items()})
+            plys.append(('%s/%04d_recon.ply' % (out_dir, data_idx), hdr, 'recon.'))
+        npz_keys = [k_ for k_ in save if save[k_] is not None] if save_npz else []
+
+        def write(arrays, data_idx=data_idx, plys=plys, npz_keys=npz_keys):
+            n = 0
+            if npz_keys:
+                path = os.path.join(out_dir, '%04d_mesh.npz' % data_idx)
+                np.savez(path, **{k_: arrays[k_] for k_ in npz_keys})
+                n += os.path.getsize(path)
+            for path, hdr, prefix in plys:
+                obj_io.write_ply_records(path, hdr, arrays, prefix)
+                n += os.path.getsize(path)
+            with lock:
+                clock['bytes_written'] += n
+                clock['files'] += len(plys) + (1 if npz_keys else 0)
+
+        if out_t:
+            writer.submit(out_t, write, tag=i)
+            if sync_io:
+                writer.drain()                                # the reference's shape: .cpu() and the file writes inside the frame
         log('# %sframe %d (data idx %d): avatar %d verts / %d faces%s' % ('rank %d: ' % rank if world > 1 else '', i, data_idx, a['cano_v'].shape[0],
             a['f'].shape[0], (', recon %d verts' % save['recon_cano_v'].shape[0]) if w_recon else ''))
         if checking:
@@ -198,7 +240,6 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
     # WHILE the following frames compute (parallel.MeshExchange: exact sizes, asynchronous), in batches of `gather_batch` steps so that a long
     # sequence does not pile every mesh of every rank up in HBM: after a batch rank 0 moves it to host memory and the device copies are dropped.
     # A failed or unattempted frame travels as an empty mesh, so the ranks' steps stay aligned.
-    dev = None if dry_run else config.device
     gathered = {}                                            # rank 0: frame -> {'v', 'vn', 'f'} numpy
     gather = {'ex': None, 'step': 0}
     steps = (len(frames) + world - 1) // world
@@ -242,6 +283,33 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
         return mesh
 
     summary = parallel.run_sharded(frames, process_and_submit, rank, world, log, max_consecutive_failures=max_failure_streak)
+    t_enqueued = time.perf_counter()
+    if dev is not None and not gather.get('dead'):
+        torch.cuda.synchronize(dev)
+    t_device = time.perf_counter()
+    for fr, why in writer.close():                             # a frame whose files could not be written has failed
+        if fr in summary['done']:
+            summary['done'].remove(fr)
+        summary['failed'].append((fr, 'output: ' + why))
+        log(f'# rank {rank}: frame {fr} FAILED while its files were written -- {why}')
+    t_written = time.perf_counter()
+    prefetch.close()
+    if timing is not None:
+        # what the loop measured about itself: the first frames pay for first-use work (launch plans, hipGraph capture, pinned allocations), so the steady
+        # figure starts at frame `skip`; `e2e` ends when the last file is on its way to the disk (closed by the writer threads), `device` when the
+        # last kernel has finished
+        n, st = len(clock['start']), clock['start']
+        skip = min(2, max(0, n - 1))
+        timing.update({
+            'frames': n, 'frames_failed': len(summary['failed']), 'skipped_first': skip, 'sync_io': bool(sync_io),
+            'outputs': {'npz': bool(save_npz), 'ply_avatar': bool(save_avatar_mesh), 'ply_recon': bool(save_final_mesh and w_recon)},
+            'e2e_ms_per_frame': (t_written - st[skip]) / (n - skip) * 1e3 if n > skip else None,
+            'device_ms_per_frame': (t_device - st[skip]) / (n - skip) * 1e3 if n > skip else None,
+            'host_enqueue_ms_per_frame': (t_enqueued - st[skip]) / (n - skip) * 1e3 if n > skip else None,
+            'writer_tail_ms': (t_written - t_device) * 1e3, 'first_frame_ms': (st[1] - st[0]) * 1e3 if n > 1 else None,
+            'bytes_written': clock['bytes_written'], 'files_written': clock['files'], 'd2h_bytes': writer.d2h_bytes,
+            'h2d_copies': prefetch.h2d_copies, 'h2d_bytes': prefetch.h2d_bytes, 'waited_for_writer_slot_ms': writer.waited_for_slot_s * 1e3,
+            'io_threads': io_threads, 'io_slots': io_slots, 'output_dir': out_dir, 'vol_res': None if dry_run else list(cfg['testing']['vol_res'])})
     if gather.get('dead') and world > 1:
         log('# rank %d: device lost (%s) -- leaving the job without touching the process group; the launcher stops the other ranks' % (rank, gather['dead']))
         sys.stdout.flush(); sys.stderr.flush()
@@ -274,6 +342,11 @@ def main(argv=None):
     arg_parser.add_argument('--frames', type=int, default=2)
     arg_parser.add_argument('--valid', type=str, default='band', choices=['band', 'dense'])
     arg_parser.add_argument('--save-ply', action='store_true', help='write the live avatar / recon meshes as PLY (obj_io layout)')
+    arg_parser.add_argument('--no-npz', action='store_true', help='do not write <idx>_mesh.npz (every mesh tensor of the frame)')
+    arg_parser.add_argument('--sync-io', action='store_true', help="the reference's loop shape: blocking upload, .cpu(), files written inside the frame (for comparison)")
+    arg_parser.add_argument('--io-threads', type=int, default=3, help='writer threads behind the loop')
+    arg_parser.add_argument('--io-slots', type=int, default=4, help='finished frames that may wait for the disk (pinned slots) before the loop does')
+    arg_parser.add_argument('--timing-json', type=str, default=None, help='write what the frame loop measured about itself (rank 0) to this file')
     arg_parser.add_argument('--nerf', action='store_true', help='also evaluate vertex colours (w_nerf)')
     arg_parser.add_argument('--integrate', type=str, default='merge', choices=['merge', 'cover'], help='normal fusion manner (main.py:281)')
     arg_parser.add_argument('--gpus', type=int, default=0, help='shard the frames over this many GPUs of the node (one process each); 0: whatever launched us')
@@ -321,11 +394,19 @@ def main(argv=None):
             parallel.pin_to_gpu_numa(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)), log=print if rank == 0 else None)
             if args.gather_meshes:
                 parallel.leave_cus_for_the_exchange(config.device, log=print if rank == 0 else None)
+    timing = {} if args.timing_json else None
     try:
         n_failed = run_avatarcap(w_recon=True, save_avatar_mesh=args.save_ply, save_final_mesh=args.save_ply, w_nerf=args.nerf,
                                  synthetic=args.synthetic, n_frames=args.frames, valid=args.valid, integrate_manner=args.integrate,
                                  rank=rank, world=world, gather_meshes=args.gather_meshes, gather_batch=max(1, args.gather_batch), dry_run=args.dry_run,
-                                 dry_fail=args.dry_fail, max_failure_streak=args.max_failure_streak, force_dist=force_dist)
+                                 dry_fail=args.dry_fail, max_failure_streak=args.max_failure_streak, force_dist=force_dist,
+                                 save_npz=not args.no_npz, sync_io=args.sync_io, io_threads=max(1, args.io_threads), io_slots=max(1, args.io_slots),
+                                 timing=timing)
+        if timing is not None and rank == 0:
+            import json
+            timing.update({'world': world, 'argv': list(sys.argv[1:] if argv is None else argv)})
+            with open(args.timing_json, 'w') as fh:
+                json.dump(timing, fh)
     finally:
         if world > 1 or force_dist:
             import torch.distributed as dist

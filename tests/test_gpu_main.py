@@ -128,3 +128,64 @@ def test_main_gathers_meshes_through_rccl_on_one_gpu(tmp_path):
         m = np.load(str(out / ('%04d_mesh.npz' % f)))
         assert m['live_v'].shape[0] > 50
         assert np.array_equal(allm['v_%04d' % f], m['live_v']) and np.array_equal(allm['vn_%04d' % f], m['live_vn']) and np.array_equal(allm['f_%04d' % f], m['f'])
+
+
+def test_async_frame_loop_writes_what_the_blocking_loop_writes(tmp_path):
+    """The frame loop with its host work off the critical path (avatarcap_amd.frame_io: prefetch thread + one pinned upload per frame, meshes out through
+    pinned slots to writer threads) against `--sync-io`, the reference's shape of the loop (blocking upload, .cpu(), files written inside the frame):
+    every file of every frame byte for byte -- .npz members and both PLYs, colours included -- and the loop's own account of its copies."""
+    import json
+    cfg = {'training': {'training_data_dir': None},
+           'testing': {'vol_res': [48, 64, 32], 'recon_net_ckpt': None, 'net_ckpt': None, 'net_ckpt_finetuned': None, 'testing_data_dir': None, 'output_dir': None},
+           'model': {'cano_template': {'pos_encoding': 10}, 'warping_field': {'pos_encoding': 0}}}
+    with open(tmp_path / 'cfg.yaml', 'w') as fh:
+        yaml.safe_dump(cfg, fh)
+    outs = {}
+    for tag, extra in (('async', ['--io-slots', '2', '--io-threads', '2']), ('sync', ['--sync-io'])):
+        out = tmp_path / tag
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'main.py'), '-c', str(tmp_path / 'cfg.yaml'), '-m', 'test', '--synthetic', '--frames', '6', '--save-ply',
+                            '--nerf', '--output-dir', str(out), '--timing-json', str(tmp_path / (tag + '.json'))] + extra,
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert '6 of 6 frames done' in r.stdout
+        outs[tag] = out
+    for f in range(6):
+        a, s = np.load(str(outs['async'] / ('%04d_mesh.npz' % f))), np.load(str(outs['sync'] / ('%04d_mesh.npz' % f)))
+        assert sorted(a.files) == sorted(s.files) and {'cano_v', 'live_v', 'recon_live_v', 'live_vc', 'recon_live_vc'} <= set(a.files)
+        for k in a.files:
+            assert np.array_equal(a[k], s[k]), (f, k)
+        assert a['cano_v'].shape[0] > 50 and a['recon_cano_v'].shape[0] > 50
+        for name in ('%04d_avatar.ply' % f, '%04d_recon.ply' % f):
+            assert open(outs['async'] / name, 'rb').read() == open(outs['sync'] / name, 'rb').read(), name
+        # the PLY is the reference writer's byte layout of the same arrays
+        from avatarcap_amd.utils import obj_io
+        obj_io.save_mesh_as_ply(str(tmp_path / 'ref.ply'), a['live_v'], a['f'], a['live_vn'], a['live_vc'].copy())
+        assert open(tmp_path / 'ref.ply', 'rb').read() == open(outs['async'] / ('%04d_avatar.ply' % f), 'rb').read()
+    t = json.load(open(tmp_path / 'async.json'))
+    assert t['frames'] == 6 and t['h2d_copies'] == 6 and t['files_written'] == 18 and t['frames_failed'] == 0      # ONE upload per frame, three files per frame
+    assert t['bytes_written'] == sum(os.path.getsize(outs['async'] / n) for n in os.listdir(outs['async']))
+
+
+def test_prefetcher_and_writer_on_the_device():
+    """FramePrefetcher: one packed upload, typed views, usable on the current stream without a host wait; MeshWriter: tensors produced on the compute stream
+    arrive intact in the writer thread (event-ordered copy on the side stream), also when the slot has to grow and when submissions outrun the writers."""
+    from avatarcap_amd.frame_io import FramePrefetcher, MeshWriter
+    dev = torch.device('cuda', 0)
+    rs = np.random.RandomState(3)
+    host = {i: {'data_idx': i, 'a': rs.randn(6, 64, 64).astype(np.float32), 'b': rs.randint(0, 9, (5,)).astype(np.int32), 'c': rs.rand(7) > 0.5,
+                'd': torch.from_numpy(rs.randn(24, 4, 4).astype(np.float32)), 'e': np.zeros((0, 3), np.float32), 'on_dev': torch.arange(4, device=dev)} for i in range(6)}
+    pf = FramePrefetcher(lambda i: host[i], list(range(6)), dev, depth=2)
+    w = MeshWriter(dev, slots=2, threads=2)
+    got = {}
+    for i in range(6):
+        it = pf.get(i)
+        assert it['a'].is_cuda and it['a'].shape == (1, 6, 64, 64) and it['c'].dtype == torch.bool and it['on_dev'].shape == (1, 4)
+        big = (it['a'][0] * 2.0).repeat(1 + 40 * (i % 3), 1, 1)                        # slot sizes vary: the pinned buffer grows
+        w.submit({'x': big, 'b': it['b'][0] + 1, 'c': it['c'][0], 'd': it['d'][0], 'e': it['e'][0]},
+                 lambda arr, i=i: got.__setitem__(i, {k: v.copy() for k, v in arr.items()}), tag=i)
+        pf.drop(i)
+    assert w.close() == [] and pf.h2d_copies == 6
+    pf.close()
+    for i in range(6):
+        assert np.array_equal(got[i]['x'], np.tile(host[i]['a'] * 2.0, (1 + 40 * (i % 3), 1, 1))) and np.array_equal(got[i]['b'], host[i]['b'] + 1)
+        assert np.array_equal(got[i]['c'], host[i]['c']) and np.array_equal(got[i]['d'], host[i]['d'].numpy()) and got[i]['e'].shape == (0, 3)

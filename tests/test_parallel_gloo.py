@@ -355,3 +355,48 @@ def test_gathered_mesh_checksums_catch_damage_and_misplaced_slots():
     assert res[0][1] and res[0][3] == []
     bad = res[1][3]
     assert [b.split(':')[0] for b in bad] == ['frame %d (owner rank 0) on rank 1' % f for f in (0, 2, 4)], bad
+
+
+def _tune_worker(rank, world, port, q):
+    """Every rank sees different timings; the choice must be the same on all of them: MAX over ranks per candidate, the earliest within tolerance of the best."""
+    from avatarcap_amd.parallel import choose_exchange_config
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        cands = [('p2p', 8), ('p2p', 4), ('p2p', 0), ('broadcast', 8), ('broadcast', 4), ('broadcast', 0)]
+        # rank r's own seconds: ('p2p', 4) is the fastest on ranks 0..2 but rank 3 is slow under it; ('broadcast', 8) is the best worst-case by far
+        local = {('p2p', 8): 0.120 + 0.001 * rank, ('p2p', 4): 0.100 if rank < 3 else 0.150, ('p2p', 0): 0.130, ('broadcast', 8): 0.105,
+                 ('broadcast', 4): 0.1055 - 0.0001 * rank, ('broadcast', 0): 0.140}
+        calls = []
+        r1 = choose_exchange_config(cands, lambda c: (calls.append(c), local[c])[1])
+        # a tie inside the tolerance goes to the EARLIER candidate (the documented default first)
+        near = {c: 0.1 for c in cands}; near[('broadcast', 0)] = 0.0995 if rank == 0 else 0.0990
+        r2 = choose_exchange_config(cands, lambda c: near[c])
+        q.put((rank, r1['choice'], r1['index'], [round(v, 3) for v in r1['table_ms']], calls == cands, r2['choice'], r1['ranks']))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_autotune_all_ranks_agree_world4():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tune_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len({r[1:] for r in [(x[0],) + tuple(map(lambda v: tuple(v) if isinstance(v, list) else v, x[1:])) for x in res]}) == 1     # identical on every rank
+    _, choice, index, table, in_order, tie_choice, ranks = res[0]
+    assert choice == ('broadcast', 8) and index == 3 and ranks == 4 and in_order          # 105.0 ms worst case; ('broadcast', 4) at 105.5 is within 2 % but later
+    assert table == [123.0, 150.0, 130.0, 105.0, 105.5, 140.0]                             # MAX over the ranks per candidate
+    assert tie_choice == ('p2p', 8)                                                        # 0.5 % faster is noise: the default stays
+
+
+def test_exchange_autotune_single_process():
+    from avatarcap_amd.parallel import choose_exchange_config
+    r = choose_exchange_config(['a', 'b', 'c'], lambda c: {'a': 0.3, 'b': 0.2, 'c': 0.1}[c])
+    assert r['choice'] == 'c' and r['index'] == 2 and r['ranks'] == 1

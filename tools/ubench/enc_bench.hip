@@ -119,7 +119,28 @@ int main(int argc, char **argv)
             CK(hipMalloc(&a.kcounter, sizeof(unsigned) * wg)); CK(hipMemset(a.kcounter, 0, sizeof(unsigned) * wg));
         }
         L.grid = (unsigned)(wg * ksplit);
+        a.xcd_bands = (getenv("XCD") && atoi(getenv("XCD")) && ntiles % 8 == 0) ? 8 : 0;
         const double us = time_us([&] { if (launch_conv(L, 0)) exit(1); }, iters);
+#ifdef AVC_ENC_PHASES
+        {   // one more launch with s_memtime stamps per workgroup: where the time of a workgroup goes (cycles of the 100 MHz-independent shader counter)
+            unsigned long long *ph = nullptr;
+            CK(hipMalloc(&ph, sizeof(unsigned long long) * 8 * L.grid)); CK(hipMemset(ph, 0, sizeof(unsigned long long) * 8 * L.grid));
+            a.phases = ph;
+            if (launch_conv(L, 0)) exit(1);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> hph(8 * (size_t)L.grid);
+            CK(hipMemcpy(hph.data(), ph, hph.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0; double seg[5] = {0, 0, 0, 0, 0};
+            for (unsigned b = 0; b < L.grid; ++b) {
+                t0 = std::min(t0, hph[8 * b]); t1 = std::max(t1, hph[8 * b + 5]);
+                for (int k = 0; k < 5; ++k) seg[k] += (double)(hph[8 * b + k + 1] - hph[8 * b + k]) / L.grid;
+            }
+            double first = 0; for (unsigned b = 0; b < L.grid; ++b) first += (double)(hph[8 * b] - t0) / L.grid;
+            printf("   phases (mean ticks per workgroup; launch span %llu ticks): start skew %.0f | prologue %.0f | main loop %.0f | range flag+splitK %.0f+emit-issue %.0f | stores drain %.0f | stats %.0f\n",
+                   t1 - t0, first, seg[0], seg[1], 0.0, seg[2], seg[3], seg[4]);
+            a.phases = nullptr;
+        }
+#endif
         const double flop = 2.0 * H * W * Cin * Cout * taps;
         printf("conv %dx%d %d->%d taps %d CT%d PT%d ksplit %d stats %d: %d workgroups, %.1f us, %.1f TFLOP/s algorithmic (%.1f issued as 3 fp16 passes)\n", H, W, Cin, Cout, taps,
                CT, PT, ksplit, stats, L.grid, us, flop / us * 1e-6, 3 * flop / us * 1e-6);
