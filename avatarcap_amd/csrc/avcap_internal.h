@@ -59,6 +59,7 @@ struct Options {
     int enc_graph = 1;        // the image encoder's launches replayed as a hipGraph
     int enc_ksplit = 1;       // convolutions with few workgroups split K over several (partial sums in HBM, added in a fixed order by the last to arrive)
     int enc_fork = 1;         // the hourglass' upper branches (b1_k) run on a second stream beside the lower ones
+    int enc_occ2 = 1;         // convolutions with at least two half-size workgroups per CU run two per CU (conv_enc.hip ConvGeo: OCC2)
     int lbs_reach_mm = 140;   // avc_lbs_prepare: cells whose centre lies within this distance of its 4th nearest vertex get a candidate list (0: no lists)
     int mc_walk = 1;          // marching cubes: the classify pass that walks z inside a workgroup, where the volume's shape allows it (0: the general one)
 };

@@ -450,6 +450,7 @@ int avc_set_option(avc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "enc_ksplit")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: enc_ksplit is 0 or 1"); ctx->opt.enc_ksplit = value; }
     else if (!strcmp(name, "mc_walk")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: mc_walk is 0 or 1"); ctx->opt.mc_walk = value; }
     else if (!strcmp(name, "lbs_reach_mm")) { AVC_REQUIRE(value >= 0 && value <= 1000, AVC_ERR_ARG, "avc_set_option: lbs_reach_mm is 0 .. 1000"); ctx->opt.lbs_reach_mm = value; }
+    else if (!strcmp(name, "enc_occ2")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: enc_occ2 is 0 or 1"); ctx->opt.enc_occ2 = value; }
     else if (!strcmp(name, "enc_fork")) { AVC_REQUIRE(value == 0 || value == 1, AVC_ERR_ARG, "avc_set_option: enc_fork is 0 or 1"); ctx->opt.enc_fork = value; }
     else AVC_REQUIRE(false, AVC_ERR_ARG, "avc_set_option: unknown option '%s'", name);
     return AVC_OK;

@@ -20,8 +20,8 @@
 //         steps ahead; one barrier per step.
 //   * the epilogue writes the raw output and/or its slice of the block's concatenated output + residual, and accumulates the
 //     GroupNorm statistics of both: with D transposed (pixels in rows) a lane owns one channel and 16 PT pixels of it, so the pixel
-//     sum is in-lane; per-workgroup group partials go to HBM and the LAST workgroup to finish (ticket counter) folds them in a fixed
-//     order, in double, into (mean, rstd) per group: deterministic, no floating-point atomics, no extra launch.
+//     sum is in-lane; per-workgroup group partials go to HBM with plain stores and the CONSUMER's prologue folds them in a fixed order, in
+//     double, into (mean, rstd) per group: deterministic, no atomics of any kind, no extra launch, nothing left to wait for at a launch's end.
 //   * avg_pool2d and bicubic-upsample + add are two small HBM-bound kernels that also leave statistics behind.
 //   * the whole encoder (~65 launches) is recorded once per input size as a hipGraph and replayed per frame.
 #include <hip/hip_runtime.h>
@@ -61,16 +61,16 @@ constexpr int MAX_CIN = 1024;               // input channels of one convolution
 constexpr int MAX_NORM_CIN = 256;           // ... of one whose input goes through a GroupNorm: its (a, b) per channel sit in LDS
 
 // GroupNorm statistics (torch.nn.GroupNorm: mean and biased variance over (C / G, H, W)) travel from the launch that produces a tensor to the
-// launches that consume it as a table of at most 32 partial (sum, sum of squares) pairs per group, in double: [group][bucket].  A bucket is
-// one tile of the producing launch, or -- launches of more than 32 tiles -- `bsize` consecutive tiles: every workgroup leaves its fp32 tile
-// partial in a level-1 table, takes a ticket on its bucket's counter, and the bucket's last arrival adds the bucket's tiles in tile order.
-// No launch-wide ticket (512 same-address atomics were 15 - 25 us at the end of every launch), no launch-wide fold by one workgroup, no
-// floating-point atomics: bitwise deterministic.  The CONSUMER folds the <= 32 buckets of a group (fold_group) when it builds its affine map.
+// launches that consume it as ONE fp32 (sum, sum of squares) pair per (group, tile of the producing launch): `part[group][ntiles]`.  A producing
+// workgroup stores the pairs of its tile's groups with plain stores and is done -- no ticket, no atomic, no device-scope round trip at the end of
+// the launch (rounds 4-5 folded tiles into <= 32 buckets through per-bucket tickets: two dependent device-scope round trips, 3 - 5 us at the end of
+// every one of the encoder's ~65 launches; `profiles/r06_enc_phases.md`).  The CONSUMER is a later launch, so the kernel boundary orders the
+// stores; its prologue folds the tiles of a group with eight threads per group, in double, in a fixed order (fold_groups): the loads fly beside the
+// first activation tile's, and the result is bitwise deterministic (fixed tile order, fixed tree).
 struct StatOut {
-    float *part;         // level 1 [rows][ntiles] (sum, sum of squares) per tile, fp32; unused when bsize == 1
-    double *part2;       // level 2 [rows][nb] per bucket; the launch's first row first.  null = the launch leaves no statistics of this kind
+    f32x2 *part;         // [rows][ntiles] (sum, sum of squares) per (group, tile), fp32; the launch's first row first.  null = the launch leaves no statistics of this kind
     int cpg;             // channels per group
-    int nb, bsize;       // buckets (<= 32), tiles per bucket
+    int ntiles;          // row pitch of the table (>= the tiles of any launch that produces the tensor; entries no launch writes stay zero)
 };
 
 // A destination of a convolution's output in one of the layouts the U-Net's layers hand to each other (all channel-last):
@@ -84,8 +84,8 @@ struct OutSpec { float *ptr; int layout, C, coff; };
 struct ConvArgs {
     const float *x;              // input (H, W, Cin) channel-last
     int H, W, Cin;
-    const double *in_part2;      // the producers' [group][in_nb] partials of x (NORM launches)
-    int in_nb; float in_inv_n, in_eps;           // 1 / (cpg H W), the GroupNorm's eps
+    const f32x2 *in_part;        // the producers' [group][in_nt] partials of x (NORM launches)
+    int in_nt; float in_inv_n, in_eps;           // tiles of the producing launches; 1 / (cpg H W), the GroupNorm's eps
     const float *gamma, *beta;   // the consumer's GroupNorm affine
     int in_cpg;
     float in_scale;              // power of two folded into (a, b): keeps small activations' lo halves normal
@@ -100,15 +100,12 @@ struct ConvArgs {
     const float *res;            // (H, W, yC)
     int yC, ycoff;
     StatOut st_raw, st_y;
-    unsigned *counter;           // [bucket][slice] tickets (self-resetting); used when bsize > 1
     int tiles_x, tiles_y;
     int ksplit;                  // workgroups per (tile, slice): each walks Cin / 32 / ksplit chunks of K (1: no split)
     float *kpart;                // split-K: [tile x slice][ksplit][accumulator registers][256 threads] raw sums
     unsigned *kcounter;          // split-K: one ticket per (tile, slice)
     unsigned *range_flag;        // set to 1 when a staged value exceeds the fp16 range of the split (avc_set_range_check reads it)
     OutSpec oa, ob;              // generic outputs (the U-Net's layouts); when oa.ptr != null they replace raw / y and no statistics are produced
-    int xcd_bands;               // 8: workgroup b takes tile (b % 8) (tiles / 8) + b / 8 -- the 8 XCDs (blockIdx round-robins over them) each get a contiguous band of the
-                                 // image, so the halo rows two vertically adjacent tiles share are fetched into ONE L2 once; 0: tile = b (set only when tiles % 8 == 0)
 #ifdef AVC_ENC_PHASES
     unsigned long long *phases;  // tools/ubench/enc_bench: [workgroup][8] s_memtime stamps (start, prologue done, main loop done, outputs stored, end)
 #endif
@@ -137,73 +134,43 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigne
 __device__ __forceinline__ constexpr int d_row0(int r) { return (r & 3) + 8 * (r >> 2); }      // + 4 h
 
 // ---- statistics ------------------------------------------------------------------------------------------------------------------
-// Level-1 partials are written and read with device-scope (sc1) accesses: they cross XCDs, whose L2s are not coherent with each other.
-__device__ __forceinline__ void store_partial(float *part, size_t index, float s, float q)
+// The consumer's side.  (mean, rstd) of the `ngroups` (<= 32) groups of a tensor from its [group][ntiles] partials into LDS (`mr[group]`), by all 256
+// threads of the workgroup: thread t sums the tiles k = t % 8, t % 8 + 8, ... of group t / 8 in double (fixed order), the eight partial sums of a group
+// meet in a three-step butterfly (a fixed tree).  `issue` runs between the issue of the loads and their first use: whatever else the caller wants in
+// flight meanwhile.  Ends with a __syncthreads().
+template <class F>
+__device__ __forceinline__ void fold_groups(const f32x2 *__restrict__ part, int ngroups, int ntiles, float inv_n, float eps, f32x2 *mr, F &&issue)
 {
-    const unsigned long long v = (unsigned long long)__builtin_bit_cast(unsigned, s) | ((unsigned long long)__builtin_bit_cast(unsigned, q) << 32);
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(part) + index, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// The consumer's side: (mean, rstd) of one group from its <= 32 bucket partials -- a butterfly in double (a fixed tree, whatever nb is)
-__device__ __forceinline__ f32x2 fold_group(const double *row, int nb, float inv_n, float eps)
-{
-    double sv[32], qv[32];
+    const int tid = threadIdx.x, g = tid >> 3, sub = tid & 7;
+    const f32x2 *row = part + (size_t)(g < ngroups ? g : 0) * ntiles;
+    double S = 0.0, Q = 0.0;
+    constexpr int B = 32;                                  // loads in flight per thread: ALL of a launch of <= 256 tiles in one round trip (512 tiles: two)
+    f32x2 v[B];
 #pragma unroll
-    for (int t = 0; t < 32; ++t) {
-        sv[t] = t < nb ? row[2 * t] : 0.0;
-        qv[t] = t < nb ? row[2 * t + 1] : 0.0;
+    for (int k = 0; k < B; ++k) { const int t = sub + 8 * k; v[k] = t < ntiles ? row[t] : f32x2{0.0f, 0.0f}; }
+    issue();
+#pragma unroll
+    for (int k = 0; k < B; ++k) { S += (double)v[k][0]; Q += (double)v[k][1]; }
+    for (int t0 = 8 * B; t0 < ntiles; t0 += 8 * B) {
+#pragma unroll
+        for (int k = 0; k < B; ++k) { const int t = t0 + sub + 8 * k; v[k] = t < ntiles ? row[t] : f32x2{0.0f, 0.0f}; }
+#pragma unroll
+        for (int k = 0; k < B; ++k) { S += (double)v[k][0]; Q += (double)v[k][1]; }
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1)
-#pragma unroll
-        for (int l = 0; l < o; ++l) { sv[l] += sv[l + o]; qv[l] += qv[l + o]; }
-    const double m = sv[0] * (double)inv_n, var = fmax(qv[0] * (double)inv_n - m * m, 0.0);
-    return f32x2{(float)m, (float)(1.0 / sqrt(var + (double)eps))};
+    for (int o = 1; o < 8; o <<= 1) { S += __shfl_xor(S, o); Q += __shfl_xor(Q, o); }
+    if (sub == 0 && g < ngroups) {
+        const double m = S * (double)inv_n, var = fmax(Q * (double)inv_n - m * m, 0.0);
+        mr[g] = f32x2{(float)m, (float)(1.0 / sqrt(var + (double)eps))};
+    }
+    __syncthreads();
 }
 
-// The producer's side.  Thread tid < nrows holds (s, q) of row row0 + tid of the launch's table for this workgroup's tile (two kinds at most:
-// a convolution's raw output and its slice of the block output share the tile grid, hence the ticket).  `counter` is this workgroup's
-// bucket's ticket (one per bucket and row block).
+// The producer's side.  Thread tid < nrows holds (s, q) of row row0 + tid of the launch's table for this workgroup's tile.
 struct StatRows { int row0, nrows; float s, q; };
-__device__ __forceinline__ void stats_commit(const StatOut &a, const StatRows &ra, const StatOut &b, const StatRows &rb, unsigned *counter, int tile, int ntiles,
-                                             int tid, char *smem_flag)
+__device__ __forceinline__ void stats_store(const StatOut &st, const StatRows &r, int tile, int tid)
 {
-    const StatOut &any = a.part2 ? a : b;
-    if (!any.part2) return;
-    if (any.bsize == 1) {                                  // the tile is the bucket
-        if (a.part2 && tid < ra.nrows) { double *d = a.part2 + ((size_t)(ra.row0 + tid) * a.nb + tile) * 2; d[0] = (double)ra.s; d[1] = (double)ra.q; }
-        if (b.part2 && tid < rb.nrows) { double *d = b.part2 + ((size_t)(rb.row0 + tid) * b.nb + tile) * 2; d[0] = (double)rb.s; d[1] = (double)rb.q; }
-        return;
-    }
-    if (a.part2 && tid < ra.nrows) store_partial(a.part, (size_t)(ra.row0 + tid) * ntiles + tile, ra.s, ra.q);
-    if (b.part2 && tid < rb.nrows) store_partial(b.part, (size_t)(rb.row0 + tid) * ntiles + tile, rb.s, rb.q);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the sc1 stores are acknowledged
-    __syncthreads();
-    const int bucket = tile / any.bsize, t0 = bucket * any.bsize, nin = min(any.bsize, ntiles - t0);
-    if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = t == (unsigned)nin - 1;
-        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *reinterpret_cast<volatile unsigned *>(smem_flag) = last ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!*reinterpret_cast<volatile unsigned *>(smem_flag)) return;
-    auto fold = [&](const StatOut &st, const StatRows &r) {
-        if (!st.part2 || tid >= r.nrows) return;
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(st.part) + (size_t)(r.row0 + tid) * ntiles + t0;
-        double S = 0.0, Q = 0.0;
-        for (int k0 = 0; k0 < nin; k0 += 16) {
-            unsigned long long v[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = k0 + k < nin ? __hip_atomic_load(src + k0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { S += (double)__builtin_bit_cast(float, (unsigned)v[k]); Q += (double)__builtin_bit_cast(float, (unsigned)(v[k] >> 32)); }
-        }
-        double *d = st.part2 + ((size_t)(r.row0 + tid) * st.nb + bucket) * 2;
-        d[0] = S; d[1] = Q;
-    };
-    fold(a, ra);
-    fold(b, rb);
+    if (st.part && tid < r.nrows) st.part[(size_t)(r.row0 + tid) * st.ntiles + tile] = f32x2{r.s, r.q};
 }
 
 // ---- the convolution ---------------------------------------------------------------------------------------------------
@@ -211,7 +178,12 @@ __device__ __forceinline__ void stats_commit(const StatOut &a, const StatRows &r
 // TWC: image columns of a pixel tile (32: one image row; 16: two rows of 16 -- images narrower than 32),
 // NORM: the input goes through relu(GroupNorm(.)) while it is staged (else: raw).
 // LDS map (per instantiation): [staged chunk A | staged chunk B | weight ring of RS 16-KiB slots | (a, b) table | flag].
-template <int PT, int TAPS, int TWC>
+// OCC2: TWO workgroups per CU.  A launch of one workgroup per CU runs its phases in lockstep on every CU -- the prologue's fetch burst (every workgroup asks for
+// its first activation tile and weight groups at once: ~75 KB per CU at the ~11 B/cycle/CU such a burst gets, 12 - 15 k cycles), the main loop, the output burst --
+// and the matrix pipe idles through the first and the last (profiles/r06_enc_phases.md: 46 - 58 % of a large launch's cycles are its main loop).  With half the LDS
+// each (ONE staged chunk instead of two: the next chunk waits in registers and is written between two chunks, which is when the OTHER workgroup's MFMAs run) two
+// workgroups of half the pixel tile share a CU and fill each other's memory phases.
+template <int PT, int TAPS, int TWC, bool OCC2 = false>
 struct ConvGeo {
     static constexpr int PTR = 32 / TWC;                          // image rows of one pixel tile
     static constexpr int ROWS = 4 * PT * PTR;                     // image rows of the workgroup's tile
@@ -223,9 +195,10 @@ struct ConvGeo {
     static constexpr int RP = TAPS == 1 ? TWC : (TWC == 32 ? HC : 32);       // LDS row pitch in pixels (32 for the 16-wide tiles: bank note in DESIGN.md)
     static constexpr int NPIX = HR * RP;
     static constexpr int ACTB = (NPIX * PIXB + 1023) & ~1023;
-    static constexpr int RS_FIT = (163840 - 8 * MAX_NORM_CIN - 64 - 256 - 2 * ACTB) / RING_SLOT;
+    static constexpr int NBUF = OCC2 ? 1 : 2, LDS_BUDGET = OCC2 ? 81920 : 163840;
+    static constexpr int RS_FIT = (LDS_BUDGET - 8 * MAX_NORM_CIN - 64 - 256 - NBUF * ACTB) / RING_SLOT;
     static constexpr int RS = RS_FIT > 6 ? 6 : RS_FIT;            // ring slots; RS - 1 groups of weights are in flight
-    static constexpr int L_ACT0 = 0, L_ACT1 = ACTB, L_RING = 2 * ACTB, L_AB = L_RING + RS * RING_SLOT, L_FLAG = L_AB + 8 * MAX_NORM_CIN, L_TOTAL = L_FLAG + 64 + 256;     // (flag, then (mean, rstd) of the input's 32 groups)
+    static constexpr int L_ACT0 = 0, L_ACT1 = OCC2 ? 0 : ACTB, L_RING = NBUF * ACTB, L_AB = L_RING + RS * RING_SLOT, L_FLAG = L_AB + 8 * MAX_NORM_CIN, L_TOTAL = L_FLAG + 64 + 256;     // (flag, then (mean, rstd) of the input's 32 groups)
     static_assert(RS >= 3, "no room for the weight ring");
 };
 
@@ -235,12 +208,12 @@ struct ConvGeo {
 #define AVC_PHASE(k) do { } while (0)
 #endif
 
-template <int CT, int PT, int TAPS, int TWC, bool NORM>
-__global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
+template <int CT, int PT, int TAPS, int TWC, bool NORM, bool OCC2 = false>
+__global__ __launch_bounds__(256, OCC2 ? 2 : 1) void conv_mfma_kernel(const ConvArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     AVC_PHASE(0);
-    using Geo = ConvGeo<PT, TAPS, TWC>;
+    using Geo = ConvGeo<PT, TAPS, TWC, OCC2>;
     constexpr int PTR = Geo::PTR, ROWS = Geo::ROWS, PAD = Geo::PAD, RP = Geo::RP, HC = Geo::HC, NPIX = Geo::NPIX, KW = Geo::KW;
     constexpr int LDS_ACT0 = Geo::L_ACT0, LDS_ACT1 = Geo::L_ACT1, LDS_RING = Geo::L_RING, LDS_AB = Geo::L_AB, LDS_FLAG = Geo::L_FLAG;
     constexpr int RS = Geo::RS, LA = RS - 1;                // ring slots, groups of weights in flight
@@ -250,31 +223,13 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
     const int j = lane & 31, h = lane >> 5;
     const int slices = p.Cout / (32 * CT);
     // blockIdx -> (k slice, channel slice, pixel tile): a workgroup walks the chunks [c0, c1) of the input channels (split-K launches: ksplit > 1)
-    int ks = blockIdx.x % p.ksplit, wg = blockIdx.x / p.ksplit;
-    int slice = wg % slices, tile = wg / slices;
-    if (p.xcd_bands) {                                     // workgroup b runs on XCD b % 8: that XCD's q-th workgroup takes the q-th (tile, slice, k slice) of ITS band of tiles
-        const int per = p.tiles_x * p.tiles_y / p.xcd_bands, q = blockIdx.x / p.xcd_bands;
-        ks = q % p.ksplit; slice = (q / p.ksplit) % slices;
-        tile = (blockIdx.x % p.xcd_bands) * per + q / (p.ksplit * slices);
-        wg = tile * slices + slice;
-    }
+    // (a band of the image per XCD -- workgroup b on XCD b % 8 taking the tiles of ITS eighth, so that vertically adjacent tiles share their halo rows in one
+    // L2 -- was measured and changes nothing: 46.3 / 46.9, 136.5 / 135.6, 51.8 / 51.1 us; the input fetch is not what a launch waits for, profiles/r06_enc_phases.md)
+    const int ks = blockIdx.x % p.ksplit, wg = blockIdx.x / p.ksplit;
+    const int slice = wg % slices, tile = wg / slices;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int y0 = ty * ROWS, x0 = tx * TWC;
     const int cpk = (p.Cin >> 5) / p.ksplit, c0 = ks * cpk, c1 = c0 + cpk;
-
-    // ---- the prologue's affine map per input channel: relu(a x + b), a = gamma rstd, b = beta - mean a (both times in_scale)
-    if constexpr (NORM) {
-        if (tid < p.Cin / p.in_cpg)
-            *reinterpret_cast<f32x2 *>(smem + LDS_FLAG + 64 + tid * 8) = fold_group(p.in_part2 + (size_t)tid * p.in_nb * 2, p.in_nb, p.in_inv_n, p.in_eps);
-        __syncthreads();
-    }
-    if constexpr (NORM) {                                  // (raw inputs: a = in_scale, b = 0 for every channel -- no table, any Cin)
-        if (tid < p.Cin) {
-            const f32x2 mr = *reinterpret_cast<const f32x2 *>(smem + LDS_FLAG + 64 + (tid / p.in_cpg) * 8);
-            const float a = p.gamma[tid] * mr[1];
-            *reinterpret_cast<f32x2 *>(smem + LDS_AB + tid * 8) = f32x2{a * p.in_scale, (p.beta[tid] - mr[0] * a) * p.in_scale};
-        }
-    }
 
     // ---- staging geometry of this thread: piece i = 4 channels `sub` of staged pixel sp = tid / 8 + 32 i
     const int sub = tid & 7;
@@ -386,8 +341,23 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         abase[n] = (unsigned)(((q * PTR + r) * RP + cc) * PIXB + h * 16);
     }
 
+    // ---- prologue.  Everything the workgroup has to fetch before its first MFMA is requested up front, in one burst: the first activation tile, the first
+    // weight group, the GroupNorm's per-channel affine and the producers' per-tile statistics (fold_groups) -- one memory round trip instead of the four
+    // dependent ones of rounds 4-5 (statistics -> gamma / beta -> activations -> weights: 11.6 k cycles before the first MFMA, profiles/r06_enc_phases.md).
     load_acts(c0);
     dma_any(0);
+    // the affine map per input channel: relu(a x + b), a = gamma rstd, b = beta - mean a (both times in_scale); raw inputs: a = in_scale, b = 0, no table
+    if constexpr (NORM) {
+        float ga = 0.0f, be = 0.0f;
+        if (tid < p.Cin) { ga = p.gamma[tid]; be = p.beta[tid]; }
+        f32x2 *mr = reinterpret_cast<f32x2 *>(smem + LDS_FLAG + 64);
+        fold_groups(p.in_part, p.Cin / p.in_cpg, p.in_nt, p.in_inv_n, p.in_eps, mr, [] {});
+        if (tid < p.Cin) {
+            const f32x2 m = mr[tid / p.in_cpg];
+            const float a = ga * m[1];
+            *reinterpret_cast<f32x2 *>(smem + LDS_AB + tid * 8) = f32x2{a * p.in_scale, (be - m[0] * a) * p.in_scale};
+        }
+    }
     __syncthreads();                                        // the (a, b) table
     store_acts(c0, LDS_ACT0, 0, NPIECE);
     for (int gi = 1; gi < LA && gi < ngroups; ++gi) dma_any(gi);
@@ -408,9 +378,12 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
     // (vmcnt completes in order), so it is consumed where those groups are due anyway: from the second group on when two are in flight, in the
     // chunk's last group otherwise
     constexpr int T0 = (TAPS == 1 || NG == 1) ? 0 : (LA == 2 ? G : G * (NG - 1));
-    for (int c = c0; c < c1; ++c) {
+    // one chunk of K; `more` (a next chunk exists: its tile is fetched, transformed and written while this one is multiplied) is a compile-time flag --
+    // as a run-time `if` it cut the loop body into basic blocks at every tap, and the staging arithmetic could not be scheduled between the MFMAs
+    // (profiles/r06_enc_phases.md: 21 % of the main loop)
+    auto chunk = [&](const int c, auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
         const unsigned abuf = ((c - c0) & 1) ? LDS_ACT1 : LDS_ACT0, nbuf = ((c - c0) & 1) ? LDS_ACT0 : LDS_ACT1;
-        const bool more = c + 1 < c1;
         unsigned org = 0;
         if constexpr (TAPS == 4) {
             const int par = p.tap_mode == 1 ? c / p.tap_div : (int)(slice * CT * 32) / p.tap_div;
@@ -420,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value, NT = group_taps(g);
             const int gi = (c - c0) * NG + g;
-            if (g == 0 && more) load_acts(c + 1);
+            if constexpr (g == 0 && more) load_acts(c + 1);
             // group gi + LA goes into the slot group gi - 1 was read from (every wave is past the barrier that ended it)
             if (gi + LA < ngroups) dma_group(std::integral_constant<int, (g + LA) % NG>{}, gi + LA);
             const unsigned wb = LDS_RING + (unsigned)(gi % RS) * RING_SLOT + lane16;
@@ -453,9 +426,9 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
 #pragma unroll
                         for (int m = 0; m < CT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[n], bh[m], acc[n][m], 0, 0, 0);
                 }
-                if (more) {
-                    if constexpr (t >= T0) store_acts(c + 1, nbuf, ((t - T0) * NPIECE) / (TAPS - T0), ((t - T0 + 1) * NPIECE) / (TAPS - T0));
-                }
+                // (a sched_group_barrier pipeline that pins the pieces' VALU instructions between the tap's MFMAs was measured: no change -- at one wave per SIMD
+                // a VALU instruction costs MFMA issue time wherever it stands, profiles/r06_enc_phases.md)
+                if constexpr (!OCC2 && more && t >= T0) store_acts(c + 1, nbuf, ((t - T0) * NPIECE) / (TAPS - T0), ((t - T0 + 1) * NPIECE) / (TAPS - T0));
             });
             // the staging loads count as "issued behind group gi + 1" while the group that was requested in their own step (group gi0 + LA)
             // is later than gi + 1
@@ -463,7 +436,17 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         });
-    }
+        if constexpr (OCC2) {
+            // one staged chunk: every wave is past the chunk's last read (the barrier above); the next chunk goes from the registers into the same buffer
+            // while the CU's other workgroup has the matrix pipe
+            if constexpr (more) {
+                store_acts(c + 1, nbuf, 0, NPIECE);
+                __syncthreads();
+            }
+        }
+    };
+    for (int c = c0; c + 1 < c1; ++c) chunk(c, std::true_type{});
+    chunk(c1 - 1, std::false_type{});
 
     AVC_PHASE(2);
     // a staged value beyond 65504 became +-inf in its `hi` half: the launch's output is not to be trusted (avc_set_range_check reports it)
@@ -471,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
 
     // ---- split-K: every k slice leaves its raw accumulators in HBM; the last one to arrive (ticket) adds all of them in slice order -- its
     // own included, re-read, so that the sum does not depend on who is last -- and goes on to the epilogue.  Device-scope accesses, no fences
-    // (see stats_commit).
+    // (the partial sums cross XCDs, whose L2s are not coherent with each other).
     if (p.ksplit > 1) {
         constexpr int NV = PT * CT * 8;                        // 8-byte pieces per thread (device-scope accesses are at most 64 bits wide)
         typedef unsigned long long u64;
@@ -633,10 +616,10 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
 #endif
 
     // ---- statistics: the two pixel halves, then the cpg adjacent channel lanes, then the four waves through LDS
-    if (p.st_raw.part2 || p.st_y.part2) {
+    if (p.st_raw.part || p.st_y.part) {
         float *red = reinterpret_cast<float *>(smem + LDS_ACT0);          // [kind][wave][32 CT groups max](s, q); the staged tiles are dead
         auto reduce = [&](const StatOut &st, float *s, float *q, int kind) {
-            if (!st.part2) return;
+            if (!st.part) return;
 #pragma unroll
             for (int m = 0; m < CT; ++m) {
                 s[m] += __shfl_xor(s[m], 32); q[m] += __shfl_xor(q[m], 32);
@@ -652,7 +635,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
         __syncthreads();
         auto rows = [&](const StatOut &st, int kind) {
             StatRows r{0, 0, 0.0f, 0.0f};
-            if (!st.part2) return r;
+            if (!st.part) return r;
             r.nrows = 32 * CT / st.cpg;                                    // groups of this workgroup's slice
             r.row0 = slice * r.nrows;
             if (tid < r.nrows)
@@ -664,8 +647,8 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_kernel(const ConvArgs p)
             return r;
         };
         const StatRows ra = rows(p.st_raw, 0), rb = rows(p.st_y, 1);
-        const int ntiles = p.tiles_x * p.tiles_y, bs = p.st_raw.part2 ? p.st_raw.bsize : p.st_y.bsize;
-        stats_commit(p.st_raw, ra, p.st_y, rb, p.counter + (size_t)(tile / bs) * slices + slice, tile, ntiles, tid, smem + LDS_FLAG);
+        stats_store(p.st_raw, ra, tile, tid);
+        stats_store(p.st_y, rb, tile, tid);
     }
     AVC_PHASE(5);
 }
@@ -701,9 +684,8 @@ struct EltArgs {
     float *out;
     int H, W, C;                 // OUTPUT size
     StatOut st;
-    unsigned *counter;           // [bucket] (elt_body) / [bucket][chunk] (tiled upsample) tickets
     int Hb, Wb;                  // size of the other tensor (pool: the input; upsample-add: low3)
-    const double *in_part2; const float *gamma, *beta; int in_cpg, in_nb; float in_inv_n, in_eps;     // norm-relu: GroupNorm of a
+    const f32x2 *in_part; const float *gamma, *beta; int in_cpg, in_nt; float in_inv_n, in_eps;     // norm-relu: GroupNorm of a
     int ppw;                     // output pixels per workgroup
     int ntiles;
 };
@@ -712,7 +694,6 @@ template <class F>
 __device__ __forceinline__ void elt_body(const EltArgs &p, F &&value)
 {
     __shared__ float red[256 * 8];
-    __shared__ unsigned flag[16];
     const int tid = threadIdx.x, c4n = p.C >> 2;         // C in {32..256}: c4n in {8..64}
     const int c4 = tid % c4n, sub = tid / c4n, nsub = 256 / c4n;
     const int npix = p.H * p.W, pix0 = blockIdx.x * p.ppw, pix1 = min(npix, pix0 + p.ppw);
@@ -724,7 +705,7 @@ __device__ __forceinline__ void elt_body(const EltArgs &p, F &&value)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
     }
-    if (!p.st.part2) return;
+    if (!p.st.part) return;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { red[tid * 8 + 2 * e] = s[e]; red[tid * 8 + 2 * e + 1] = q[e]; }
     __syncthreads();
@@ -734,8 +715,7 @@ __device__ __forceinline__ void elt_body(const EltArgs &p, F &&value)
     if (tid < groups)
         for (int c = tid * p.st.cpg; c < (tid + 1) * p.st.cpg; ++c)
             for (int k = 0; k < nsub; ++k) { const float *rr = red + ((k * c4n + (c >> 2)) * 8 + 2 * (c & 3)); r.s += rr[0]; r.q += rr[1]; }
-    StatOut none{};
-    stats_commit(p.st, r, none, StatRows{0, 0, 0.0f, 0.0f}, p.counter + blockIdx.x / p.st.bsize, blockIdx.x, p.ntiles, tid, reinterpret_cast<char *>(flag));
+    stats_store(p.st, r, blockIdx.x, tid);
 }
 
 __global__ __launch_bounds__(256) void avgpool_kernel(const EltArgs p)
@@ -803,7 +783,6 @@ __global__ __launch_bounds__(256) void upadd_tiled_kernel(const UpTiledArgs a)
 {
     const EltArgs &p = a.e;
     __shared__ __attribute__((aligned(16))) float src[UT_SR * UT_SC * UT_C];     // 24 KiB
-    __shared__ unsigned flag[16];
     const int tid = threadIdx.x;
     const int nt = a.tiles_x * a.tiles_y, tile = blockIdx.x % nt, chunk = blockIdx.x / nt;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
@@ -851,27 +830,25 @@ __global__ __launch_bounds__(256) void upadd_tiled_kernel(const UpTiledArgs a)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
     }
-    if (!p.st.part2) return;
+    if (!p.st.part) return;
     __syncthreads();
     float *red = src;                                              // [16 pixel lanes][64 channels](s, q)
 #pragma unroll
     for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x2 *>(red + (((tid >> 4) * UT_C) + quad * 4 + e) * 2) = f32x2{s[e], q[e]};
     __syncthreads();
-    const int gpc = UT_C / p.st.cpg, nchunks = p.C / UT_C;         // groups of this workgroup's 64 channels
+    const int gpc = UT_C / p.st.cpg;                               // groups of this workgroup's 64 channels
     StatRows r{chunk * gpc, gpc, 0.0f, 0.0f};
     if (tid < gpc)
         for (int c = tid * p.st.cpg; c < (tid + 1) * p.st.cpg; ++c)
             for (int k = 0; k < 16; ++k) { const f32x2 v = *reinterpret_cast<const f32x2 *>(red + (k * UT_C + c) * 2); r.s += v[0]; r.q += v[1]; }
-    StatOut none{};
-    stats_commit(p.st, r, none, StatRows{0, 0, 0.0f, 0.0f}, p.counter + (size_t)(tile / p.st.bsize) * nchunks + chunk, tile, nt, tid, reinterpret_cast<char *>(flag));
+    stats_store(p.st, r, tile, tid);
 }
 
 // relu(GroupNorm(a)) materialised (HGFilters.py:178: the block that follows normalises THIS tensor again and needs its statistics)
 __global__ __launch_bounds__(256) void normrelu_kernel(const EltArgs p)
 {
     __shared__ f32x2 mr[32];
-    if (threadIdx.x < p.C / p.in_cpg) mr[threadIdx.x] = fold_group(p.in_part2 + (size_t)threadIdx.x * p.in_nb * 2, p.in_nb, p.in_inv_n, p.in_eps);
-    __syncthreads();
+    fold_groups(p.in_part, p.C / p.in_cpg, p.in_nt, p.in_inv_n, p.in_eps, mr, [] {});
     const int c4 = threadIdx.x % (p.C >> 2);
     float a[4], b[4];
 #pragma unroll
@@ -943,12 +920,13 @@ struct DevNorm { float *gamma = nullptr, *beta = nullptr; int C = 0, groups = 32
 struct DevBlock { DevConv conv[3], ds; bool has_ds = false; DevNorm bn[4]; int cin = 0, cout = 0; };
 
 struct Tensor { float *data = nullptr; int H = 0, W = 0, C = 0;
-                double *part2 = nullptr; int nb = 0; };      // GroupNorm partials [32 groups][nb buckets] its producers leave, its consumers fold
+                f32x2 *part = nullptr; int nt = 0; };       // GroupNorm partials [32 groups][nt tiles] its producers leave, its consumers fold
 
 enum LaunchKind { L_S2D, L_CONV, L_POOL, L_UPADD, L_UPADD_TILED, L_NORMRELU, L_UP2, L_FORK, L_JOIN };
 struct Launch {
     LaunchKind kind;
     ConvArgs conv; int CT = 0, PT = 0, TAPS = 0, TWC = 0; bool norm = false;
+    bool occ2 = false;               // the two-workgroups-per-CU flavour of the kernel (ConvGeo: OCC2)
     S2dArgs s2d;
     Up2Args up2;
     EltArgs elt; int ut_x = 0, ut_y = 0;     // (L_UPADD_TILED: the tile grid)
@@ -976,7 +954,7 @@ struct Encoder {
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr, side_stream = nullptr;
     std::vector<hipEvent_t> events;
-    int fork = -1, ksplit = -1;
+    int fork = -1, ksplit = -1, occ2 = -1;
 };
 
 static void free_plan(Encoder *e)
@@ -1192,26 +1170,31 @@ struct Planner {
         t.data = static_cast<float *>(alloc(sizeof(float) * (size_t)H * W * C));
         return t;
     }
-    // the statistics a launch of `ntiles` tiles leaves for channels [first_channel, + channels) of t; row_blocks = the launch's workgroups per tile
-    // (channel slices / chunks), each with its own ticket per bucket
-    StatOut stat(Tensor &t, int first_channel, int channels, int ntiles, int row_blocks, unsigned **counter)
+    // the statistics a launch of `ntiles` tiles leaves for the channels from first_channel on of t: its rows of the tensor's [group][pitch] table.  The
+    // producers of one tensor fill different rows and need not cut the image into the same tiles: the pitch is the largest tile count any launch shape
+    // has on a tensor of this size, the table is zeroed once when the plan is built, a producer of fewer tiles leaves the rest of its rows zero, and the
+    // consumers fold whole rows.
+    static int stat_pitch(int H, int W)
+    {
+        const int twc = W >= 32 ? 32 : 16, rows = 4 * (32 / twc), npix = H * W;
+        const int conv_tiles = ((H + rows - 1) / rows) * ((W + twc - 1) / twc);                                      // a convolution's smallest tile (PT = 1)
+        const int ppw = npix <= 1024 ? std::max(16, (npix + 31) / 32) : std::max(16, (npix + 511) / 512);           // elementwise()
+        const int elt_tiles = std::max((npix + ppw - 1) / ppw, ((W + UT_W - 1) / UT_W) * ((H + UT_H - 1) / UT_H));
+        return (std::max(conv_tiles, elt_tiles) + 7) & ~7;
+    }
+    StatOut stat(Tensor &t, int first_channel, int ntiles)
     {
         StatOut s{};
         s.cpg = t.C / gn_groups;
-        s.bsize = (ntiles + 31) / 32;
-        s.nb = (ntiles + s.bsize - 1) / s.bsize;
-        if (!t.part2) { t.part2 = static_cast<double *>(alloc(sizeof(double) * 2 * (size_t)gn_groups * s.nb, true)); t.nb = s.nb; }
-        if (t.nb != s.nb && !rc) { set_error("avc_hgfilter_forward: internal: the producers of one tensor disagree on its tile grid (%d vs %d buckets)", t.nb, s.nb); rc = AVC_ERR_STATE; }
-        s.part2 = t.part2 + 2 * (size_t)(first_channel / s.cpg) * s.nb;
-        if (s.bsize > 1) {
-            s.part = static_cast<float *>(alloc(sizeof(float) * 2 * (size_t)(channels / s.cpg) * ntiles));
-            if (!*counter) *counter = static_cast<unsigned *>(alloc(sizeof(unsigned) * (size_t)s.nb * row_blocks, true));
-        }
+        if (!t.part) { t.nt = stat_pitch(t.H, t.W); t.part = static_cast<f32x2 *>(alloc(sizeof(f32x2) * (size_t)gn_groups * t.nt, true)); }
+        if (ntiles > t.nt && !rc) { set_error("avc_hgfilter_forward: internal: a launch of %d tiles on a statistics table of pitch %d", ntiles, t.nt); rc = AVC_ERR_STATE; }
+        s.ntiles = t.nt;
+        s.part = t.part + (size_t)(first_channel / s.cpg) * t.nt;
         return s;
     }
 
     // conv: x (through gn + ReLU when gn != null) -> raw (with statistics when raw_stats) and / or y[:, ycoff ...] = conv + res
-    // (force_pt: the three convolutions of a block write their slices of ONE statistics table and must agree on the tile grid)
+    // (force_pt: the tile height the block chose for its three convolutions; a two-per-CU launch takes its own)
     void conv(const DevConv &w, const Tensor &x, const DevNorm *gn, Tensor *raw, bool raw_stats, Tensor *y, const Tensor *res, int ycoff, float raw_in_scale = 1.0f,
               int force_pt = 0)
     {
@@ -1222,7 +1205,14 @@ struct Planner {
         L.CT = conv_ct(w.cout); L.PT = (L.TWC == 32 && w.taps != 16) ? 2 : 1;
         auto wgs = [&](int CT, int PT) { const int rows = 4 * PT * (32 / L.TWC); return ((x.H + rows - 1) / rows) * ((x.W + L.TWC - 1) / L.TWC) * (w.cout / (32 * CT)); };
         if (force_pt) L.PT = force_pt;
-        while (wgs(L.CT, L.PT) < ctx->num_cus) {
+        // two half-height workgroups per CU (ConvGeo: OCC2) where the launch then has two to four of them per CU: 3x3 on 32-wide tiles, channel slices
+        // of 64 or 32.  Measured on the encoder's shapes (profiles/r06_enc_phases.md): 44.8 -> 41.8 us (256^2 128 -> 64), 29.9 -> 27.6 (64 -> 64), 20.0 -> 18.9
+        // (64 -> 32), 48.5 -> 43.6 (128^2 256 -> 128 as 32-channel slices); NOT where it takes narrower slices AND more rounds (256^2 256 -> 128: 133 -> 147 us as
+        // 1024 workgroups of 64 channels) nor for the 1x1 convolutions (59.7 -> 77.7 us: they are output-bound, and half tiles double the weight stream).
+        if (ctx->opt.enc_occ2 && L.TWC == 32 && w.taps == 9)
+            for (int ct = std::min(L.CT, 2); ct >= 1 && !L.occ2; ct /= 2)
+                if (wgs(ct, 1) >= 2 * ctx->num_cus && wgs(ct, 1) < 4 * ctx->num_cus) { L.occ2 = true; L.PT = 1; L.CT = ct; }
+        while (!L.occ2 && wgs(L.CT, L.PT) < ctx->num_cus) {
             if (L.PT == 2 && !force_pt) L.PT = 1;
             else if (L.CT > 1 && w.taps != 16) L.CT /= 2;
             else break;
@@ -1230,9 +1220,9 @@ struct Planner {
         const int rows = 4 * L.PT * (32 / L.TWC);
         ConvArgs &a = L.conv;
         a.x = x.data; a.H = x.H; a.W = x.W; a.Cin = x.C;
-        a.in_part2 = gn ? x.part2 : nullptr; a.in_nb = x.nb; a.in_eps = gn_eps;
+        a.in_part = gn ? x.part : nullptr; a.in_nt = x.nt; a.in_eps = gn_eps;
         a.in_inv_n = gn ? 1.0f / ((float)(x.C / gn->groups) * (float)x.H * (float)x.W) : 0.0f;
-        if (gn && !x.part2 && !rc) { set_error("avc_hgfilter_forward: internal: a normalised input without statistics"); rc = AVC_ERR_STATE; }
+        if (gn && !x.part && !rc) { set_error("avc_hgfilter_forward: internal: a normalised input without statistics"); rc = AVC_ERR_STATE; }
         a.gamma = gn ? gn->gamma : nullptr; a.beta = gn ? gn->beta : nullptr; a.in_cpg = gn ? x.C / gn->groups : 1;
         a.in_scale = gn ? 16.0f : raw_in_scale;
         a.in_slope = 1.0f;
@@ -1245,8 +1235,8 @@ struct Planner {
         a.tiles_x = (x.W + L.TWC - 1) / L.TWC; a.tiles_y = (x.H + rows - 1) / rows;
         const int ntiles = a.tiles_x * a.tiles_y;
         const int slices = w.cout / (32 * L.CT);
-        if (raw && raw_stats) a.st_raw = stat(*raw, 0, w.cout, ntiles, slices, &a.counter);
-        if (y) a.st_y = stat(*y, ycoff, w.cout, ntiles, slices, &a.counter);
+        if (raw && raw_stats) a.st_raw = stat(*raw, 0, ntiles);
+        if (y) a.st_y = stat(*y, ycoff, ntiles);
         // few workgroups, each streaming its whole K serially, are bound by the latency of their weight stream: split K over more of them
         const int wg = ntiles * (w.cout / (32 * L.CT)), nchunk = x.C / 32;
         a.range_flag = e->range_flag;
@@ -1285,7 +1275,7 @@ struct Planner {
         g.a = a.data; g.b = b ? b->data : nullptr; g.out = out.data; g.H = H; g.W = W; g.C = a.C;
         g.Hb = b ? b->H : a.H; g.Wb = b ? b->W : a.W;
         if (gn) {
-            g.in_part2 = a.part2; g.in_nb = a.nb; g.gamma = gn->gamma; g.beta = gn->beta; g.in_cpg = a.C / gn->groups;
+            g.in_part = a.part; g.in_nt = a.nt; g.gamma = gn->gamma; g.beta = gn->beta; g.in_cpg = a.C / gn->groups;
             g.in_inv_n = 1.0f / ((float)g.in_cpg * (float)a.H * (float)a.W); g.in_eps = gn_eps;
         }
         const int npix = H * W;
@@ -1294,12 +1284,12 @@ struct Planner {
             L.ut_x = (W + UT_W - 1) / UT_W; L.ut_y = (H + UT_H - 1) / UT_H;
             g.ntiles = L.ut_x * L.ut_y;
             g.ppw = UT_H * UT_W;
-            g.st = stat(out, 0, a.C, g.ntiles, a.C / UT_C, &g.counter);
+            g.st = stat(out, 0, g.ntiles);
             L.grid = (unsigned)(g.ntiles * (a.C / UT_C));
         } else {
             g.ppw = npix <= 1024 ? std::max(16, (npix + 31) / 32) : std::max(16, (npix + 511) / 512);      // small tensors: <= 32 tiles, no tickets
             g.ntiles = (npix + g.ppw - 1) / g.ppw;
-            g.st = stat(out, 0, a.C, g.ntiles, 1, &g.counter);
+            g.st = stat(out, 0, g.ntiles);
             L.grid = (unsigned)g.ntiles;
         }
         push(L);
@@ -1325,24 +1315,30 @@ struct Planner {
     }
 };
 
-template <int CT, int PT, int TAPS, int TWC, bool NORM>
+template <int CT, int PT, int TAPS, int TWC, bool NORM, bool OCC2 = false>
 static int launch_conv_t(const ConvArgs &a, unsigned grid, hipStream_t s)
 {
     static bool attr[64] = {};                               // per device: the attribute belongs to the function on the current device
     int dev = 0;
     AVC_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr[dev]) {
-        AVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<CT, PT, TAPS, TWC, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    ConvGeo<PT, TAPS, TWC>::L_TOTAL));
+        AVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<CT, PT, TAPS, TWC, NORM, OCC2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    ConvGeo<PT, TAPS, TWC, OCC2>::L_TOTAL));
         if (dev >= 0 && dev < 64) attr[dev] = true;
     }
-    constexpr int lds = ConvGeo<PT, TAPS, TWC>::L_TOTAL;
-    hipLaunchKernelGGL((conv_mfma_kernel<CT, PT, TAPS, TWC, NORM>), dim3(grid), dim3(256), lds, s, a);
+    constexpr int lds = ConvGeo<PT, TAPS, TWC, OCC2>::L_TOTAL;
+    static_assert(!OCC2 || 2 * lds <= 163840, "two workgroups of this variant do not fit a CU's LDS");
+    hipLaunchKernelGGL((conv_mfma_kernel<CT, PT, TAPS, TWC, NORM, OCC2>), dim3(grid), dim3(256), lds, s, a);
     return AVC_OK;
 }
 
 static int launch_conv(const Launch &L, hipStream_t s)
 {
+#define AVC_ENC_OCC2(CT_, TAPS_, NORM_) \
+    if (L.occ2 && L.CT == CT_ && L.PT == 1 && L.TAPS == TAPS_ && L.TWC == 32 && L.norm == NORM_) return launch_conv_t<CT_, 1, TAPS_, 32, NORM_, true>(L.conv, L.grid, s);
+    AVC_ENC_OCC2(1, 9, true) AVC_ENC_OCC2(2, 9, true) AVC_ENC_OCC2(1, 1, true) AVC_ENC_OCC2(2, 1, true) AVC_ENC_OCC2(1, 1, false) AVC_ENC_OCC2(2, 1, false)
+#undef AVC_ENC_OCC2
+    if (L.occ2) { set_error("avc_hgfilter_forward: no two-per-CU kernel for CT %d PT %d taps %d tile width %d norm %d", L.CT, L.PT, L.TAPS, L.TWC, (int)L.norm); return AVC_ERR_STATE; }
 #define AVC_ENC_CASE(CT_, PT_, TAPS_, TWC_, NORM_) \
     if (L.CT == CT_ && L.PT == PT_ && L.TAPS == TAPS_ && L.TWC == TWC_ && L.norm == NORM_) return launch_conv_t<CT_, PT_, TAPS_, TWC_, NORM_>(L.conv, L.grid, s);
 #define AVC_ENC_CT(PT_, TAPS_, TWC_, NORM_) AVC_ENC_CASE(1, PT_, TAPS_, TWC_, NORM_) AVC_ENC_CASE(2, PT_, TAPS_, TWC_, NORM_) AVC_ENC_CASE(4, PT_, TAPS_, TWC_, NORM_)
@@ -1416,7 +1412,7 @@ static int build_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
     e->out = out;
     e->plan_allocs = P.allocs;
     if (P.rc) { free_plan(e); return P.rc; }
-    e->Hin = Hin; e->Win = Win; e->fork = ctx->opt.enc_fork; e->ksplit = ctx->opt.enc_ksplit;
+    e->Hin = Hin; e->Win = Win; e->fork = ctx->opt.enc_fork; e->ksplit = ctx->opt.enc_ksplit; e->occ2 = ctx->opt.enc_occ2;
     // record the launches once as a hipGraph (replayed with one hipGraphLaunch per frame)
     if (ctx->opt.enc_graph) {
         if (!e->cap_stream) AVC_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
@@ -1445,7 +1441,7 @@ int encoder_forward(avc_ctx *ctx, const float *image, int H, int W, float *feat_
     Encoder *e = static_cast<Encoder *>(ctx->encoder);
     AVC_REQUIRE(e && e->packed, AVC_ERR_STATE, "avc_hgfilter_forward: no encoder weights (call avc_hgfilter_pack first)");
     AVC_REQUIRE(image && H >= 2 && W >= 2 && (int64_t)H * W <= (1 << 22), AVC_ERR_ARG, "avc_hgfilter_forward: NULL image or unsupported size %d x %d", H, W);
-    if (e->Hin != H || e->Win != W || e->fork != ctx->opt.enc_fork || e->ksplit != ctx->opt.enc_ksplit || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
+    if (e->Hin != H || e->Win != W || e->fork != ctx->opt.enc_fork || e->ksplit != ctx->opt.enc_ksplit || e->occ2 != ctx->opt.enc_occ2 || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
         // (re)building frees buffers a replay in flight may still use
         AVC_HIP(hipDeviceSynchronize());
         if (int rc = build_plan(ctx, e, H, W)) return rc;
@@ -1725,7 +1721,7 @@ static int build_unet_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
     e->out = out;
     e->plan_allocs = P.allocs;
     if (P.rc) { free_plan(e); return P.rc; }
-    e->Hin = Hin; e->Win = Win; e->fork = ctx->opt.enc_fork; e->ksplit = ctx->opt.enc_ksplit;
+    e->Hin = Hin; e->Win = Win; e->fork = ctx->opt.enc_fork; e->ksplit = ctx->opt.enc_ksplit; e->occ2 = ctx->opt.enc_occ2;
     if (ctx->opt.enc_graph) {
         if (!e->cap_stream) AVC_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
         AVC_HIP(hipDeviceSynchronize());                    // the zero-fills of the plan's buffers (null stream) are done
@@ -1750,7 +1746,7 @@ int unet_forward(avc_ctx *ctx, const float *pos_map, int H, int W, float *out_nc
     Encoder *e = static_cast<Encoder *>(ctx->unet);
     AVC_REQUIRE(e && e->packed, AVC_ERR_STATE, "avc_unet_forward: no U-Net weights (call avc_unet_pack first)");
     AVC_REQUIRE(pos_map, AVC_ERR_ARG, "avc_unet_forward: NULL position map");
-    if (e->Hin != H || e->Win != W || e->ksplit != ctx->opt.enc_ksplit || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
+    if (e->Hin != H || e->Win != W || e->ksplit != ctx->opt.enc_ksplit || e->occ2 != ctx->opt.enc_occ2 || (ctx->opt.enc_graph != 0) != (e->exec != nullptr)) {
         AVC_HIP(hipDeviceSynchronize());
         if (int rc = build_unet_plan(ctx, e, H, W)) return rc;
     }

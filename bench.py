@@ -474,7 +474,10 @@ def main():
                        'semantics': '`value` is the DENSE stress variant BASELINE configs[1] names (every one of the 256^3 grid points evaluated); the reference itself '
                                     'evaluates only the valid band around the canonical SMPL and fills the rest (main.py:362-363): that is `masked` and the '
                                     '`configs` legs below',
-                       'dense_points': 'generated from the grid index (avc_avatar_query_grid), offsets not written'},
+                       'dense_points': 'generated from the grid index (avc_avatar_query_grid), offsets not written',
+                       # third-party arithmetic whose pinned version could not be had offline: parity is pinned on what IS here
+                       'unpinned': ['scikit-image 0.17.2 marching_cubes (pinned on 0.18.3)', 'pytorch3d 0.6.0 knn_points tie order',
+                                    'trimesh 3.9.15 contains', 'opencv resize / Rodrigues']},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_TFLOPS,
                          # HBM-side bytes per launch of the dense 256^3 query + its column pass: PMC counters of separate rocprofv3 --pmc passes over this very launch
@@ -644,7 +647,42 @@ def other_configs(device, frames=3):
     out['configs[3]'] = {'workload': '512^3 dense grid (134,217,728 points) + marching cubes + normals + LBS, colour head on 200 k vertices (64 samples per ray)',
                          'avatar_frame_ms': t5, 'frames_per_s': 1e3 / t5, 'query_kernel_ms': qa.value, 'vertices': int(a5['cano_v'].shape[0]),
                          'faces': int(a5['f'].shape[0]), 'colour_vertices': nv, 'colour_ms': tc, 'rgb_finite': bool(torch.isfinite(rgb).all())}
+    del ds, pipe, items, a5, v, n, rgb
+    torch.cuda.empty_cache()
+    out['main_py_e2e'] = main_py_e2e(out['example.yaml']['ms_per_frame'])
     return out
+
+
+def main_py_e2e(device_ms, frames=32):
+    """The entry point itself, end to end: `python main.py -c configs/example.yaml -m test --synthetic --frames 32` as a process of its
+    own, files written to a scratch directory, timed by the loop itself (--timing-json: steady frames from the third on, until the last file is closed).
+    Three output shapes: none; the reference's mesh output (live avatar + live reconstruction as PLY, main.py:491-498); PLY + every mesh tensor as .npz."""
+    import shutil
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix='avc_e2e_')
+    legs = {}
+    try:
+        for tag, flags in (('no outputs', ['--no-npz']), ('ply (the reference\'s mesh output)', ['--no-npz', '--save-ply']), ('ply + npz', ['--save-ply'])):
+            tj = os.path.join(tmp, 'timing.json')
+            cmd = [sys.executable, os.path.join(ROOT, 'main.py'), '-c', os.path.join(ROOT, 'configs', 'example.yaml'), '-m', 'test', '--synthetic',
+                   '--frames', str(frames), '--output-dir', os.path.join(tmp, 'out'), '--timing-json', tj] + flags
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+            if r.returncode != 0 or not os.path.exists(tj):
+                legs[tag] = {'error': (r.stderr or r.stdout)[-400:]}
+                continue
+            t = json.load(open(tj))
+            legs[tag] = {'ms_per_frame': t['e2e_ms_per_frame'], 'frames_per_s': 1e3 / t['e2e_ms_per_frame'], 'vs_device_figure': t['e2e_ms_per_frame'] / device_ms,
+                         'device_done_ms_per_frame': t['device_ms_per_frame'], 'mb_written_per_frame': t['bytes_written'] / 1e6 / t['frames'],
+                         'writer_tail_ms': t['writer_tail_ms'], 'waited_for_writer_slot_ms': t['waited_for_writer_slot_ms'],
+                         'h2d_copies_per_frame': t['h2d_copies'] / t['frames'], 'first_frame_ms': t['first_frame_ms']}
+            shutil.rmtree(os.path.join(tmp, 'out'), ignore_errors=True)
+            os.remove(tj)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {'command': f'python main.py -c configs/example.yaml -m test --synthetic --frames {frames} [--no-npz] [--save-ply]', 'frames': frames,
+            'device_figure_ms': device_ms, 'timed': 'by the loop itself (main.py --timing-json): frames 3..N, until the last file is closed',
+            'scratch': 'tempfile.mkdtemp() of the box', 'legs': legs}
 
 
 def masked_run(res, device, K, W):

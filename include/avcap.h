@@ -380,7 +380,10 @@ int avc_timing_read_cycles(avc_ctx *ctx, int which, double *avg_cycles_out, int6
  *   "mc_walk"      1 (default: marching cubes classifies volumes whose 1024-point tiles are whole x rows of one z plane -- 256^3, 512^3, 384 x 384 x 128 --
  *                  with a pass that walks z inside a workgroup: a quarter of the cache requests) | 0 (the general classify pass for every volume); same results
  *   "enc_fork"     1 (default: the hourglass' upper branches run on a second stream -- parallel branches of the hipGraph -- beside the lower ones) |
- *                  0 one stream -- same kernels, same bits */
+ *                  0 one stream -- same kernels, same bits
+ *   "enc_occ2"     1 (default: an encoder convolution whose launch has at least two half-height workgroups per CU runs them two per CU, each with half
+ *                  the LDS, so that one workgroup's fetch and output bursts fall into the other's matrix work) | 0 one workgroup per CU; the two cut the
+ *                  image into different tiles, so GroupNorm's fp32 partial sums -- and with them the outputs -- differ by rounding (~1e-7) */
 int avc_set_option(avc_ctx *ctx, const char *name, int value);
 
 #ifdef __cplusplus

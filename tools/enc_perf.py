@@ -49,12 +49,13 @@ def main():
     hg = HGFilter(1, 4, 6, 32, 'group', 'no_down', False).to('cuda').eval()
     syn.load_synth(hg, gi.SEED_NET)
     x = torch.from_numpy(gi.normal_maps(a.res)[None]).cuda()
-    settings = [(1, 1, 1)] if a.once else [(1, 1, 1), (0, 1, 1), (1, 1, 0), (1, 0, 1)]
+    settings = [(1, 1, 1, 1)] if a.once else [(1, 1, 1, 1), (1, 1, 1, 0), (1, 1, 1, 1), (1, 1, 1, 0), (0, 1, 1, 1), (1, 1, 0, 1), (1, 0, 1, 1)]
     with torch.no_grad():
-        for graph, ksplit, fork in settings:
+        for graph, ksplit, fork, occ2 in settings:
             _lib.set_option('enc_graph', graph)
             _lib.set_option('enc_ksplit', ksplit)
             _lib.set_option('enc_fork', fork)
+            _lib.set_option('enc_occ2', occ2)
             for _ in range(1 if a.once else 3):
                 hg.encode(x, want_feat=False, bind=True)
             torch.cuda.synchronize()
@@ -66,7 +67,7 @@ def main():
                 hg.encode(x, want_feat=False, bind=True)
             e1.record()
             torch.cuda.synchronize()
-            print(f'encoder {a.res}^2  graph={graph} ksplit={ksplit} fork={fork}: {e0.elapsed_time(e1) / a.iters:.3f} ms per frame', flush=True)
+            print(f'encoder {a.res}^2  graph={graph} ksplit={ksplit} fork={fork} occ2={occ2}: {e0.elapsed_time(e1) / a.iters:.3f} ms per frame', flush=True)
 
 
 if __name__ == '__main__':

@@ -58,24 +58,19 @@ static double time_us(F &&launch, int iters)
     return 1e3 * ms / iters;
 }
 
-static StatOut make_stat(int C, int first, int channels, int ntiles, int row_blocks, unsigned **counter)
+static StatOut make_stat(int C, int first, int ntiles)
 {
     StatOut s{};
-    s.cpg = C / 32;
-    s.bsize = (ntiles + 31) / 32; s.nb = (ntiles + s.bsize - 1) / s.bsize;
-    double *t = nullptr; CK(hipMalloc(&t, sizeof(double) * 2 * 32 * s.nb)); CK(hipMemset(t, 0, sizeof(double) * 2 * 32 * s.nb));
-    s.part2 = t + 2 * (size_t)(first / s.cpg) * s.nb;
-    if (s.bsize > 1) {
-        s.part = dev_zero(2 * (size_t)(channels / s.cpg) * ntiles);
-        if (!*counter) { CK(hipMalloc(counter, sizeof(unsigned) * s.nb * row_blocks)); CK(hipMemset(*counter, 0, sizeof(unsigned) * s.nb * row_blocks)); }
-    }
+    s.cpg = C / 32; s.ntiles = ntiles;
+    f32x2 *t = nullptr; CK(hipMalloc(&t, sizeof(f32x2) * 32 * ntiles)); CK(hipMemset(t, 0, sizeof(f32x2) * 32 * ntiles));
+    s.part = t + (size_t)(first / s.cpg) * ntiles;
     return s;
 }
-static double *dev_part2(int nb)
+static f32x2 *dev_part(int nt)
 {
-    std::vector<double> h(2 * 32 * nb);
-    for (int i = 0; i < 32 * nb; ++i) { h[2 * i] = 0.01 * (i % 7); h[2 * i + 1] = 1.0 + 0.1 * (i % 5); }
-    double *p = nullptr; CK(hipMalloc(&p, h.size() * sizeof(double))); CK(hipMemcpy(p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<float> h(2 * 32 * (size_t)nt);
+    for (int i = 0; i < 32 * nt; ++i) { h[2 * i] = 0.01f * (i % 7); h[2 * i + 1] = 1.0f + 0.1f * (i % 5); }
+    f32x2 *p = nullptr; CK(hipMalloc(&p, h.size() * sizeof(float))); CK(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     return p;
 }
 
@@ -97,10 +92,12 @@ int main(int argc, char **argv)
         DevConv dc;
         if (pack_conv(&e, c, taps, dc, "bench")) return 1;
         Launch L{}; L.kind = L_CONV; L.TAPS = taps; L.norm = taps != 16; L.TWC = W >= 32 ? 32 : 16; L.CT = CT; L.PT = PT;
+        L.occ2 = getenv("OCC2") && atoi(getenv("OCC2"));
         const int rows = 4 * PT * (32 / L.TWC);
         ConvArgs &a = L.conv;
         a.x = dev_random((size_t)H * W * Cin, -2.f, 2.f, 2); a.H = H; a.W = W; a.Cin = Cin;
-        a.in_part2 = dev_part2(32); a.in_nb = 32; a.in_inv_n = 1.0f / 32; a.in_eps = 1e-5f;
+        const int in_nt = getenv("IN_NT") ? atoi(getenv("IN_NT")) : 256;
+        a.in_part = dev_part(in_nt); a.in_nt = in_nt; a.in_inv_n = 1.0f / in_nt; a.in_eps = 1e-5f;
         a.gamma = dev_random(Cin, 0.5f, 1.5f, 4); a.beta = dev_random(Cin, -0.5f, 0.5f, 5); a.in_cpg = Cin / 32; a.in_scale = 16.f; a.in_slope = 1.0f;
         const int v = CT == 4 ? 2 : (CT == 2 ? 1 : 0);
         a.slice_bytes = (unsigned)(Cin / 32) * taps * 2 * CT * 2048;
@@ -111,15 +108,14 @@ int main(int argc, char **argv)
         a.y = stats >= 2 ? dev_zero((size_t)H * W * yC) : nullptr; a.res = stats >= 2 ? dev_random((size_t)H * W * yC, -1.f, 1.f, 6) : nullptr; a.yC = yC; a.ycoff = 0;
         a.tiles_x = (W + L.TWC - 1) / L.TWC; a.tiles_y = (H + rows - 1) / rows;
         const int ntiles = a.tiles_x * a.tiles_y, wg = ntiles * (Cout / (32 * CT));
-        if (stats >= 1) a.st_raw = make_stat(Cout, 0, Cout, ntiles, Cout / (32 * CT), &a.counter);
-        if (stats >= 2) a.st_y = make_stat(yC, 0, Cout, ntiles, Cout / (32 * CT), &a.counter);
+        if (stats >= 1) a.st_raw = make_stat(Cout, 0, ntiles);
+        if (stats >= 2) a.st_y = make_stat(yC, 0, ntiles);
         a.ksplit = ksplit; a.range_flag = nullptr;
         if (ksplit > 1) {
             a.kpart = dev_zero((size_t)wg * ksplit * 256 * PT * CT * 16);
             CK(hipMalloc(&a.kcounter, sizeof(unsigned) * wg)); CK(hipMemset(a.kcounter, 0, sizeof(unsigned) * wg));
         }
         L.grid = (unsigned)(wg * ksplit);
-        a.xcd_bands = (getenv("XCD") && atoi(getenv("XCD")) && ntiles % 8 == 0) ? 8 : 0;
         const double us = time_us([&] { if (launch_conv(L, 0)) exit(1); }, iters);
 #ifdef AVC_ENC_PHASES
         {   // one more launch with s_memtime stamps per workgroup: where the time of a workgroup goes (cycles of the 100 MHz-independent shader counter)
@@ -156,25 +152,25 @@ int main(int argc, char **argv)
         g.a = dev_random((size_t)npix * C, -1.f, 1.f, 1); g.b = dev_random((size_t)npix / 4 * C, -1.f, 1.f, 2); g.Hb = H / 2; g.Wb = W / 2;
         UpTiledArgs u{g, (W + UT_W - 1) / UT_W, (H + UT_H - 1) / UT_H};
         u.e.ntiles = u.tiles_x * u.tiles_y; u.e.ppw = UT_H * UT_W;
-        if (stats) u.e.st = make_stat(C, 0, C, u.e.ntiles, C / UT_C, &u.e.counter);
+        if (stats) u.e.st = make_stat(C, 0, u.e.ntiles);
         const unsigned grid = u.e.ntiles * (C / UT_C);
         const double us = time_us([&] { hipLaunchKernelGGL(upadd_tiled_kernel, dim3(grid), dim3(256), 0, 0, u); }, iters);
         printf("upadd (tiled) %dx%dx%d stats %d: %u workgroups, %.1f us, %.2f TB/s of (up1 + out + low3)\n", H, W, C, (int)stats, grid, us, 2.25 * npix * C * 4 / us * 1e-6);
         g.ppw = std::max(16, (npix + 511) / 512); g.ntiles = (npix + g.ppw - 1) / g.ppw;
-        if (stats) g.st = make_stat(C, 0, C, g.ntiles, 1, &g.counter);
+        if (stats) g.st = make_stat(C, 0, g.ntiles);
         const double us2 = time_us([&] { hipLaunchKernelGGL(upadd_kernel, dim3(g.ntiles), dim3(256), 0, 0, g); }, iters);
         printf("upadd (direct) %dx%dx%d stats %d: %d workgroups, %.1f us\n", H, W, C, (int)stats, g.ntiles, us2);
         return 0;
     }
     g.ppw = std::max(16, (npix + 511) / 512); g.ntiles = (npix + g.ppw - 1) / g.ppw;
-    if (stats) g.st = make_stat(C, 0, C, g.ntiles, 1, &g.counter);
+    if (stats) g.st = make_stat(C, 0, g.ntiles);
     if (what == "pool") {
         g.a = dev_random((size_t)npix * 4 * C, -1.f, 1.f, 1); g.Hb = 2 * H; g.Wb = 2 * W;
         const double us = time_us([&] { hipLaunchKernelGGL(avgpool_kernel, dim3(g.ntiles), dim3(256), 0, 0, g); }, iters);
         printf("avgpool -> %dx%dx%d stats %d: %d workgroups, %.1f us, %.2f TB/s\n", H, W, C, (int)stats, g.ntiles, us, 5.0 * npix * C * 4 / us * 1e-6);
     } else if (what == "normrelu") {
         g.a = dev_random((size_t)npix * C, -1.f, 1.f, 1); g.Hb = H; g.Wb = W;
-        g.in_part2 = dev_part2(32); g.in_nb = 32; g.in_inv_n = 1.0f / 32; g.in_eps = 1e-5f; g.gamma = dev_random(C, 0.5f, 1.5f, 4); g.beta = dev_random(C, -0.5f, 0.5f, 5); g.in_cpg = C / 32;
+        g.in_part = dev_part(256); g.in_nt = 256; g.in_inv_n = 1.0f / 256; g.in_eps = 1e-5f; g.gamma = dev_random(C, 0.5f, 1.5f, 4); g.beta = dev_random(C, -0.5f, 0.5f, 5); g.in_cpg = C / 32;
         const double us = time_us([&] { hipLaunchKernelGGL(normrelu_kernel, dim3(g.ntiles), dim3(256), 0, 0, g); }, iters);
         printf("normrelu %dx%dx%d stats %d: %d workgroups, %.1f us, %.2f TB/s\n", H, W, C, (int)stats, g.ntiles, us, 2.0 * npix * C * 4 / us * 1e-6);
     }
