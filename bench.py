@@ -56,9 +56,8 @@ PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA (MI355X_MICROA
 SUSTAINED_F16_TFLOPS = 1505.0      # what this part sustains at its power cap on split-fp16 MFMAs of FULL-ENTROPY operands fed from LDS, nothing else in
                                     # the instruction stream (1.47 GHz): tools/ubench/mfma_order.hip, profiles/r03_power_wall.md -- information only
                                     # (round 1's 1673 was measured on low-entropy operands)
-# roofline.traffic -- HBM bytes per launch -- comes from PMC counters, which only a separate `rocprofv3 --pmc` pass can collect (profiles/r05_pmc_avatar.md, the
-# round's final library, the launch this script times): query kernel (2 x 145,889 + 65,536) KB + column pass (2 x 11,670 + 131,072) KB
-PMC_TRAFFIC_BYTES_256 = int((2 * 145889 + 65536 + 2 * 11670.2 + 131072) * 1024)
+# roofline.traffic -- HBM bytes per launch -- comes from PMC counters, which only a separate `rocprofv3 --pmc` pass can collect: tools/pmc_traffic.py
+# writes them, with the hash of the kernel's sources, to profiles/pmc_traffic.json; this script carries the figure only while that hash is the tree's.
 
 
 class _stdout_to_stderr:
@@ -452,6 +451,9 @@ def main():
     achieved = N * FLOP_PER_POINT / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
 
     if rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import pmc_traffic
+        traffic_bytes, traffic_ref = pmc_traffic.load(ROOT)
         line = {
             'metric': 'reconstructed-mesh frames/sec at 256^3 grid (avatar occupancy-only, dense query + marching cubes + LBS)',
             'value': world * K / dt, 'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': K, 'warmup': W,
@@ -480,12 +482,13 @@ def main():
                                     'trimesh 3.9.15 contains', 'opencv resize / Rodrigues']},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_TFLOPS,
-                         # HBM-side bytes per launch of the dense 256^3 query + its column pass: PMC counters of separate rocprofv3 --pmc passes over this very launch
-                         # with the round's final library (profiles/r05_pmc_avatar.md: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the guide's gfx950 correction); counters
-                         # cannot be read from inside this process, so the figure is that pass's, not this run's -- null for any other grid
-                         'traffic': PMC_TRAFFIC_BYTES_256 if res == 256 else None, 'traffic_unit': 'bytes per launch',
-                         'traffic_note': 'separate rocprofv3 --pmc passes of the same launch (profiles/r05_pmc_avatar.md): 0.524 GB against 0.087 GB algorithmic -- the 131 MB column '
-                                         'table written and read back, the feature map once per XCD; 0.1 % of the HBM bandwidth (the kernel is MFMA / power bound)',
+                         # HBM-side bytes per launch of the dense 256^3 query + its column pass: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of separate rocprofv3 --pmc
+                         # passes over this very launch (the guide's gfx950 correction).  Counters cannot be read from inside this process: the figure is that
+                         # pass's -- null for any other grid, and null once the kernel's sources differ from the ones it was measured on (`traffic_ref.state`)
+                         'traffic': traffic_bytes if res == 256 else None, 'traffic_unit': 'bytes per launch', 'traffic_ref': traffic_ref,
+                         'traffic_note': 'separate rocprofv3 --pmc passes of the same launch (tools/pmc_traffic.py -> profiles/pmc_traffic.json, carried only while the kernel '
+                                         'sources hash to what they were when the counters were read): ~0.52 GB against 0.087 GB algorithmic -- the 131 MB column table written '
+                                         'and read back, the feature map once per XCD; 0.1 % of the HBM bandwidth (the kernel is MFMA / power bound)',
                          'kernel': 'avc::avatar_kernel<true,false,1> (+ its column_terms_kernel pass, timed together)', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
                          'shader_cycles_per_launch': avg_cyc.value, 'clock_mhz': (avg_cyc.value / (avg_ms.value * 1e3)) if avg_ms.value > 0 else 0.0,
                          'cycles_per_mfma': avg_cyc.value / (4728 * -(-(N // 128) // min(N // 128, query_wgs or torch.cuda.get_device_properties(device).multi_processor_count))) if avg_cyc.value > 0 else 0.0,

@@ -284,3 +284,26 @@ def test_hgfilter_range_check_trips():
     finally:
         config.check_range = False
         _lib.apply_range_check(_lib.ctx(x.device))
+
+
+def test_hgfilter_one_or_two_workgroups_per_cu():
+    """avc_set_option "enc_occ2": the 3x3 convolutions that have two to four half-height workgroups per CU run two per CU (half the LDS each, one staged
+    chunk), the others one per CU.  The two forms cut the image into different tiles, so the fp32 per-tile partial sums of GroupNorm differ by rounding: both
+    are held to the launch-by-launch reference, and to each other to a few 1e-6 of the map's scale; each is deterministic."""
+    from avatarcap_amd import _lib
+    hg = _hg()
+    x = _t(gi.normal_maps(512)[None])
+    with torch.no_grad():
+        a = hg(x)[0][-1].clone()
+        assert torch.equal(hg(x)[0][-1], a)
+        _lib.set_option('enc_occ2', 0)
+        try:
+            worst = _walk_plan(hg, x)
+            b = hg(x)[0][-1].clone()
+            assert torch.equal(hg(x)[0][-1], b)
+        finally:
+            _lib.set_option('enc_occ2', 1)
+        assert torch.equal(hg(x)[0][-1], a)                                       # back: the plan is rebuilt, same bits as before
+    d = float((a - b).abs().max()) / max(1.0, float(a.abs().max()))
+    print(f'one workgroup per CU: worst launch {worst:.3e}; feature map two-per-CU vs one-per-CU {d:.3e}')
+    assert d < 2e-5

@@ -4,6 +4,8 @@
 //   order 1  t0.hh t0.hl t0.lh t1.hh t1.hl t1.lh   (three-long dependent chains: the accumulator can stay in the matrix pipe's forwarding path)
 //   trunc B  the B `lo` fragment (activation residuals) keeps 4 of its 11 significant bits
 //   trunc A  the A `lo` fragments (weight residuals) keep 4 significant bits
+//   no LDS   (round 6, TRUNC == 3) the A fragments are read from LDS ONCE, four k-steps' worth kept in registers and rotated: the same MFMAs on operands of the
+//            same entropy without a single ds_read in the loop -- what the LDS operand path costs at the power cap
 // Full-entropy fp16 operands (hashed), A fragments from LDS one k-step ahead (4 x ds_read_b128 per k-step), B fragments rotate through 8 registers sets,
 // 256 workgroups x 4 waves, one wave per SIMD.  hipcc --offload-arch=gfx950 -O3 -o mfma_order mfma_order.hip
 #include <hip/hip_runtime.h>
@@ -45,11 +47,27 @@ __global__ __launch_bounds__(256, 1) void bench(float *out, long long *cyc, int 
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
     half8 ah[2][2], al[2][2];
     for (int t = 0; t < 2; ++t) { ah[0][t] = *reinterpret_cast<const half8 *>(smem + addr + t * 2048); al[0][t] = *reinterpret_cast<const half8 *>(smem + addr + t * 2048 + 1024); }
+    half8 rh[4][2], rl[4][2];                      // TRUNC == 3: four k-steps of A fragments, register-resident
+    if (TRUNC == 3)
+        for (int k = 0; k < 4; ++k)
+            for (int t = 0; t < 2; ++t) { rh[k][t] = *reinterpret_cast<const half8 *>(smem + addr + (k * 2 + t) * 2048); rl[k][t] = *reinterpret_cast<const half8 *>(smem + addr + (k * 2 + t) * 2048 + 1024); }
+    __syncthreads();
     const long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int cur = u & 1, nxt = cur ^ 1, s = u & 7;
+            if (TRUNC == 3) {
+                const int k = u & 3;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[k][0], bh[s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[k][1], bh[s], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[k][0], bl[s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[k][1], bl[s], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[k][0], bh[s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[k][1], bh[s], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -113,6 +131,7 @@ int main()
         run<1, 0>("order 1 (chains of 3 per tile), full entropy");
         run<0, 1>("order 0, B lo keeps 4 significant bits");
         run<0, 2>("order 0, A lo keeps 4 significant bits");
+        run<0, 3>("order 0, A in registers (no ds_read), full entropy");
     }
     return 0;
 }
