@@ -47,7 +47,9 @@ def build(force: bool = False, verbose: bool = True, asan: bool = False) -> str:
     jobs = []
     # (object name, source, extra flags): fused_mlp.hip is built twice -- the plain kernels and the range-checking flavour
     # (include/avcap.h avc_set_range_check), which live in different namespaces of the same library
-    units = [(src + '.o', src, []) for src in SOURCES] + [('fused_mlp_checked.o', 'fused_mlp.hip', ['-DAVC_CHECK_RANGE=1'])]
+    # and a third time with the Softplus layers' weight scale undone in the epilogue (-DAVC_LAYER_SCALE=1: namespace `scaled`, pack.cpp add_warp)
+    units = [(src + '.o', src, []) for src in SOURCES] + [('fused_mlp_checked.o', 'fused_mlp.hip', ['-DAVC_CHECK_RANGE=1']),
+                                                          ('fused_mlp_scaled.o', 'fused_mlp.hip', ['-DAVC_LAYER_SCALE=1'])]
     for obj, src, extra in units:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, obj)

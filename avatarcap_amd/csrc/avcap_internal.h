@@ -32,8 +32,7 @@ struct ChunkDesc { uint32_t offset, bytes; };
 struct PackedNet {
     std::vector<uint8_t> stream;      // host copy of the chunk stream
     std::vector<ChunkDesc> chunks;
-    std::vector<float> bias;          // per-row bias, pre-scaled by 2^sw, padded to the tile grid
-    std::vector<float> oscale;        // 2^-sw per layer
+    std::vector<float> bias;          // per-row bias, padded to the tile grid
     std::vector<float> colw;          // column-folded stream only: [conv1 | conv5][256][64] fp32 weights of the 64 pose-feature columns (fused_mlp.hip)
     float *d_colw = nullptr;
     void *d_stream = nullptr;
@@ -41,6 +40,7 @@ struct PackedNet {
     float *d_bias = nullptr;
     bool ready = false;
     bool has_colour = false;
+    float sp_unscale = 1.0f;          // 2^-s: the Softplus layers (the warping field's conv1..7) were packed times 2^s and need the scaled kernels (fused_mlp.hip AVC_LAYER_SCALE)
 };
 
 struct Timing { bool enabled = false; double total_ms[2] = {0, 0}; int64_t launches[2] = {0, 0};
@@ -122,7 +122,13 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
                   float *occ, float *offset, float *rgba, bool template_only, hipStream_t s);
 int launch_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], float *out, hipStream_t s);
 }
-namespace checked {     // the same file built with -DAVC_CHECK_RANGE=1 (synchronous; returns AVC_ERR_RANGE)
+namespace scaled {      // the same file built with -DAVC_LAYER_SCALE=1: Softplus layers packed with a power-of-two weight scale (pack.cpp add_warp)
+int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], int occ_sigmoid,
+                  float *occ, float *offset, float *rgba, bool template_only, hipStream_t s);
+}
+// which build of the avatar kernels serves the context's packed warping field
+inline bool needs_scaled_kernels(const avc_ctx *ctx) { return ctx->warp_tmpl.sp_unscale != 1.0f; }
+namespace checked {     // the same file built with -DAVC_CHECK_RANGE=1 (synchronous; returns AVC_ERR_RANGE; carries the Softplus multiply too)
 int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], int occ_sigmoid,
                   float *occ, float *offset, float *rgba, bool template_only, hipStream_t s);
 int launch_recon(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], float *out, hipStream_t s);

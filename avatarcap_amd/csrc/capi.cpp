@@ -176,8 +176,9 @@ int avc_set_img_feat_map(avc_ctx *ctx, const float *map, int C, int H, int W, av
 static int run_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t n, const float center[3], int sig, float *occ, float *offset,
                       float *rgba, bool template_only, hipStream_t s)
 {
-    return ctx->check_range ? checked::launch_avatar(ctx, pts, grid, n, center, sig, occ, offset, rgba, template_only, s)
-                            : plain::launch_avatar(ctx, pts, grid, n, center, sig, occ, offset, rgba, template_only, s);
+    if (ctx->check_range) return checked::launch_avatar(ctx, pts, grid, n, center, sig, occ, offset, rgba, template_only, s);
+    if (!template_only && needs_scaled_kernels(ctx)) return scaled::launch_avatar(ctx, pts, grid, n, center, sig, occ, offset, rgba, template_only, s);
+    return plain::launch_avatar(ctx, pts, grid, n, center, sig, occ, offset, rgba, template_only, s);
 }
 
 int avc_avatar_query(avc_ctx *ctx, const float *pts, int64_t n, const float center[3], int occupancy_sigmoid,

@@ -65,8 +65,16 @@
 #ifndef AVC_CHECK_RANGE
 #define AVC_CHECK_RANGE 0
 #endif
+// Softplus layers whose weights were packed with a power-of-two scale (pack.cpp add_warp: a BatchNorm fold that leaves the fp16 range): a THIRD build of this
+// file with -DAVC_LAYER_SCALE=1 multiplies the accumulator by the inverse (one v_mul per value, exact) before the Softplus; the default build has no such
+// instruction and no such kernels -- a checkpoint inside the range runs the very code it always ran.  The range-checking build carries the multiply too.
+#ifndef AVC_LAYER_SCALE
+#define AVC_LAYER_SCALE AVC_CHECK_RANGE
+#endif
 #if AVC_CHECK_RANGE
 #define AVC_FLAVOUR checked
+#elif AVC_LAYER_SCALE
+#define AVC_FLAVOUR scaled
 #else
 #define AVC_FLAVOUR plain
 #endif
@@ -114,6 +122,7 @@ struct QueryParams {
     unsigned gry, grz;
     const int32_t *gidx;     // dense-grid mode, optional: the launch covers the n grid points gidx[0..n) (the valid band) instead of all of them
     unsigned *range_flag;    // AVC_CHECK_RANGE builds: set to 1 when a value left the fp16 range
+    float sp_unscale;        // AVC_LAYER_SCALE builds: what undoes the Softplus layers' weight scale (1 when there is none)
     const float *colterms;   // column-folded dense launches: per (x, y) column 512 floats [conv1 | conv5] (column_terms_kernel), else null
     long long *clk;          // timed launches (avc_timing_enable): workgroup 0 stores its s_memtime at entry and exit here, else null
     // subset launches of the reconstruction query (band_prepass_kernel): the folded kernel leaves the tiles flagged in tile_skip (a wavefront with more than
@@ -174,6 +183,9 @@ struct PointAhead {
 // running max of the magnitudes that go through an fp16 split (AVC_CHECK_RANGE builds only)
 struct RangeTrack {
     float amax = 0.0f;
+#if AVC_LAYER_SCALE
+    float unscale = 1.0f;      // 2^-s of the Softplus layers' weight scale (QueryParams::sp_unscale)
+#endif
     __device__ __forceinline__ void see(float a, float b)
     {
 #if AVC_CHECK_RANGE
@@ -628,7 +640,12 @@ __device__ __forceinline__ void epi_part(const f32x16 *__restrict__ acc, Frag *_
             auto write_out = [&]() { out4[2 * t + (r >> 3)].hi[(r & 7) >> 1] = st.hi[i]; out4[2 * t + (r >> 3)].lo[(r & 7) >> 1] = st.lo[i]; };
             auto cvt = [&]() { range.see(x0, x1); const half2_t hv = {(_Float16)x0, (_Float16)x1}; st.hi[i] = __builtin_bit_cast(unsigned, hv); };
             if constexpr (ACT == ACT_SOFTPLUS) {
+#if AVC_LAYER_SCALE
+                if constexpr (R == 0) { x0 = acc[t][r] * range.unscale; x1 = acc[t][r + 1] * range.unscale;
+                                        e0 = __builtin_amdgcn_exp2f(-__builtin_fabsf(x0)); e1 = __builtin_amdgcn_exp2f(-__builtin_fabsf(x1)); }
+#else
                 if constexpr (R == 0) { x0 = acc[t][r]; x1 = acc[t][r + 1]; e0 = __builtin_amdgcn_exp2f(-__builtin_fabsf(x0)); e1 = __builtin_amdgcn_exp2f(-__builtin_fabsf(x1)); }
+#endif
                 else if constexpr (R == 1) { e0 = e0 + 1.0f; e1 = e1 + 1.0f; }
                 else if constexpr (R == 2) { e0 = __builtin_amdgcn_logf(e0); e1 = __builtin_amdgcn_logf(e1); }
                 else if constexpr (R == 3) {
@@ -932,6 +949,9 @@ __device__ __forceinline__ Stream stream_init(const QueryParams &p, int wave, in
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Stream s;
+#if AVC_LAYER_SCALE
+    s.range.unscale = p.sp_unscale;
+#endif
     s.wave = wave; s.lane_off = lane * 16u;
     s.gs = p.wstream;
     s.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p.wstream), 0, (int)p.stream_bytes, 0x00027000);   // raw buffer, range-checked at stream_bytes
@@ -1807,6 +1827,10 @@ int launch_avatar(avc_ctx *ctx, const float *pts, const GridDesc *grid, int64_t 
     p.feat = ctx->pose_feat_hwc; p.H = ctx->pose_H; p.W = ctx->pose_W;
     p.cx = center ? center[0] : 0.f; p.cy = center ? center[1] : 0.f; p.cz = center ? center[2] : 0.f;
     p.wstream = (const char *)net.d_stream; p.bias = net.d_bias;
+    p.sp_unscale = net.sp_unscale;
+#if !AVC_LAYER_SCALE
+    AVC_REQUIRE(net.sp_unscale == 1.0f, AVC_ERR_STATE, "avatar query: internal: a scaled weight stream on the unscaled kernels");
+#endif
     p.out0 = occ; p.out1 = offset; p.out2 = rgba; p.sigmoid_occ = occ_sigmoid;
     p.ntiles = (n + TILE_PTS - 1) / TILE_PTS;
     p.stream_bytes = bytes_until(net, net.chunks.size());

@@ -2,6 +2,7 @@
 // (fp16 hi, fp16 lo) pair, permutes the K axis into the kernels' register "slot" order and lays the
 // result out as the chunk stream the fused kernels stream through LDS (see mlp_layout.h and
 // fused_mlp.hip).  Accepts exactly the tensors of the reference checkpoints.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -27,12 +28,67 @@ const char *last_error() { return g_err.c_str(); }
 
 namespace {
 
+// ---- weights beyond the fp16 range ------------------------------------------------------------------------------------------------------------------------
+// The kernels multiply split-fp16 operands: a weight's `hi` half must be a finite fp16 number.  Round 5 refused any layer with |w| > 3e4 -- a BatchNorm fold with
+// a small running variance, or a weight_norm gain, can produce one -- and had no remedy.  Two remedies, both exact (powers of two):
+//   * ReLU / LeakyReLU / linear layers are positively homogeneous: act(2^s z) = 2^s act(z).  rebalance() scales an output ROW that is out of range (and its
+//     bias) by 2^s, s < 0, down to the magnitude of the layer's ordinary rows, and the matching input COLUMN of every consumer by 2^-s: the network computes the
+//     same function, only the offending channel and what reads it change (a trained network that carries a huge row carries a tiny column behind it: both come
+//     back to ordinary magnitudes, where the split has its full precision and the channel's activation fits fp16 again), and the kernels know nothing of it -- the default build, no instruction added.  A consumer row pushed over the limit by the compensation
+//     is rebalanced in its turn; a HEAD (its output is the result) has nowhere to pass a scale on to and is still refused.
+//   * Softplus is not homogeneous: the warping field's seven Conv1d + BatchNorm1d + Softplus layers share ONE scale 2^s on weights and biases -- the mildest
+//     that brings the largest weight under the limit, because it costs every other weight |s| bits of its `lo` half -- and the `scaled` build of the kernels
+//     (fused_mlp.hip AVC_LAYER_SCALE) multiplies the accumulator by 2^-s in front of the Softplus (PackedNet::sp_unscale).
+constexpr double W_LIMIT = 30000.0;
+
+double max_abs(const std::vector<double> &v) { double m = 0; for (double x : v) m = std::fmax(m, std::fabs(x)); return m; }
+// the s <= 0 closest to 0 with m 2^s <= W_LIMIT
+int down_exponent(double m)
+{
+    int s = 0;
+    while (m > W_LIMIT && s > -1000) { m *= 0.5; --s; }
+    return s;
+}
+void scale_all(std::vector<double> &v, int s) { const double f = std::ldexp(1.0, s); for (double &x : v) x *= f; }
+
+struct Link { int consumer, col0; };       // the producer's outputs are columns [col0, col0 + cout) of the consumer's input
+struct Node { std::vector<double> *W, *b; int cout, cin; bool head; std::vector<Link> out; };
+// in topological order; false: a head layer is out of range.  `rows_scaled`: how many rows were touched.
+// An out-of-range row is brought to the magnitude of the layer's ORDINARY rows (the median row maximum), not merely under the limit: its activation shrinks by
+// the same factor, and an activation has to fit fp16 as well (a row left at 2^14 would still put 2^18 times the ordinary values into the next layer's operands).
+bool rebalance(std::vector<Node> &g, int *rows_scaled = nullptr)
+{
+    for (Node &n : g) {
+        std::vector<double> rmax(n.cout, 0.0), ordinary;
+        for (int r = 0; r < n.cout; ++r) {
+            for (int i = 0; i < n.cin; ++i) rmax[r] = std::fmax(rmax[r], std::fabs((*n.W)[(size_t)r * n.cin + i]));
+            if (rmax[r] <= W_LIMIT && rmax[r] > 0.0) ordinary.push_back(rmax[r]);
+        }
+        std::sort(ordinary.begin(), ordinary.end());
+        const double med = ordinary.empty() ? 1.0 : ordinary[ordinary.size() / 2];
+        for (int r = 0; r < n.cout; ++r) {
+            if (!(rmax[r] > W_LIMIT)) continue;
+            if (n.head) return false;
+            const int s = (int)std::floor(std::log2(med / rmax[r]));                 // rmax 2^s in (med / 2, med]
+            const double dn = std::ldexp(1.0, s), up = std::ldexp(1.0, -s);
+            for (int i = 0; i < n.cin; ++i) (*n.W)[(size_t)r * n.cin + i] *= dn;
+            if (n.b) (*n.b)[r] *= dn;
+            if (rows_scaled) ++*rows_scaled;
+            for (const Link &k : n.out) {
+                Node &c = g[k.consumer];
+                for (int q = 0; q < c.cout; ++q) (*c.W)[(size_t)q * c.cin + k.col0 + r] *= up;
+            }
+        }
+    }
+    return true;
+}
+
 struct Seg { int ks; std::function<int(int)> col; };   // slot -> column of W (or -1 = zero)
 
 struct Builder {
     PackedNet &net;
     bool overflow = false;
-    explicit Builder(PackedNet &n) : net(n) { net.stream.clear(); net.chunks.clear(); net.bias.clear(); net.oscale.clear(); net.colw.clear(); }
+    explicit Builder(PackedNet &n) : net(n) { net.stream.clear(); net.chunks.clear(); net.bias.clear(); net.colw.clear(); net.sp_unscale = 1.0f; }
 
     // W: (cout, cin) row-major effective weights, b: (cout).  tpc = tiles per chunk (accumulators
     // live at once in the kernel), kspc = k-steps per chunk.
@@ -43,14 +99,11 @@ struct Builder {
         const int nt = ((nt_raw + tpc - 1) / tpc) * tpc;
         double m = 0;
         for (double w : W) m = std::fmax(m, std::fabs(w));
-        // Power-of-two pre-scaling of a layer's weights (undone in the epilogue) would keep the fp16 `lo`
-        // halves normal.  It is only needed when the largest weight would overflow fp16: gfx950 MFMA
-        // does not flush fp16 subnormal inputs, a subnormal `lo` still carries the residual to 2^-25
-        // absolute, and skipping the rescale saves one VALU instruction per activation.
-        const int sw = 0;
-        if (m > 30000.0) overflow = true;     // reported by the caller: |w| must stay below the fp16 range
-        const double scale = std::ldexp(1.0, sw);
-        net.oscale.push_back((float)std::ldexp(1.0, -sw));
+        // No per-layer rescale here: gfx950 MFMA does not flush fp16 subnormal inputs, a subnormal `lo` still carries the residual to 2^-25 absolute, and small
+        // weights need none.  LARGE weights are dealt with before they get here (rebalance() / the warping field's Softplus scale, below); what still exceeds
+        // the range at this point is a head layer, which has nowhere to put a scale.
+        if (m > W_LIMIT) overflow = true;     // reported by the caller: |w| must stay below the fp16 range
+        const double scale = 1.0;
         for (int r = 0; r < nt * 32; ++r) net.bias.push_back(r < cout ? (float)(b[r] * scale) : 0.0f);
         for (int g = 0; g < nt / tpc; ++g)
             for (const Seg &sg : segs)
@@ -236,12 +289,41 @@ static void add_template(Builder &B, const avc_ctx::Staged &t, bool colour, bool
 int pack_avatar(avc_ctx *ctx)
 {
     const bool has_clr = ctx->tmpl_st.W.size() == 12;
+    // working copies: weights beyond the fp16 range are brought inside before anything is packed (see rebalance())
+    avc_ctx::Staged tmpl = ctx->tmpl_st, warp_w = ctx->warp_st;
+    float sp_unscale = 1.0f;
+    if (ctx->tmpl_set) {
+        // shared.0 .. 5 (ReLU) -> shared.6 (linear) -> geo.0 (LeakyReLU) -> geo.1 (head); shared.6 -> clr.0 -> clr.1 (ReLU) -> clr.2 (head); shared.4 = [x | posenc]
+        std::vector<Node> g;
+        const int n = (int)tmpl.W.size();
+        for (int i = 0; i < n; ++i) {
+            const int co = (int)tmpl.b[i].size(), ci = (int)(tmpl.W[i].size() / tmpl.b[i].size());          // (Staged keeps no shapes: rows = biases)
+            g.push_back(Node{&tmpl.W[i], &tmpl.b[i], co, ci, i == 8 || i == 11, {}});
+        }
+        for (int i = 0; i < 6; ++i) g[i].out.push_back(Link{i + 1, 0});
+        g[6].out.push_back(Link{7, 0});
+        g[7].out.push_back(Link{8, 0});
+        if (has_clr) { g[6].out.push_back(Link{9, 0}); g[9].out.push_back(Link{10, 0}); g[10].out.push_back(Link{11, 0}); }
+        AVC_REQUIRE(rebalance(g), AVC_ERR_ARG, "cano_template: an output layer (geo_mlp / clr_mlp last fc) has weights beyond 3e4 in magnitude, also after the layers "
+                    "in front of it were rebalanced: not representable by the split-fp16 kernels");
+    }
+    if (ctx->warp_set) {
+        // conv1 .. conv7 + BatchNorm1d + Softplus: one scale for the seven (the accumulator becomes m log2(e) 2^s; the scaled kernels undo 2^s before the Softplus)
+        double m = 0;
+        for (int i = 0; i < 7; ++i) m = std::fmax(m, max_abs(warp_w.W[i]) * 1.4426950408889634074);
+        if (const int s = down_exponent(m)) {
+            for (int i = 0; i < 7; ++i) { scale_all(warp_w.W[i], s); scale_all(warp_w.b[i], s); }
+            sp_unscale = (float)std::ldexp(1.0, -s);
+        }
+    }
     auto build = [&](PackedNet &net, bool warp, bool colour, bool fold = false) -> int {
         Builder B(net);
-        if (warp) add_warp(B, ctx->warp_st, fold, ctx->warp_pe);
-        add_template(B, ctx->tmpl_st, colour, warp, ctx->tmpl_pe);
-        AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "weights exceed 3e4 in magnitude: not representable by the split-fp16 kernel");
+        if (warp) add_warp(B, warp_w, fold, ctx->warp_pe);
+        add_template(B, tmpl, colour, warp, ctx->tmpl_pe);
+        AVC_REQUIRE(!B.overflow, AVC_ERR_ARG, "weights exceed 3e4 in magnitude (warping_field.out_layer_coord_affine, or a warping-field layer beyond 2^40): not "
+                    "representable by the split-fp16 kernels");
         net.has_colour = colour;
+        net.sp_unscale = warp ? sp_unscale : 1.0f;
         return upload(net);
     };
     if (ctx->tmpl_set) {
@@ -270,6 +352,13 @@ int pack_recon(avc_ctx *ctx, const avc_dense fc[4])
                     "recon fc[%d]: expected (%d,%d), got (%d,%d)", i, cout[i], cin[i], fc[i].cout, fc[i].cin);
         int rc = effective(fc[i], nullptr, W[i], b[i]);
         if (rc) return rc;
+    }
+    {   // fc0 -> fc1 [x(512) | in33] -> fc2 [x(256) | in33] (LeakyReLU) -> fc3 (head): weight_norm gains beyond the fp16 range are rebalanced (see rebalance())
+        std::vector<Node> g;
+        for (int i = 0; i < 4; ++i) g.push_back(Node{&W[i], &b[i], cout[i], cin[i], i == 3, {}});
+        for (int i = 0; i < 3; ++i) g[i].out.push_back(Link{i + 1, 0});
+        AVC_REQUIRE(rebalance(g), AVC_ERR_ARG, "recon image_decoder: the output layer has weights beyond 3e4 in magnitude, also after the layers in front of it were "
+                    "rebalanced: not representable by the split-fp16 kernels");
     }
     // Consumption order of recon_kernel (fused_mlp.hip): fc0 is evaluated in two halves of 256
     // channels so that fc1 (545 = [x(512) | in(33)] inputs, mlp.py:61) can accumulate over each half

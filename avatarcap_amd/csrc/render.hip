@@ -180,7 +180,8 @@ int render_rays_cano(avc_ctx *ctx, const float *ray_o, const float *ray_d, const
         RayArgs ra{ray_o, ray_d, near, far, depth, t_vals, near_dist, far_dist, p0, np, S, pts, z};
         hipLaunchKernelGGL(ray_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ra);
         const int rc = ctx->check_range ? checked::launch_avatar(ctx, pts, nullptr, n, center, occ_sigmoid, occ, off, rgba, false, s)
-                                        : plain::launch_avatar(ctx, pts, nullptr, n, center, occ_sigmoid, occ, off, rgba, false, s);
+                       : needs_scaled_kernels(ctx) ? scaled::launch_avatar(ctx, pts, nullptr, n, center, occ_sigmoid, occ, off, rgba, false, s)
+                                                   : plain::launch_avatar(ctx, pts, nullptr, n, center, occ_sigmoid, occ, off, rgba, false, s);
         if (rc) return rc;
         if (int rk = near_flags(ctx, pts, n, smpl_v, n_smpl, (float)(0.08 * 0.08), d2, s)) return rk;
         CompArgs ca{p0, np, S, pts, z, off, rgba, d2, {bounds[0], bounds[1], bounds[2]}, {bounds[3], bounds[4], bounds[5]}, (float)(0.08 * 0.08),

@@ -100,7 +100,8 @@ def build_pipeline(res, valid, n_frames, device):
 
 
 def _cpu_info():
-    """(model name, physical cores, sockets, logical CPUs this process may use) of the host, from /proc/cpuinfo ('report core count, model name')."""
+    """(model name, physical cores, sockets, logical CPUs this process may use) of the host, from /proc/cpuinfo
+    ('report core count, model name')."""
     model, cores, socks = 'unknown', set(), set()
     try:
         phys = core = None
@@ -203,13 +204,18 @@ def cpu_baseline(pipe, sd, frame_in, frame_out, res, budget_s=12.0):
     t_np, _ = timed(lambda: orc.occupancy_query(pts_all[:m0].numpy(), tf.numpy(), ds.cano_smpl_center, sd, dt=np.float32))
     return {'value': 1.0 / frame_s, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
             'cpu_model': model, 'physical_cores': phys, 'sockets': socks, 'logical_cpus_available': avail,
-            'sample': f'stock PyTorch-CPU restatement (oracle/torch_cpu.py) on {threads} threads of {phys} physical cores ({model}): U-Net in full ({t_u:.2f} s); query '
-                      f'{n1} of {N} grid points = {n1 // 262144} chunks of 262,144 ({t_q:.1f} s, {per_pt*1e6:.2f} us/pt) scaled to {N}; C marching cubes on the full '
-                      f'{res}^3 volume ({st["mc"]:.2f} s, 1 thread); Sobel normals (torch conv3d) + fetch at the {V} vertices ({st["normals"]:.2f} s); torch-CPU KNN-4 '
+            'sample': f'stock PyTorch-CPU restatement (oracle/torch_cpu.py) on {threads} threads of {phys} physical cores ({model}): U-Net in full '
+                      f'({t_u:.2f} s); query '
+                      f'{n1} of {N} grid points = {n1 // 262144} chunks of 262,144 ({t_q:.1f} s, {per_pt*1e6:.2f} us/pt) scaled to {N}; C marching cubes on '
+                      f'the full '
+                      f'{res}^3 volume ({st["mc"]:.2f} s, 1 thread); Sobel normals (torch conv3d) + fetch at the {V} vertices ({st["normals"]:.2f} s); '
+                      f'torch-CPU KNN-4 '
                       f'LBS + skinning on a 65,536-vertex sample scaled to {V} ({st["lbs"]:.2f} s)',
             'seconds_per_frame': frame_s,
-            'seconds_per_frame_by_piece': {'unet7ds': t_u, 'query (scaled)': per_pt * N, 'marching cubes': st['mc'], 'normals': st['normals'], 'lbs + skinning (scaled)': st['lbs']},
-            'config0_64cube_full': {'workload': 'BASELINE configs[0]: 64^3 grid (262,144 points), one frame in full on the CPU: U-Net, query, marching cubes, normals, LBS',
+            'seconds_per_frame_by_piece': {'unet7ds': t_u, 'query (scaled)': per_pt * N, 'marching cubes': st['mc'], 'normals': st['normals'],
+                                           'lbs + skinning (scaled)': st['lbs']},
+            'config0_64cube_full': {'workload': 'BASELINE configs[0]: 64^3 grid (262,144 points), one frame in full on the CPU: U-Net, query, marching '
+                                                'cubes, normals, LBS',
                                     'repeats': len(runs), 'median_seconds_per_frame': med64, 'frames_per_s': 1.0 / med64, 'all_seconds': tot64,
                                     'median_run_by_piece': rmed, 'vertices': V64},
             'numpy_port_us_per_point': t_np / m0 * 1e6, 'torch_cpu_us_per_point': per_pt * 1e6}
@@ -255,8 +261,8 @@ def dry_run(args, world, rank):
         complaints = verify_gathered_meshes(got, {f: mesh(f) for f in shard_frames(n_frames, rank, world)})
     for c in complaints:
         print('# bench.py --dry-run: ' + c, file=sys.stderr, flush=True)
-    ok = not complaints and len(got) == n_frames and all(got[f]['v'].shape[0] == sizes[f] and float(got[f]['v'][0, 0]) == float(f) and int(got[f]['f'][0, 0]) == f
-                                                        for f in range(n_frames))
+    ok = not complaints and len(got) == n_frames and all(
+        got[f]['v'].shape[0] == sizes[f] and float(got[f]['v'][0, 0]) == float(f) and int(got[f]['f'][0, 0]) == f for f in range(n_frames))
     if world > 1:
         flag = torch.tensor([0 if ok else 1])
         with _stdout_to_stderr():
@@ -325,7 +331,8 @@ def main():
     if world > 1:
         pin_to_gpu_numa(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))       # each rank on the cores of its GPU's NUMA node
         from avatarcap_amd.parallel import leave_cus_for_the_exchange
-        query_wgs = leave_cus_for_the_exchange(device, 8 if args.spare_cus is None else args.spare_cus)   # RCCL's copy kernels need somewhere to run beside the query
+        # RCCL's copy kernels need somewhere to run beside the query
+        query_wgs = leave_cus_for_the_exchange(device, 8 if args.spare_cus is None else args.spare_cus)
     K, W, res = args.steps, args.warmup, args.res
     n_frames = world * (K + W)
     pipe, sd = build_pipeline(res, 'dense', n_frames, device)
@@ -345,7 +352,8 @@ def main():
     for s in range(W):
         out = pipe.avatar_frame(my[s], next_items=my[s + 1] if s + 1 < W else None)
     if world > 1 or force_dist:   # warm the exchange too (RCCL sets its point-to-point connections up on first use)
-        warm = ({'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']} if out is not None and out.get('live_v') is not None else       # --warmup 0: a token mesh
+        # (--warmup 0: a token mesh)
+        warm = ({'v': out['live_v'], 'vn': out['live_vn'], 'f': out['f']} if out is not None and out.get('live_v') is not None else
                 {'v': torch.zeros((3, 3), device=device), 'vn': torch.zeros((3, 3), device=device), 'f': torch.zeros((1, 3), dtype=torch.int32, device=device)})
         with _stdout_to_stderr():
             all_gather_meshes([warm], world, force=force_dist)
@@ -454,6 +462,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         import pmc_traffic
         traffic_bytes, traffic_ref = pmc_traffic.load(ROOT)
+        n_cus = torch.cuda.get_device_properties(device).multi_processor_count
         line = {
             'metric': 'reconstructed-mesh frames/sec at 256^3 grid (avatar occupancy-only, dense query + marching cubes + LBS)',
             'value': world * K / dt, 'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': K, 'warmup': W,
@@ -470,10 +479,13 @@ def main():
                        'frames_in_batch': world * K, 'meshes_all_gathered': bool(world > 1 or force_dist),
                        'query_workgroups': query_wgs or 'one per CU', 'exchange_transport': exchange_mode if (world > 1 or force_dist) else None,
                        'exchange_autotune': autotune,
-                       'mesh_exchange': 'exact-size point-to-point sends per step (every pair of GPUs over its own xGMI link), issued from a side stream behind the NEXT frame\'s query launch (parallel.MeshExchange.pump): '
-                                        'K - 1 of a rank\'s K steps travel beside compute, the last one is `exchange_tail_ms`; `meshes_verified`: per-frame integer checksums '
+                       'mesh_exchange': 'exact-size point-to-point sends per step (every pair of GPUs over its own xGMI link), issued from a side stream '
+                                        'behind the NEXT frame\'s query launch (parallel.MeshExchange.pump): '
+                                        'K - 1 of a rank\'s K steps travel beside compute, the last one is `exchange_tail_ms`; `meshes_verified`: per-frame '
+                                        'integer checksums '
                                         'of every received mesh against its owner\'s, checked on every rank outside the timed region',
-                       'semantics': '`value` is the DENSE stress variant BASELINE configs[1] names (every one of the 256^3 grid points evaluated); the reference itself '
+                       'semantics': '`value` is the DENSE stress variant BASELINE configs[1] names (every one of the 256^3 grid points evaluated); the '
+                                    'reference itself '
                                     'evaluates only the valid band around the canonical SMPL and fills the rest (main.py:362-363): that is `masked` and the '
                                     '`configs` legs below',
                        'dense_points': 'generated from the grid index (avc_avatar_query_grid), offsets not written',
@@ -482,22 +494,27 @@ def main():
                                     'trimesh 3.9.15 contains', 'opencv resize / Rodrigues']},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F16_TFLOPS,
-                         # HBM-side bytes per launch of the dense 256^3 query + its column pass: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of separate rocprofv3 --pmc
-                         # passes over this very launch (the guide's gfx950 correction).  Counters cannot be read from inside this process: the figure is that
+                         # HBM-side bytes per launch of the dense 256^3 query + its column pass: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of separate
+                         # rocprofv3 --pmc passes over this very launch (the guide's gfx950 correction).  Counters cannot be read from inside this
+                         # process: the figure is that
                          # pass's -- null for any other grid, and null once the kernel's sources differ from the ones it was measured on (`traffic_ref.state`)
                          'traffic': traffic_bytes if res == 256 else None, 'traffic_unit': 'bytes per launch', 'traffic_ref': traffic_ref,
-                         'traffic_note': 'separate rocprofv3 --pmc passes of the same launch (tools/pmc_traffic.py -> profiles/pmc_traffic.json, carried only while the kernel '
-                                         'sources hash to what they were when the counters were read): ~0.52 GB against 0.087 GB algorithmic -- the 131 MB column table written '
+                         'traffic_note': 'separate rocprofv3 --pmc passes of the same launch (tools/pmc_traffic.py -> profiles/pmc_traffic.json, carried '
+                                         'only while the kernel '
+                                         'sources hash to what they were when the counters were read): ~0.52 GB against 0.087 GB algorithmic -- the 131 MB '
+                                         'column table written '
                                          'and read back, the feature map once per XCD; 0.1 % of the HBM bandwidth (the kernel is MFMA / power bound)',
-                         'kernel': 'avc::avatar_kernel<true,false,1> (+ its column_terms_kernel pass, timed together)', 'avg_launch_ms': avg_ms.value, 'launches': launches.value,
+                         'kernel': 'avc::avatar_kernel<true,false,1> (+ its column_terms_kernel pass, timed together)',
+                         'avg_launch_ms': avg_ms.value, 'launches': launches.value,
                          'shader_cycles_per_launch': avg_cyc.value, 'clock_mhz': (avg_cyc.value / (avg_ms.value * 1e3)) if avg_ms.value > 0 else 0.0,
-                         'cycles_per_mfma': avg_cyc.value / (4728 * -(-(N // 128) // min(N // 128, query_wgs or torch.cuda.get_device_properties(device).multi_processor_count))) if avg_cyc.value > 0 else 0.0,
+                         'cycles_per_mfma': avg_cyc.value / (4728 * -(-(N // 128) // min(N // 128, query_wgs or n_cus))) if avg_cyc.value > 0 else 0.0,
                          'algorithmic_flop_per_launch': N * FLOP_PER_POINT,
                          'mfma_issued_tflops': N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0,
                          'mfma_util': (N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 / PEAK_F16_TFLOPS) if avg_ms.value > 0 else 0.0,
                          'fp32_mfma_peak_equiv': achieved / 157.3,
                          'sustained_mfma_tflops_measured': SUSTAINED_F16_TFLOPS,
-                         'mfma_issued_vs_sustained': (N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 / SUSTAINED_F16_TFLOPS) if avg_ms.value > 0 else 0.0},
+                         'mfma_issued_vs_sustained': (N * MFMA_ISSUED_PER_POINT / (avg_ms.value * 1e-3) / 1e12 / SUSTAINED_F16_TFLOPS)
+                                                     if avg_ms.value > 0 else 0.0},
         }
         if world == 1:
             # the HBM-bound kernels of the same frame, timed on its own volume and mesh (algorithmic bytes of SURVEY.md 8(d) / time / 8 TB/s)
@@ -524,12 +541,13 @@ def main():
                     smpl_util.skinning_normal(n1, w, jm)
                 t_lbs = timed(lbs_all)
                 mc_bytes, lbs_bytes = 4 * N + 24 * V + 12 * Fc, V * (12 + 96 + 24 + 12 + 12 + 64) + 83_000
+                def hbm(t, nbytes, **more):
+                    return {'bound': 'hbm', 'ms': t * 1e3, 'algorithmic_bytes': nbytes, 'achieved': nbytes / t / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                            'frac': nbytes / t / 8e12, **more}
                 line['roofline_secondary'] = {
-                    'marching cubes + normals (mesh.hip, 6 launches, one host wait at the end)': {'bound': 'hbm', 'ms': t_mc * 1e3, 'algorithmic_bytes': mc_bytes,
-                                                                                       'achieved': mc_bytes / t_mc / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': mc_bytes / t_mc / 8e12},
-                    'KNN-4 LBS + skinning of points and normals (knn_lbs.hip)': {'bound': 'hbm', 'ms': t_lbs * 1e3, 'algorithmic_bytes': lbs_bytes,
-                                                                                'achieved': lbs_bytes / t_lbs / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': lbs_bytes / t_lbs / 8e12,
-                                                                                'note': 'the search is VALU-bound (DESIGN.md section 3): the HBM fraction is reported for completeness'}}
+                    'marching cubes + normals (mesh.hip, 6 launches, one host wait at the end)': hbm(t_mc, mc_bytes),
+                    'KNN-4 LBS + skinning of points and normals (knn_lbs.hip)': hbm(
+                        t_lbs, lbs_bytes, note='the search is VALU-bound (DESIGN.md section 3): the HBM fraction is reported for completeness')}
             except Exception as e:       # informational only
                 line['roofline_secondary'] = {'error': repr(e)}
         if world == 1 and not args.no_masked:
@@ -623,17 +641,21 @@ def other_configs(device, frames=3):
     # secondary roofline fractions of the other kernels of the path, from the legs' own timings (algorithmic work of SURVEY.md 8(d) / time / peak)
     c2 = out['configs[2]']
     nb = c2['valid_points']
+    def mfma(flop, ms):
+        return {'bound': 'mfma', 'achieved_tflops': flop / (ms * 1e-3) / 1e12}
+    km, sm = c2['kernel_ms'], c2['stage_ms']
     out['secondary_rooflines'] = {
-        'avatar band query (avatar_kernel, column-folded band)': {'bound': 'mfma', 'achieved_tflops': nb * FLOP_PER_POINT / (c2['kernel_ms']['avatar query (band, column-folded)'] * 1e-3) / 1e12},
-        'recon band query (recon_fold_kernel<2>, column-folded band)': {'bound': 'mfma', 'achieved_tflops': nb * 387072 / (c2['kernel_ms']['recon query (band, column-folded)'] * 1e-3) / 1e12},
-        'HGFilter encoder (conv_enc.hip, ~70 launches incl. their gaps)': {'bound': 'mfma', 'achieved_tflops': 232.3e9 / (c2['stage_ms']['of which hgfilter'] * 1e-3) / 1e12},
-        'UNet7DS (conv_enc.hip, 18 launches; weight-stream bound at its deep levels)': {'bound': 'mfma', 'achieved_tflops': 10.35e9 / (c2['stage_ms']['of which unet7ds (in avatar_frame)'] * 1e-3) / 1e12},
+        'avatar band query (avatar_kernel, column-folded band)': mfma(nb * FLOP_PER_POINT, km['avatar query (band, column-folded)']),
+        'recon band query (recon_fold_kernel<2>, column-folded band)': mfma(nb * 387072, km['recon query (band, column-folded)']),
+        'HGFilter encoder (conv_enc.hip, ~70 launches incl. their gaps)': mfma(232.3e9, sm['of which hgfilter']),
+        'UNet7DS (conv_enc.hip, 18 launches; weight-stream bound at its deep levels)': mfma(10.35e9, sm['of which unet7ds (in avatar_frame)']),
     }
     for v in out['secondary_rooflines'].values():
         v['peak_tflops'] = PEAK_F16_TFLOPS
         v['frac'] = v['achieved_tflops'] / PEAK_F16_TFLOPS
     out['example.yaml'] = full_leg([384, 384, 128], "the reference's own configuration: vol_res 384 x 384 x 128 (configs/example.yaml:14-17), valid band "
-                                                    "(dataset/avatarcap_dataset.py:111-125) -- what `main.py -c configs/example.yaml -m test` computes per frame")
+                                                    "(dataset/avatarcap_dataset.py:111-125) -- what `main.py -c configs/example.yaml -m test` computes per "
+                                                    "frame")
     # ---- configs[3]: 512^3 dense + marching cubes + colour head on the vertices (HBM-bound stress)
     config.cfg['testing']['vol_res'] = [512] * 3
     ds = SyntheticTestDataset([512] * 3, valid='dense', n_frames=2, device=device)
@@ -647,7 +669,8 @@ def other_configs(device, frames=3):
     nv = min(200_000, int(a5['cano_v'].shape[0]))
     v, n = a5['cano_v'][:nv].contiguous(), a5['cano_vn'][:nv].contiguous()
     tc, rgb = stage_ms(lambda: pipe.colour_vertices(items[1], v, n), 2)
-    out['configs[3]'] = {'workload': '512^3 dense grid (134,217,728 points) + marching cubes + normals + LBS, colour head on 200 k vertices (64 samples per ray)',
+    out['configs[3]'] = {'workload': '512^3 dense grid (134,217,728 points) + marching cubes + normals + LBS, colour head on 200 k vertices (64 samples per '
+                                     'ray)',
                          'avatar_frame_ms': t5, 'frames_per_s': 1e3 / t5, 'query_kernel_ms': qa.value, 'vertices': int(a5['cano_v'].shape[0]),
                          'faces': int(a5['f'].shape[0]), 'colour_vertices': nv, 'colour_ms': tc, 'rgb_finite': bool(torch.isfinite(rgb).all())}
     del ds, pipe, items, a5, v, n, rgb
@@ -657,8 +680,9 @@ def other_configs(device, frames=3):
 
 
 def main_py_e2e(device_ms, frames=32):
-    """The entry point itself, end to end: `python main.py -c configs/example.yaml -m test --synthetic --frames 32` as a process of its
-    own, files written to a scratch directory, timed by the loop itself (--timing-json: steady frames from the third on, until the last file is closed).
+    """The entry point itself, end to end: `python main.py -c configs/example.yaml -m test --synthetic --frames 32` as a
+    process of its own, files written to a scratch directory, timed by the loop itself (--timing-json: steady frames from the third on, until the
+    last file is closed).
     Three output shapes: none; the reference's mesh output (live avatar + live reconstruction as PLY, main.py:491-498); PLY + every mesh tensor as .npz."""
     import shutil
     import subprocess
@@ -675,7 +699,8 @@ def main_py_e2e(device_ms, frames=32):
                 legs[tag] = {'error': (r.stderr or r.stdout)[-400:]}
                 continue
             t = json.load(open(tj))
-            legs[tag] = {'ms_per_frame': t['e2e_ms_per_frame'], 'frames_per_s': 1e3 / t['e2e_ms_per_frame'], 'vs_device_figure': t['e2e_ms_per_frame'] / device_ms,
+            legs[tag] = {'ms_per_frame': t['e2e_ms_per_frame'], 'frames_per_s': 1e3 / t['e2e_ms_per_frame'],
+                         'vs_device_figure': t['e2e_ms_per_frame'] / device_ms,
                          'device_done_ms_per_frame': t['device_ms_per_frame'], 'mb_written_per_frame': t['bytes_written'] / 1e6 / t['frames'],
                          'writer_tail_ms': t['writer_tail_ms'], 'waited_for_writer_slot_ms': t['waited_for_writer_slot_ms'],
                          'h2d_copies_per_frame': t['h2d_copies'] / t['frames'], 'first_frame_ms': t['first_frame_ms']}

@@ -124,7 +124,7 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
             """Everything of frame i that is read or made on the host (main.py:349-351 and the image-observed normal map of :406-411): runs on the
             prefetch thread, two frames ahead of the device."""
             item = dict(ds[i * img_num_per_pose + view_idx])
-            if w_recon and synthetic:       # the stand-in of the captured normal map bends the posed normals by a seeded field (dataset.synthetic_observed_normals)
+            if w_recon and synthetic:       # the stand-in of the captured normal map: a seeded field bends the posed normals (dataset.py)
                 item['observed_bend_axes'] = torch.randn(3, 3, generator=torch.Generator().manual_seed(i)).numpy()
             elif w_recon:
                 item['observed_normal'] = _observed_normals_host(ds, int(item['data_idx']), view_idx)
@@ -166,7 +166,7 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
             items = prefetch.get(i)
             if sync_io and dev is not None:
                 torch.cuda.synchronize(dev)                   # the reference's blocking to_cuda
-            nxt = prefetch.peek(nxt_i)      # its U-Net is queued behind this frame's query (FramePipeline.avatar_frame); None: its own turn reports what is wrong
+            nxt = prefetch.peek(nxt_i)      # its U-Net is queued behind this frame's query (FramePipeline.avatar_frame); None: its own turn reports it
             return frame(k, i, items, nxt, checking)
         finally:
             prefetch.drop(i)
@@ -343,7 +343,8 @@ def main(argv=None):
     arg_parser.add_argument('--valid', type=str, default='band', choices=['band', 'dense'])
     arg_parser.add_argument('--save-ply', action='store_true', help='write the live avatar / recon meshes as PLY (obj_io layout)')
     arg_parser.add_argument('--no-npz', action='store_true', help='do not write <idx>_mesh.npz (every mesh tensor of the frame)')
-    arg_parser.add_argument('--sync-io', action='store_true', help="the reference's loop shape: blocking upload, .cpu(), files written inside the frame (for comparison)")
+    arg_parser.add_argument('--sync-io', action='store_true',
+                            help="the reference's loop shape: blocking upload, .cpu(), files written inside the frame (for comparison)")
     arg_parser.add_argument('--io-threads', type=int, default=3, help='writer threads behind the loop')
     arg_parser.add_argument('--io-slots', type=int, default=4, help='finished frames that may wait for the disk (pinned slots) before the loop does')
     arg_parser.add_argument('--timing-json', type=str, default=None, help='write what the frame loop measured about itself (rank 0) to this file')
@@ -354,7 +355,8 @@ def main(argv=None):
     arg_parser.add_argument('--gather-batch', type=int, default=8, help='--gather-meshes: steps (frames per rank) exchanged and moved to the host at a time')
     arg_parser.add_argument('--max-failure-streak', type=int, default=3,
                             help='give up on a rank\'s remaining frames after this many consecutive failures OF THE SAME KIND (0: never)')
-    arg_parser.add_argument('--check-range', action='store_true', help='run EVERY frame with the fp16 range check of the fused kernels (default: until one frame has passed it)')
+    arg_parser.add_argument('--check-range', action='store_true',
+                            help='run EVERY frame with the fp16 range check of the fused kernels (default: until one frame has passed it)')
     arg_parser.add_argument('--dist-timeout', type=float, default=180.0, help='seconds a rank may take to show up at the rendezvous')
     arg_parser.add_argument('--collective-timeout', type=float, default=None,
                             help='seconds a collective may wait for the slowest rank AFTER the rendezvous (default: 10 x --dist-timeout, at least 1800)')
