@@ -187,7 +187,12 @@ int avc_avatar_query_grid_subset(avc_ctx *ctx, const float *axis_x_dev, const fl
                                  int occupancy_sigmoid, float *occ_out_dev, float *offset_out_dev, avc_stream stream);
 
 /* Numeric range.  The fused queries evaluate every float32 product as three fp16 x fp16 products with float32 accumulation
- * (DESIGN.md section 2): weights are split on the host -- a packed weight above 3e4 in magnitude is refused with AVC_ERR_ARG --
+ * (DESIGN.md section 2): weights are split on the host -- a weight above 3e4 in magnitude does not fit the split; the packers bring
+ * such layers inside the range exactly (powers of two): an out-of-range output row of a ReLU / LeakyReLU / linear layer (cano_template, the recon decoder:
+ * a weight_norm gain) is scaled down to the layer's ordinary magnitude and its consumers' matching input column up, which no kernel notices; the
+ * warping field's seven Conv1d + BatchNorm1d + Softplus layers (a BatchNorm fold with a small running variance) take ONE common scale that a separate
+ * build of the query kernels undoes in front of the Softplus (chosen automatically; a checkpoint inside the range runs the default kernels unchanged);
+ * an output layer (geo_mlp / clr_mlp / out_layer_coord_affine / the decoder's last fc) that is still out of range is refused with AVC_ERR_ARG --
  * and every sampled feature, positional-encoding value and post-activation value is split on the fly, which requires
  * |value| <= 65504 (Softplus layers carry y / ln 2).  The reference's float32 path has no such bound (network/mlp.py:90-110).
  * avc_set_range_check(ctx, 1) switches the queries of this context to a build of the kernels that tracks the largest
