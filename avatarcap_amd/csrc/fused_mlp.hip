@@ -37,26 +37,9 @@
 #include "avcap_internal.h"
 #include "mlp_layout.h"
 
-// Compile-time ablation knobs for kernel A/B timing (tools/ablate_build.sh, tools/ablate_run.sh).  All default to 0; any other
-// setting produces WRONG results and exists only to attribute time.
-#ifndef AVC_DBG_NO_PREFETCH
-#define AVC_DBG_NO_PREFETCH 0
-#endif
-#ifndef AVC_DBG_NO_BARRIER
-#define AVC_DBG_NO_BARRIER 0
-#endif
-#ifndef AVC_DBG_OCML_SINCOS
-#define AVC_DBG_OCML_SINCOS 0
-#endif
-#ifndef AVC_DBG_TIMING
-#define AVC_DBG_TIMING 0
-#endif
-#ifndef AVC_DBG_PF_SAME
-#define AVC_DBG_PF_SAME 0
-#endif
-#ifndef AVC_DBG_NO_LDSREAD
-#define AVC_DBG_NO_LDSREAD 0      // A fragments read once per chunk instead of once per k-step
-#endif
+// (Rounds 2 - 5 carried compile-time ablation knobs here and at ~35 sites of the kernel bodies -- no prefetch, no barrier, per-chunk s_memtime stamps, ... -- that
+// attributed time and produced wrong results; what they measured is in profiles/r02_* / r03_avatar_time_split.md / r03_recon_time_split.md.  Removed in round 6:
+// the product kernels contain no debugging code path; the device code of the default build is unchanged by the removal, checked instruction for instruction.)
 
 // Opt-in range check (a second build of this file with -DAVC_CHECK_RANGE=1, selected at run time by avc_set_range_check): every value
 // that is about to be split into fp16 halves -- sampled features, positional encodings, every post-activation value of every layer -- feeds
@@ -289,34 +272,15 @@ struct Stream {
     unsigned parity;         // ring slot of the chunk about to be consumed
     unsigned wave;           // wave index in the workgroup
     unsigned lane_off;       // lane * 16
-#if AVC_DBG_TIMING
-    long long t_bar = 0;     // cycles spent waiting at chunk barriers
-    long long t_drain = 0;   // ... of which waiting for this wave's own LDS-DMA pieces (s_waitcnt vmcnt(0))
-    long long t_pro = 0;     // cycles of the per-tile prologues (point load, gathers, positional encoding) and output stores
-    long long *stamp = nullptr;   // AVC_DBG_TIMING == 2, last tile of the workgroup only: (entry, drained, released) s_memtime of every chunk / head
-    unsigned nstamp = 0;
-#endif
 };
 
-#if AVC_DBG_TIMING
-// three timestamps per chunk step of the workgroup's LAST tile, lane 0 of every wave (tools/timing_probe.py turns them into profiles/r03_avatar_time_split.md)
-__device__ __forceinline__ void stamp3(Stream &s, long long t0, long long t1, long long t2)
-{
-#if AVC_DBG_TIMING >= 2
-    if (s.stamp) {
-        if (s.lane_off == 0) { s.stamp[3 * s.nstamp] = t0; s.stamp[3 * s.nstamp + 1] = t1; s.stamp[3 * s.nstamp + 2] = t2; }
-        ++s.nstamp;
-    }
-#endif
-}
-#endif
 
 // The next chunk travels L2 -> LDS by LDS-DMA in its BUFFER form, `buffer_load_dwordx4 v_off32, s[rsrc], s_off offen lds`: the data never
 // touches a VGPR, there is no ds_write, and the only per-lane operand is one 32-bit offset register (lane * 16) that never changes.
 // Measured beside the MFMA stream of this kernel's chunk step (tools/ubench/copy_cost.hip, profiles/r02_ubench_copy_cost.md): 35.9 cycles
 // per MFMA against 34.6 with no copy at all -- while `global_load_lds_dwordx4` (64-bit address VGPR pair) costs 41.3, the saddr-form
 // global_load + ds_write_b128 40.9, and what round 1 shipped (global_load with a 64-bit vaddr + ds_write_b128) cost the kernel 28 % of its
-// time (tools/ablate_run.sh).  A chunk is covered in GROUPS of 16 KiB (a shorter last group for sizes that are not a multiple of 16 KiB);
+// time (round 2's ablation builds).  A chunk is covered in GROUPS of 16 KiB (a shorter last group for sizes that are not a multiple of 16 KiB);
 // inside a group wave w owns a contiguous quarter, one 1 KiB piece per instruction: M0 = LDS destination, soffset = stream offset.
 // Completion: every wave drains its own pieces (`s_waitcnt vmcnt(0)`) right before the chunk barrier that publishes them.
 constexpr int GROUP = 16384;
@@ -359,13 +323,11 @@ __device__ __forceinline__ void pf_dma(__amdgpu_buffer_rsrc_t rs, unsigned so, u
 template <int KS, int NEXT_BYTES, int SLOT>
 __device__ __forceinline__ void pf_step(__amdgpu_buffer_rsrc_t rs, unsigned so, unsigned dst, unsigned lane16, unsigned wave)
 {
-#if !AVC_DBG_NO_PREFETCH
     constexpr PfPlan P = pf_plan(KS, NEXT_BYTES);
     static_for<P.npw>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
         if constexpr (pf_load_slot(P, n) == SLOT) pf_dma<NEXT_BYTES, pf_nth(NEXT_BYTES, n)>(rs, so, dst, lane16, wave);
     });
-#endif
 }
 
 // every piece this wave has issued is in LDS (LDS-DMA completes in vmcnt order); the barrier that follows publishes them
@@ -388,22 +350,8 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // acquire: every wave has stored its share of this chunk (ds_write) and finished reading the other slot
-#if AVC_DBG_TIMING
-    const long long tb0 = clock64();
-#endif
     pf_drain();
-#if AVC_DBG_TIMING
-    const long long tb1 = clock64();
-    s.t_drain += tb1 - tb0;
-#endif
-#if !AVC_DBG_NO_BARRIER
     __syncthreads();
-#endif
-#if AVC_DBG_TIMING
-    const long long tb2 = clock64();
-    s.t_bar += tb2 - tb0;
-    stamp3(s, tb0, tb1, tb2);
-#endif
     // Values every address of this chunk derives from are made opaque HERE, after the barrier: with
     // everything unrolled and compile-time, the compiler otherwise hoists the address arithmetic of all
     // ~60 chunks of a tile (hundreds of values) to the top of the tile loop and spills them.
@@ -411,9 +359,6 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
     unsigned so = s.pf_off;
     unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES;
     asm volatile("" : "+v"(base), "+s"(so), "+s"(dst));
-#if AVC_DBG_PF_SAME
-    so &= 0u;
-#endif
 
     // The chunk is walked as Q steps of T2 (two, or one for the single-tile heads) output tiles: step q = k-step q / G, tile group q % G.  Units are
     // k-major in LDS, so step q's A fragments are units q * T2 .. q * T2 + T2 - 1 whatever TPC is -- an 8-tile chunk (recon fc1) is the same loop as
@@ -442,12 +387,8 @@ __device__ __forceinline__ void chunk(Stream &s, const In &in, f32x16 *__restric
             b[nxt] = in.template get<(q + 1) / G>();
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
-#if AVC_DBG_NO_LDSREAD
-                ah[nxt][t] = ah[cur][t]; al[nxt][t] = al[cur][t];
-#else
                 ah[nxt][t] = *reinterpret_cast<const half8 *>(smem + base + ((q + 1) * T2 + t) * layout::UNIT_BYTES);
                 al[nxt][t] = *reinterpret_cast<const half8 *>(smem + base + ((q + 1) * T2 + t) * layout::UNIT_BYTES + 1024);
-#endif
             }
         }
         pf_step<Q, NEXT_BYTES, 3 * q + 0>(s.rs, so, dst, s.lane_off, s.wave);
@@ -789,22 +730,8 @@ __device__ __forceinline__ f32x16 head(Stream &s, const Frag *__restrict__ in, B
     if constexpr (LAST) bias.rewind(bias_head);      // the next block is the first one of the next point tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a1[r] = 0.f; a2[r] = 0.f; }
-#if AVC_DBG_TIMING
-    const long long tb0 = clock64();
-#endif
     pf_drain();
-#if AVC_DBG_TIMING
-    const long long tb1 = clock64();
-    s.t_drain += tb1 - tb0;
-#endif
-#if !AVC_DBG_NO_BARRIER
     __syncthreads();
-#endif
-#if AVC_DBG_TIMING
-    const long long tb2 = clock64();
-    s.t_bar += tb2 - tb0;
-    stamp3(s, tb0, tb1, tb2);
-#endif
     unsigned base = s.parity * layout::SLOT_BYTES + s.lane_off;
     unsigned so = s.pf_off;
     unsigned dst = (s.parity ^ 1u) * layout::SLOT_BYTES;
@@ -914,11 +841,7 @@ __device__ __forceinline__ void posenc_values(const float q[3], int h, float v[3
 #pragma unroll
     for (int i = 0; i < 15; ++i) {
         float sn, cs;
-#if AVC_DBG_OCML_SINCOS
-        sincosf(q[i % 3] * (float)(1 << (i / 3)) * hs, &sn, &cs);
-#else
         sincos_pow2(q[i % 3], (float)(1 << (i / 3)) * hs, sn, cs);
-#endif
         v[2 * i] = sn;
         v[2 * i + 1] = cs;
     }
@@ -1173,16 +1096,6 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int64_t pidx_raw = tile * TILE_PTS + wave * 32 + j;
         const int64_t pidx = pidx_raw < p.n ? pidx_raw : p.n - 1;
-#if AVC_DBG_TIMING
-        const long long tp0 = clock64();
-#if AVC_DBG_TIMING >= 2
-        if (p.out1 && tile + gridDim.x >= p.ntiles) {      // the workgroup's last tile: stamp every chunk step (rows of 256 x int64 behind the 64 KiB summary area)
-            s.stamp = reinterpret_cast<long long *>(p.out1) + 8192 + (size_t)(blockIdx.x * 4 + wave) * 256;
-            s.nstamp = 0;
-            stamp3(s, tp0, tp0, tp0);                       // opening stamp: the tile's prologue lies between this one and the first chunk's entry
-        }
-#endif
-#endif
         float pt[3];
         unsigned col = 0;
         if constexpr (FOLD == 2) {
@@ -1232,9 +1145,6 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
             if constexpr (WPE) posenc_frags(pt, h, WP, s.range);                                                        // arch_avatar.py:122
             const ParkPeIn SW{park, WP};
             const RegIn RX{X}, RY{Y}, R4{&S4};
-#if AVC_DBG_TIMING
-            s.t_pro += clock64() - tp0;
-#endif
             using SP = Pending<ACT_SOFTPLUS, 8>;
             // column-folded launch: conv1's and conv5's blocks come from the column table, everything else from the layer table
             const float *after1 = nullptr, *col5 = nullptr, *after5 = nullptr;
@@ -1291,17 +1201,11 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
         }
 
         // ---- DoubleTNet.forward (arch_avatar.py:65-83) ----
-#if AVC_DBG_TIMING
-        const long long tp1 = clock64();
-#endif
         constexpr bool WIDE0 = !(WARP && COLOUR);      // (the warped colour kernel sits at the register limit: it keeps shared.0 as four chunks of a tile pair)
         if constexpr (WIDE0) wide_bias_early(bias, w8);                                                                         // shared.0's blocks, tiles 2 .. 7
         posenc(q, h, park, s.range);                                                                                            // :70 (parked in LDS)
         const ParkIn P{park, nullptr};
         const RegIn TX{X}, TY{Y};
-#if AVC_DBG_TIMING
-        s.t_pro += clock64() - tp1;
-#endif
         using RP = Pending<ACT_RELU, 8>;
         if constexpr (WIDE0) {
             wide8<layout::PE_KS, B_MAIN>(s, P, w8, bias, h);                                                             // shared 0
@@ -1344,16 +1248,6 @@ __global__ __launch_bounds__(256, 1) void avatar_kernel(const QueryParams p)
     }
     s.range.report(p);
     if (p.clk && blockIdx.x == 0 && threadIdx.x == 0) { p.clk[0] = tk0; p.clk[1] = clock64(); }     // workgroup 0 is there from the first tile to the last
-#if AVC_DBG_TIMING
-    if (p.out1) {                  // debug: overwrite the head of the offsets buffer with (total, barrier, drain, prologue) cycles per wave
-        const long long tend = clock64();
-        stamp3(s, tend, tend, (long long)s.nstamp);     // closing stamp of the last tile + the number of chunk steps stamped
-        if (lane == 0) {
-            long long *dbg = reinterpret_cast<long long *>(p.out1) + 4 * (blockIdx.x * 4 + wave);
-            dbg[0] = tend - tk0; dbg[1] = s.t_bar; dbg[2] = s.t_drain; dbg[3] = s.t_pro;
-        }
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1601,14 +1495,6 @@ __global__ __launch_bounds__(256, 1) void recon_fold_kernel(const QueryParams p)
 
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int64_t pidx_raw = tile * TILE_PTS + wave * 32 + j;
-#if AVC_DBG_TIMING >= 2
-        const long long tp0 = clock64();
-        if (tile + gridDim.x >= p.ntiles) {                 // as in avatar_kernel: stamps of the workgroup's last tile, behind the head of the OUTPUT buffer
-            s.stamp = reinterpret_cast<long long *>(p.out0) + 8192 + (size_t)(blockIdx.x * 4 + wave) * 256;
-            s.nstamp = 0;
-            stamp3(s, tp0, tp0, tp0);
-        }
-#endif
         float pt[3] = {pt_next[0], pt_next[1], pt_next[2]};
         const unsigned col = col_next;
         const int64_t tile_n = tile + gridDim.x < p.ntiles ? tile + gridDim.x : tile;           // the tile this workgroup runs next (itself: the last one)
@@ -1694,16 +1580,6 @@ __global__ __launch_bounds__(256, 1) void recon_fold_kernel(const QueryParams p)
     }
     s.range.report(p);
     if (p.clk && blockIdx.x == 0 && threadIdx.x == 0) { p.clk[0] = tk0; p.clk[1] = clock64(); }
-#if AVC_DBG_TIMING >= 2
-    {
-        const long long tend = clock64();
-        stamp3(s, tend, tend, (long long)s.nstamp);
-        if (lane == 0) {
-            long long *dbg = reinterpret_cast<long long *>(p.out0) + 4 * (blockIdx.x * 4 + wave);
-            dbg[0] = tend - tk0; dbg[1] = s.t_bar; dbg[2] = s.t_drain; dbg[3] = s.t_pro;
-        }
-    }
-#endif
 }
 #endif
 

@@ -71,6 +71,7 @@ class FramePipeline:
         self.ds = dataset
         self.vol_res = list(dataset.vol_res)
         self.exchange = None          # a parallel.MeshExchange while a sharded batch is running: avatar_frame pumps it behind its query launch
+        self.after_query = []         # one-shot host work to run right behind the NEXT query launch (main.py: the previous frame's output section)
         self.lookahead_on_side_stream = os.environ.get('AVC_LOOKAHEAD_SIDE', '1') == '1'     # the next frame's U-Net beside this frame's tail (avatar_frame)
         self._side = None
         smpl_util.set_smpl_skinning_weights(dataset.body['skin_weights'])
@@ -131,6 +132,7 @@ class FramePipeline:
             # kernels (parallel.MeshExchange.pump -- waits for the peers' counts of that step, never for this stream)
             with _stage('avc/mesh_exchange pump'):
                 self.exchange.pump()
+        self.run_after_query()
         try:
             with _stage('avc/marching_cubes'):
                 vol = fill_volume(out['cano_pts_ov'][0, :, 0], self.ds.valid_u8, self.ds.invalid_pts_ov)   # :362-364
@@ -150,6 +152,14 @@ class FramePipeline:
                 cur.wait_event(side_done)
                 self._next_map[1].record_stream(cur)
         return res
+
+    def run_after_query(self):
+        """Host work parked for the shadow of a query launch (`after_query`): the one place of the frame where the device has ~10 ms of work queued and the host
+        nothing to do.  main.py assembles and hands over the PREVIOUS frame's outputs here: between two frames the device's queue is empty (marching cubes has
+        just read its counts), and every host microsecond there is a device microsecond lost (1.3 - 2.4 ms per frame with PLY outputs, profiles/r06_main_e2e.md)."""
+        hooks, self.after_query = self.after_query, []
+        for fn in hooks:
+            fn()
 
     def _avatar_query(self, items: dict):
         if self._grid_items(items) == 'dense':

@@ -18,25 +18,33 @@ def ply_header(n_vertices, n_faces, normals=True, colors=False) -> bytes:
 
 
 def ply_records_device(vertices, faces=None, normals=None, colors=None):
-    """The byte payload of `save_mesh_as_ply` assembled ON THE DEVICE: -> (header bytes, {'vrec': (V, 12|24|15|27) uint8, 'frec': (F, 4) int32}).
+    """The byte payload of `save_mesh_as_ply` assembled ON THE DEVICE: -> (header bytes, {'vrec': (V, 3|6) float32 or, with colours, (V, 15|27) uint8; 'frec': (F, 4) int32}).
     The per-vertex records `3f [3f] [3B]` and the per-face records `int 3 + 3 int` (obj_io.py:249-268) are two concatenations there; what crosses to
     the host is the file's own bytes, and the writer thread does nothing but `write` (avatarcap_amd.frame_io.MeshWriter).  The colour rule of :246-248
     (floats below 1 are scaled by 255, then truncated to bytes) is evaluated without reading the maximum back."""
     import torch
     V = int(vertices.shape[0])
-    cols = [vertices.to(torch.float32).contiguous().reshape(-1).view(torch.uint8).view(V, 12)]
-    if normals is not None:
-        cols.append(normals.to(torch.float32).contiguous().reshape(-1).view(torch.uint8).view(V, 12))
-    if colors is not None:
+    v = vertices.to(torch.float32)
+    if colors is None:
+        # records of whole floats: one float32 concatenation, handed over as it is (the writer takes the bytes of whatever array it gets)
+        out = {'vrec': (torch.cat([v, normals.to(torch.float32)], dim=1) if normals is not None else v).contiguous()}
+    else:
+        # 3 bytes of colour behind 12 or 24 bytes of floats: the record is not a multiple of 4 bytes, so it is assembled byte-wise
+        cols = [v.contiguous().reshape(-1).view(torch.uint8).view(V, 12)]
+        if normals is not None:
+            cols.append(normals.to(torch.float32).contiguous().reshape(-1).view(torch.uint8).view(V, 12))
         c = colors.to(torch.float32)
         scale = torch.where(c.max() < 1., 255., 1.).to(torch.float32) if V else 1.
         cols.append((c * scale).to(torch.uint8).contiguous().view(V, 3))
-    out = {'vrec': torch.cat(cols, dim=1) if len(cols) > 1 else cols[0]}
+        out = {'vrec': torch.cat(cols, dim=1)}
     F = 0
     if faces is not None:
         F = int(faces.shape[0])
         f = faces.to(torch.int32)
-        out['frec'] = torch.cat([torch.full((F, 1), 3, dtype=torch.int32, device=f.device), f], dim=1)
+        frec = torch.empty((F, 4), dtype=torch.int32, device=f.device)
+        frec[:, 0] = 3
+        frec[:, 1:] = f
+        out['frec'] = frec
     return ply_header(V, F, normals is not None, colors is not None), out
 
 

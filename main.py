@@ -147,6 +147,8 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
     mine = [frames[j] for j in parallel.shard_frames(len(frames), rank, world)]
     prefetch = FramePrefetcher(load_host, mine, dev, depth=1 if sync_io else 2)
     writer = MeshWriter(dev, slots=io_slots, threads=io_threads)
+    # (Leaving a few CUs to the output copies -- blit kernels on this runtime -- as multi-rank runs do for RCCL was measured and does not help: 21.7 / 22.7 /
+    # 21.4 - 22.6 / 23.1 ms per frame with 0 / 4 / 8 / 16 spare CUs; what the PLY leg lost was host time between two frames, see emit_outputs below.)
     clock = {'start': [], 'bytes_written': 0, 'files': 0}
     lock = __import__('threading').Lock()
 
@@ -197,7 +199,30 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
                 save['recon_live_vc'] = pipe.transfer_colours(save['recon_cano_v'], a['cano_v'], save['live_vc'])
         # ---- outputs (main.py:491-498): the file bytes are assembled on the device (obj_io.ply_records_device), copied out behind the frame's kernels
         # and written by the writer threads; nothing here waits for the device
+        # Assembling and handing over takes the loop thread 1 - 2 ms, and HERE the device's queue is empty (marching cubes has just read its counts): the
+        # section is parked and runs behind the NEXT frame's query launch (FramePipeline.after_query), or after the loop for the last frame.
+        def outputs(save=save, a=a, data_idx=data_idx, i=i):
+            try:
+                emit_outputs(save, a, data_idx, i)
+            except Exception as e:      # noqa: BLE001 -- reported for ITS frame, not for the frame in whose shadow it runs
+                deferred_failures.append((i, f'{type(e).__name__}: {e}'))
+        if sync_io or not hasattr(pipe, 'after_query'):
+            outputs()
+        else:
+            pipe.after_query.append(outputs)
+        log('# %sframe %d (data idx %d): avatar %d verts / %d faces%s' % ('rank %d: ' % rank if world > 1 else '', i, data_idx, a['cano_v'].shape[0],
+            a['f'].shape[0], (', recon %d verts' % save['recon_cano_v'].shape[0]) if w_recon else ''))
+        if checking:
+            check['pending'] = False              # this frame went through every kernel with the range check on
+        if gather_meshes and a.get('live_v') is not None:
+            return {'v': a['live_v'], 'vn': a['live_vn'], 'f': a['f']}
+        return None
+
+    deferred_failures = []
+
+    def emit_outputs(save, a, data_idx, i):
         from avatarcap_amd.utils import obj_io
+        t_out = time.perf_counter()
         out_t, plys = {}, []
         if save_npz:
             out_t.update({k_: v for k_, v in save.items() if v is not None})
@@ -228,13 +253,7 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
             writer.submit(out_t, write, tag=i)
             if sync_io:
                 writer.drain()                                # the reference's shape: .cpu() and the file writes inside the frame
-        log('# %sframe %d (data idx %d): avatar %d verts / %d faces%s' % ('rank %d: ' % rank if world > 1 else '', i, data_idx, a['cano_v'].shape[0],
-            a['f'].shape[0], (', recon %d verts' % save['recon_cano_v'].shape[0]) if w_recon else ''))
-        if checking:
-            check['pending'] = False              # this frame went through every kernel with the range check on
-        if gather_meshes and a.get('live_v') is not None:
-            return {'v': a['live_v'], 'vn': a['live_vn'], 'f': a['f']}
-        return None
+        clock['out_host_s'] = clock.get('out_host_s', 0.0) + time.perf_counter() - t_out
 
     # --gather-meshes: the one collective of the throughput mode: every rank's finished avatar meshes, exchanged step by step
     # WHILE the following frames compute (parallel.MeshExchange: exact sizes, asynchronous), in batches of `gather_batch` steps so that a long
@@ -283,11 +302,13 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
         return mesh
 
     summary = parallel.run_sharded(frames, process_and_submit, rank, world, log, max_consecutive_failures=max_failure_streak)
+    if hasattr(pipe, 'run_after_query') and not gather.get('dead'):
+        pipe.run_after_query()                                 # the last frame's outputs (nothing follows in whose shadow they could run)
     t_enqueued = time.perf_counter()
     if dev is not None and not gather.get('dead'):
         torch.cuda.synchronize(dev)
     t_device = time.perf_counter()
-    for fr, why in writer.close():                             # a frame whose files could not be written has failed
+    for fr, why in deferred_failures + writer.close():         # a frame whose files could not be written has failed
         if fr in summary['done']:
             summary['done'].remove(fr)
         summary['failed'].append((fr, 'output: ' + why))
@@ -309,7 +330,8 @@ def run_avatarcap(w_recon=True, save_avatar_mesh=False, save_final_mesh=False, w
             'writer_tail_ms': (t_written - t_device) * 1e3, 'first_frame_ms': (st[1] - st[0]) * 1e3 if n > 1 else None,
             'bytes_written': clock['bytes_written'], 'files_written': clock['files'], 'd2h_bytes': writer.d2h_bytes,
             'h2d_copies': prefetch.h2d_copies, 'h2d_bytes': prefetch.h2d_bytes, 'waited_for_writer_slot_ms': writer.waited_for_slot_s * 1e3,
-            'io_threads': io_threads, 'io_slots': io_slots, 'output_dir': out_dir, 'vol_res': None if dry_run else list(cfg['testing']['vol_res'])})
+            'io_threads': io_threads, 'io_slots': io_slots,
+            'output_section_host_ms_per_frame': clock.get('out_host_s', 0.0) / max(1, n) * 1e3, 'output_dir': out_dir, 'vol_res': None if dry_run else list(cfg['testing']['vol_res'])})
     if gather.get('dead') and world > 1:
         log('# rank %d: device lost (%s) -- leaving the job without touching the process group; the launcher stops the other ranks' % (rank, gather['dead']))
         sys.stdout.flush(); sys.stderr.flush()
