@@ -233,6 +233,30 @@ def host_mirror(batch, key):
     return a if a.size == batch[key].numel() else None
 
 
+class TensorWatch:
+    """Has anything a module's packed weights were made from changed?  The modules re-pack when a parameter or buffer was edited in place (`_version`), moved or
+    re-assigned (`data_ptr`, `id`) -- a check that runs at every query, at the START of a frame, where the device's queue is empty and host time is device time.
+    `tuple(p._version for p in module.parameters())` walks the module tree (0.1 - 0.7 ms for the networks here, three times per signature); this resolves the
+    (owner dict, key) slot of every parameter and buffer ONCE and re-reads the slots: ~30 us.  The slots are those of the module tree at construction -- the
+    reference never adds or replaces sub-modules of a built network; a tensor re-assigned in its slot IS seen (the slot is read, not a cached tensor)."""
+
+    def __init__(self, module, include=None):
+        self.slots = []
+        for name, m in module.named_modules():
+            if include is not None and not include(name):
+                continue
+            for d in (m._parameters, m._buffers):
+                for k in d:
+                    self.slots.append((d, k))
+
+    def signature(self):
+        out = []
+        for d, k in self.slots:
+            t = d.get(k)
+            out.append(None if t is None else (id(t), t._version, t.data_ptr()))
+        return tuple(out)
+
+
 # ---- weight marshalling --------------------------------------------------------------------
 def _host(t) -> np.ndarray:
     a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)

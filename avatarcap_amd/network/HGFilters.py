@@ -73,13 +73,18 @@ class HGFilter(nn.Module):
     def __getstate__(self):                        # the pack token refers to a live context: never pickled / deep-copied
         d = dict(self.__dict__)
         d['_packed'] = None
+        d.pop('_watch', None)
         return d
 
     def _ctx(self, device):
         """The device's context with THIS module's weights packed (again after load_state_dict / in-place edits / another module's pack)."""
         from .. import _lib
         ctx = _lib.ctx(device)
-        ver = (ctx, id(self), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        w = self.__dict__.get('_watch')
+        if w is None:
+            w = _lib.TensorWatch(self)
+            object.__setattr__(self, '_watch', w)
+        ver = (ctx, id(self), w.signature())
         if self._packed != ver or not _lib.owns(ctx, 'hgfilter', ver):
             w = _lib.HGFilterWeights(self)
             _lib.check(_lib.lib().avc_hgfilter_pack(ctx, w.struct))

@@ -165,7 +165,11 @@ class GeoTexAvatar(nn.Module):
 
     # ---- packing (BatchNorm folded from running stats => eval-mode semantics, as in main.py:297) ----
     def _weights_version(self):
-        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        w = self.__dict__.get('_watch')
+        if w is None:
+            w = _lib.TensorWatch(self)
+            object.__setattr__(self, '_watch', w)
+        return w.signature()
 
     def _ctx(self, device):
         ctx = _lib.ctx(device)

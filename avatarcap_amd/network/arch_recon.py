@@ -55,7 +55,11 @@ class ReconNetwork(nn.Module):
 
     def _ctx(self, device):
         ctx = _lib.ctx(device)
-        ver = (ctx, id(self), tuple(p._version for p in self.image_decoder.parameters()))
+        w = self.__dict__.get('_watch')
+        if w is None:
+            w = _lib.TensorWatch(self.image_decoder)
+            object.__setattr__(self, '_watch', w)
+        ver = (ctx, id(self), w.signature())
         if self._packed_version != ver or not _lib.owns(ctx, 'recon', ver):      # another ReconNetwork may have packed into this context since
             fc = _lib.DenseList(_mlp_entries(self.image_decoder))
             _lib.check(_lib.lib().avc_pack_recon_weights(ctx, fc.arr))

@@ -214,3 +214,35 @@ def test_exr_reader_round_trip(tmp_path):
     open(bad, 'wb').write(b'not an exr file at all')
     with pytest.raises(ValueError):
         read_exr(bad)
+
+
+def test_tensor_watch_sees_what_the_packers_must_see():
+    """_lib.TensorWatch: the per-query 'have the packed weights changed?' check without walking the module tree (0.03 ms instead of 0.7): in-place edits under
+    no_grad, buffers (BatchNorm running statistics), load_state_dict, a parameter re-assigned in its slot; a deep copy gets a watch of its own."""
+    import copy
+    import contextlib
+    import io
+    import torch
+    from avatarcap_amd import config
+    from avatarcap_amd.network.arch_avatar import GeoTexAvatar
+    old_cfg, old_dev = config.cfg, config.device
+    config.cfg, config.device = config.default_cfg(), torch.device('cpu')
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = GeoTexAvatar(base_weight_volume=np.zeros((2, 2, 2, 24), np.float32))
+        s = [net._weights_version()]
+        assert net._weights_version() == s[0]
+        with torch.no_grad():
+            net.cano_template.geo_mlp.fc_list[1].weight.mul_(2)
+        s.append(net._weights_version())
+        net.warping_field.mlp.bn3.running_var.add_(1)
+        s.append(net._weights_version())
+        net.cano_template.geo_mlp.fc_list[1].weight = torch.nn.Parameter(torch.zeros_like(net.cano_template.geo_mlp.fc_list[1].weight))
+        s.append(net._weights_version())
+        net.load_state_dict(net.state_dict())
+        s.append(net._weights_version())
+        assert len(set(s)) == len(s)
+        twin = copy.deepcopy(net)
+        assert twin._weights_version() != net._weights_version() and twin._weights_version() == twin._weights_version()
+    finally:
+        config.cfg, config.device = old_cfg, old_dev
