@@ -19,10 +19,11 @@
 //                     column from the next lane) and one comparison of 20 "above the level" bits tells that none is crossed (most are not).  Tiles
 //                     (1024 consecutive grid points) with a crossed cell get their cells' cube indices stored (1 byte each) and a place in the list of
 //                     crossed tiles; the volume is not walked again.  No tables, 32 registers: bound by the cache's request rate (four rows per cell row)
-//   pass A2 count   : per crossed tile: cube index -> tiling-table row (the face / interior tests in fp64 read the 8 corner values of the few cells
+//   pass A2 count   : per crossed tile, the crossed cells compacted per wave (every lane takes one crossed cell at a time): cube index -> tiling-table row
+//                     (the face / interior tests in fp64 read the 8 corner values of the few cells
 //                     that need them), stored as 2 bytes per cell; #vertices created, #triangles, #crossed cells -> tile sums
 //   scan            : exclusive scan of the tile sums (one workgroup, through LDS), totals and "fits the caller's capacity" left on the device
-//   pass B  verts   : per crossed tile, in any order: the stored rows, in-tile scan, number the new vertices, record their ids in the edge map (3 ints
+//   pass B  verts   : per crossed tile, in any order: the stored rows, in-tile scan (per-cell offsets in LDS), the crossed cells compacted per wave, number the new vertices, record their ids in the edge map (3 ints
 //                     per grid point, sparsely written), write one 16-byte record per crossed cell {cell, table row, first face, centre-vertex id}
 //                     and, into each new vertex's output slot, which (cell, edge) it is
 //   pass B' eval    : one thread per vertex: position (the library's fp64 formula) + normal (64-tap stencil)
@@ -429,82 +430,74 @@ __global__ __launch_bounds__(1024) void mc_compact_kernel(const unsigned *__rest
 
 // ---------------- pass A2: the crossed tiles' cells -> tiling rows, counts ----------------
 // rows16: one int16 per grid point of a crossed tile (the tiling row of the cell whose low corner it is, -1 = not crossed / not a cell)
+// Crossed cells are sparse even in a crossed tile (~11 % of the cells of a dense frame's tiles): walking a thread's four cells in lockstep ran the case
+// analysis (resolve_row: table look-ups, the fp64 face and interior tests) four times per wave with a tenth of the lanes alive.  Each wave now COMPACTS the
+// crossed cells of its 256 cells (ballot-free: a lane prefix over the per-lane counts, the cells listed in LDS in traversal order) and gives every lane one
+// crossed cell at a time: one or two passes of the case analysis per wave with most lanes alive (94 -> see profiles/r06_mc_kernels.md).
+// wave-level exclusive prefix of one small count per lane; returns the lane's base, `total` = the wave's sum
+__device__ __forceinline__ unsigned wave_exclusive(unsigned v, unsigned &total)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    total = __shfl(incl, 63, 64);
+    return incl - v;
+}
+
 __global__ __launch_bounds__(256) void mc_count_kernel(McArgs a, const unsigned *__restrict__ list, const unsigned *__restrict__ list_n,
                                                        const uint8_t *__restrict__ idx8, unsigned *__restrict__ tile_v, unsigned *__restrict__ tile_t,
                                                        unsigned *__restrict__ tile_c, int16_t *__restrict__ rows16)
 {
     __shared__ uint32_t tab[mc::BLOB_WORDS];
     __shared__ unsigned red[12];
+    __shared__ uint16_t items[TILE];            // per wave [256]: (lane << 2 | k) of its crossed cells, in traversal order; low byte pair reused below
+    __shared__ uint8_t cube[TILE];              // the tile's cube indices
+    __shared__ int16_t rows_l[TILE];            // the tile's tiling rows (-1: not crossed)
     const unsigned n = *list_n;
     if (blockIdx.x >= n) return;
     load_tables(a.tables, tab);
     const int yx = a.n1 * a.n2;
-    const bool vec = (a.n2 & 3) == 0 && (reinterpret_cast<uintptr_t>(a.vol) & 15) == 0;      // a thread's four cells lie in one x row, 16-byte aligned
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
         const int tile = (int)list[it];
-        unsigned nv = 0, nt = 0, nc = 0;
-        int rows[4] = {-1, -1, -1, -1};
         const int64_t li0 = (int64_t)tile * TILE + threadIdx.x * 4;
         const unsigned word = li0 < a.N ? *reinterpret_cast<const unsigned *>(idx8 + li0) : 0u;
-        if (word) {
-            const int z = (int)(li0 / yx), r2 = (int)(li0 - (int64_t)z * yx), y = r2 / a.n2, x0 = r2 - y * a.n2;
-            if (vec) {
-                // the four corner rows of the thread's four cells in one round of loads (a crossed cell exists: the rows (z + 1, .) and (., y + 1) do)
-                float r[4][5];
-                const bool fifth = x0 + 4 < a.n2;
-                const float *p = a.vol + li0;
+        *reinterpret_cast<unsigned *>(cube + threadIdx.x * 4) = word;
+        *reinterpret_cast<uint2 *>(rows_l + threadIdx.x * 4) = make_uint2(0xffffffffu, 0xffffffffu);
+        const unsigned mine = (word & 0xffu ? 1u : 0u) + (word & 0xff00u ? 1u : 0u) + (word & 0xff0000u ? 1u : 0u) + (word & 0xff000000u ? 1u : 0u);
+        unsigned total;
+        unsigned base = wave_exclusive(mine, total);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float *pq = p + (q >> 1) * (int64_t)yx + (q & 1) * a.n2;
-                    const float4 v4 = *reinterpret_cast<const float4 *>(pq);
-                    r[q][0] = v4.x; r[q][1] = v4.y; r[q][2] = v4.z; r[q][3] = v4.w;
-                    r[q][4] = fifth ? pq[4] : v4.w;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned idx = (word >> (8 * k)) & 255u;
-                    if (idx == 0u) continue;
-                    const float val[8] = {r[0][k], r[0][k + 1], r[1][k + 1], r[1][k], r[2][k], r[2][k + 1], r[3][k + 1], r[3][k]};
-                    const int row = resolve_row(val, a, (int)idx, tab);
-                    rows[k] = row;
-                    if (row >= 0) {
-                        nt += row_ntri(tab, row);
-                        nv += __popc(row_mask(tab, row) & creator_mask(z, y, x0 + k));
-                        nc += 1;
-                    }
-                }
-            } else {
-#pragma unroll 1
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned idx = (word >> (8 * k)) & 255u;
-                    if (idx == 0u) continue;
-                    const int64_t li = li0 + k;
-                    const int zz = (int)(li / yx), r3 = (int)(li - (int64_t)zz * yx), yy = r3 / a.n2, xx = r3 - yy * a.n2;
-                    const float *p = a.vol + li;
-                    const float val[8] = {p[0], p[1], p[a.n2 + 1], p[a.n2], p[yx], p[yx + 1], p[yx + a.n2 + 1], p[yx + a.n2]};
-                    const int row = resolve_row(val, a, (int)idx, tab);
-                    rows[k] = row;
-                    if (row >= 0) {
-                        nt += row_ntri(tab, row);
-                        nv += __popc(row_mask(tab, row) & creator_mask(zz, yy, xx));
-                        nc += 1;
-                    }
-                }
+        for (int k = 0; k < 4; ++k)
+            if ((word >> (8 * k)) & 255u) items[wave * 256 + base++] = (uint16_t)(lane * 4 + k);
+        __builtin_amdgcn_wave_barrier();        // a wave reads only what it wrote itself (LDS operations of a wave complete in order)
+        unsigned nv = 0, nt = 0, nc = 0;
+        for (unsigned i = lane; i < total; i += 64) {
+            const int c = wave * 256 + items[wave * 256 + i];               // the cell's place in the tile
+            const int64_t li = (int64_t)tile * TILE + c;
+            const int z = (int)(li / yx), r2 = (int)(li - (int64_t)z * yx), y = r2 / a.n2, x = r2 - y * a.n2;
+            const float *p = a.vol + li;                                    // (a crossed cell exists: its +1 neighbours along every axis do)
+            const float val[8] = {p[0], p[1], p[a.n2 + 1], p[a.n2], p[yx], p[yx + 1], p[yx + a.n2 + 1], p[yx + a.n2]};
+            const int row = resolve_row(val, a, (int)cube[c], tab);
+            rows_l[c] = (int16_t)row;
+            if (row >= 0) {
+                nt += row_ntri(tab, row);
+                nv += __popc(row_mask(tab, row) & creator_mask(z, y, x));
+                nc += 1;
             }
         }
         for (int o = 32; o > 0; o >>= 1) { nv += __shfl_down(nv, o, 64); nt += __shfl_down(nt, o, 64); nc += __shfl_down(nc, o, 64); }
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = nv; red[4 + (threadIdx.x >> 6)] = nt; red[8 + (threadIdx.x >> 6)] = nc; }
+        if (lane == 0) { red[wave] = nv; red[4 + wave] = nt; red[8 + wave] = nc; }
         __syncthreads();
         if (threadIdx.x == 0) {
             tile_v[tile] = red[0] + red[1] + red[2] + red[3];
             tile_t[tile] = red[4] + red[5] + red[6] + red[7];
             tile_c[tile] = red[8] + red[9] + red[10] + red[11];
         }
-        if (li0 < a.N) {
-            const unsigned lo = ((unsigned)rows[0] & 0xffffu) | ((unsigned)rows[1] << 16), hi = ((unsigned)rows[2] & 0xffffu) | ((unsigned)rows[3] << 16);
-            *reinterpret_cast<uint2 *>(rows16 + li0) = make_uint2(lo, hi);
-        }
+        if (li0 < a.N) *reinterpret_cast<uint2 *>(rows16 + li0) = *reinterpret_cast<const uint2 *>(rows_l + threadIdx.x * 4);
+        __syncthreads();                         // the LDS arrays are rewritten by the next tile
     }
 }
 
@@ -690,65 +683,84 @@ __global__ __launch_bounds__(256) void mc_verts_kernel(McArgs a, EmitArgs e, con
 {
     __shared__ uint32_t tab[mc::BLOB_WORDS];
     __shared__ unsigned red[4];
+    __shared__ uint16_t items[TILE];            // per wave [256]: its crossed cells (lane << 2 | k) in traversal order (as in mc_count_kernel)
+    __shared__ int16_t rows_l[TILE];
+    __shared__ unsigned loc_l[TILE], floc_l[TILE], cloc_l[TILE];      // per cell: where its first new vertex, first face and its record go
     if (!totals[3]) return;                                  // the mesh does not fit the caller's buffers: nothing is written (AVC_ERR_CAPACITY)
     const unsigned nlist = *list_n;
     if (blockIdx.x >= nlist) return;
     load_tables(a.tables, tab);
     const int yx = a.n1 * a.n2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (unsigned it = blockIdx.x; it < nlist; it += gridDim.x) {          // the crossed tiles, in any order: their offsets say where they write
         const int tile = (int)list[it];
         const unsigned vbase = tile_voff[tile], tbase = tile_toff[tile], cbase = tile_coff[tile];
         int rows[4] = {-1, -1, -1, -1};
-        int cz[4], cy[4], cx[4];
+        unsigned cv[4] = {0, 0, 0, 0}, ct[4] = {0, 0, 0, 0};
         unsigned nv = 0, nt = 0, nc = 0;
         const int64_t li0 = (int64_t)tile * TILE + threadIdx.x * 4;
         if (li0 < a.N) {
             const uint2 rw = *reinterpret_cast<const uint2 *>(rows16 + li0);
             rows[0] = (int16_t)(rw.x & 0xffffu); rows[1] = (int16_t)(rw.x >> 16); rows[2] = (int16_t)(rw.y & 0xffffu); rows[3] = (int16_t)(rw.y >> 16);
+            *reinterpret_cast<uint2 *>(rows_l + threadIdx.x * 4) = rw;
+        } else {
+            *reinterpret_cast<uint2 *>(rows_l + threadIdx.x * 4) = make_uint2(0xffffffffu, 0xffffffffu);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t li = li0 + k;
-            cz[k] = (int)(li / yx);
-            const int r = (int)(li - (int64_t)cz[k] * yx);
-            cy[k] = r / a.n2; cx[k] = r - cy[k] * a.n2;
             if (rows[k] >= 0) {
-                nt += row_ntri(tab, rows[k]);
-                nv += __popc(row_mask(tab, rows[k]) & creator_mask(cz[k], cy[k], cx[k]));
-                nc += 1;
+                const int64_t li = li0 + k;
+                const int cz = (int)(li / yx), r = (int)(li - (int64_t)cz * yx), cy = r / a.n2, cx = r - cy * a.n2;
+                ct[k] = row_ntri(tab, rows[k]);
+                cv[k] = __popc(row_mask(tab, rows[k]) & creator_mask(cz, cy, cx));
+                nt += ct[k]; nv += cv[k]; nc += 1;
             }
         }
         unsigned total, tt, tc;
-        unsigned loc = block_exclusive(nv, red, total);
+        unsigned loc = vbase + block_exclusive(nv, red, total);
         unsigned floc = tbase + block_exclusive(nt, red, tt);
         unsigned cloc = cbase + block_exclusive(nc, red, tc);
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            if (rows[k] < 0) continue;
-            const int row = rows[k], n = 3 * row_ntri(tab, row);
-            const unsigned creator = creator_mask(cz[k], cy[k], cx[k]);
-            const int64_t li = li0 + k;
+        // the crossed cells of this wave, compacted in traversal order, with their offsets (the serial emission loop below then runs with most lanes alive
+        // instead of four times per wave with a tenth of them)
+        unsigned wtotal;
+        unsigned base = wave_exclusive(nc, wtotal);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (rows[k] >= 0) {
+                const int c = threadIdx.x * 4 + k;
+                items[wave * 256 + base++] = (uint16_t)(lane * 4 + k);
+                loc_l[c] = loc; floc_l[c] = floc; cloc_l[c] = cloc;
+                loc += cv[k]; floc += ct[k]; ++cloc;
+            }
+        __builtin_amdgcn_wave_barrier();
+        for (unsigned i = lane; i < wtotal; i += 64) {
+            const int c = wave * 256 + items[wave * 256 + i];
+            const int64_t li = (int64_t)tile * TILE + c;
+            const int cz = (int)(li / yx), r2 = (int)(li - (int64_t)cz * yx), cy = r2 / a.n2, cx = r2 - cy * a.n2;
+            const int row = rows_l[c], n = 3 * row_ntri(tab, row);
+            const unsigned creator = creator_mask(cz, cy, cx);
+            unsigned vloc = loc_l[c];
             unsigned seen = 0;
             int32_t cvid = -1;
-            for (int i = 0; i < n; ++i) {
-                const int ed = row_edge(tab, row, i);
+            for (int k = 0; k < n; ++k) {
+                const int ed = row_edge(tab, row, k);
                 if (seen & (1u << ed)) continue;
                 seen |= 1u << ed;
                 if (!(creator & (1u << ed))) continue;
-                const int32_t id = (int32_t)(vbase + loc);
+                const int32_t id = (int32_t)vloc;
                 const uint64_t d = ((uint64_t)li << 4) | (uint64_t)ed;
                 reinterpret_cast<uint32_t *>(verts)[3 * (size_t)id] = (uint32_t)d; reinterpret_cast<uint32_t *>(verts)[3 * (size_t)id + 1] = (uint32_t)(d >> 32);
-                ++loc;
+                ++vloc;
                 if (ed == 12) { cvid = id; continue; }
                 int dx, dy, dz, axis;
                 edge_base(ed, dx, dy, dz, axis);
                 edge_map[3 * (li + (int64_t)dz * yx + dy * a.n2 + dx) + axis] = id;
             }
-            CellRec r;
-            r.li = (uint32_t)li; r.row = (uint32_t)row; r.face0 = floc; r.cvid = cvid;
-            cells[cloc] = r;
-            floc += n / 3; ++cloc;
+            CellRec rec;
+            rec.li = (uint32_t)li; rec.row = (uint32_t)row; rec.face0 = floc_l[c]; rec.cvid = cvid;
+            cells[cloc_l[c]] = rec;
         }
+        __syncthreads();                         // the LDS arrays are rewritten by the next tile
     }
 }
 

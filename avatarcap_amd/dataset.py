@@ -50,11 +50,12 @@ class SyntheticTestDataset:
                 d2[s:s + step] = d[0, :, 0]
             self.infer_pts_flag = d2 < 0.1 ** 2                                            # :116
             self.infer_pts = vol_pts[self.infer_pts_flag].contiguous()                     # :118
-            inv = vol_pts[~self.infer_pts_flag].cpu().numpy()
-            sign = np.empty(inv.shape[0], np.float32)
-            for s in range(0, inv.shape[0], 1 << 20):                                      # :121-125 (contains -> [-1, 1])
-                sign[s:s + (1 << 20)] = np.where(syn.body_sdf(inv[s:s + (1 << 20)]) < 0, 1.0, -1.0)
-            self.invalid_pts_ov = torch.from_numpy(sign).to(self.device)
+            inv = vol_pts[~self.infer_pts_flag]
+            sign = torch.empty(inv.shape[0], dtype=torch.float32, device=self.device)
+            for s in range(0, inv.shape[0], 1 << 21):                                      # :121-125 (contains -> [-1, 1]), on the device where there is one
+                sdf = syn.body_sdf_device(inv[s:s + (1 << 21)]) if self.device.type == 'cuda' else torch.from_numpy(syn.body_sdf(inv[s:s + (1 << 21)].numpy()))
+                sign[s:s + (1 << 21)] = torch.where(sdf < 0, 1.0, -1.0).to(torch.float32)
+            self.invalid_pts_ov = sign
         else:
             raise ValueError("valid must be 'dense' or 'band'")
         self.valid_u8 = self.infer_pts_flag.to(torch.uint8).contiguous()
