@@ -101,7 +101,6 @@ struct ConvArgs {
     int yC, ycoff;
     StatOut st_raw, st_y;
     int tiles_x, tiles_y;
-    int tile0, tile_step;        // this launch covers the tiles tile0, tile0 + tile_step, ... (0, 1: all of them; a launch cut in two interleaved halves: (0, 2) and (1, 2))
     int ksplit;                  // workgroups per (tile, slice): each walks Cin / 32 / ksplit chunks of K (1: no split)
     float *kpart;                // split-K: [tile x slice][ksplit][accumulator registers][256 threads] raw sums
     unsigned *kcounter;          // split-K: one ticket per (tile, slice)
@@ -226,8 +225,10 @@ __global__ __launch_bounds__(256, OCC2 ? 2 : 1) void conv_mfma_kernel(const Conv
     // blockIdx -> (k slice, channel slice, pixel tile): a workgroup walks the chunks [c0, c1) of the input channels (split-K launches: ksplit > 1)
     // (a band of the image per XCD -- workgroup b on XCD b % 8 taking the tiles of ITS eighth, so that vertically adjacent tiles share their halo rows in one
     // L2 -- was measured and changes nothing: 46.3 / 46.9, 136.5 / 135.6, 51.8 / 51.1 us; the input fetch is not what a launch waits for, profiles/r06_enc_phases.md)
-    const int ks = blockIdx.x % p.ksplit, wgl = blockIdx.x / p.ksplit;
-    const int slice = wgl % slices, tile = p.tile0 + (wgl / slices) * p.tile_step, wg = tile * slices + slice;
+    // (cutting a launch into two launches of every other tile on two streams, so that the halves start a launch latency apart, costs its fork and join: +15 - 20 us
+    // on every shape tried, profiles/r06_enc_phases.md)
+    const int ks = blockIdx.x % p.ksplit, wg = blockIdx.x / p.ksplit;
+    const int slice = wg % slices, tile = wg / slices;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int y0 = ty * ROWS, x0 = tx * TWC;
     const int cpk = (p.Cin >> 5) / p.ksplit, c0 = ks * cpk, c1 = c0 + cpk;
@@ -1241,7 +1242,7 @@ struct Planner {
         // few workgroups, each streaming its whole K serially, are bound by the latency of their weight stream: split K over more of them
         const int wg = ntiles * (w.cout / (32 * L.CT)), nchunk = x.C / 32;
         a.range_flag = e->range_flag;
-        a.ksplit = 1; a.tile0 = 0; a.tile_step = 1;
+        a.ksplit = 1;
         if (ctx->opt.enc_ksplit)
             while (nchunk % (2 * a.ksplit) == 0 && a.ksplit < 8 && 2 * wg * a.ksplit <= ctx->num_cus) a.ksplit *= 2;       // slices of whole chunks
         if (a.ksplit > 1) {
@@ -1665,7 +1666,7 @@ static int build_unet_plan(avc_ctx *ctx, Encoder *e, int Hin, int Win)
         }
         a.range_flag = e->range_flag;
         const int wg = a.tiles_x * a.tiles_y * (w.cout / (32 * L.CT));
-        a.ksplit = ks; a.tile0 = 0; a.tile_step = 1;
+        a.ksplit = ks;
         if (a.ksplit > 1) {
             a.kpart = static_cast<float *>(P.alloc(sizeof(float) * (size_t)wg * a.ksplit * 256 * L.PT * L.CT * 16));
             a.kcounter = static_cast<unsigned *>(P.alloc(sizeof(unsigned) * wg, true));

@@ -116,30 +116,6 @@ int main(int argc, char **argv)
             CK(hipMalloc(&a.kcounter, sizeof(unsigned) * wg)); CK(hipMemset(a.kcounter, 0, sizeof(unsigned) * wg));
         }
         L.grid = (unsigned)(wg * ksplit);
-        a.tile0 = 0; a.tile_step = 1;
-        if (getenv("SPLIT2") && atoi(getenv("SPLIT2")) && ntiles % 2 == 0 && ksplit == 1) {
-            // the launch as TWO launches of every other tile on two streams (a fork / join per iteration, as consecutive dependent launches of a plan would have):
-            // the halves share the CUs and start a launch latency apart -- are their memory phases then out of step?
-            hipStream_t s1; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
-            hipStream_t s0; CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
-            hipEvent_t fork, join; CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
-            Launch LA = L, LB = L;
-            LA.conv.tile_step = LB.conv.tile_step = 2; LB.conv.tile0 = 1; LA.grid = LB.grid = L.grid / 2;
-            auto both = [&] {
-                CK(hipEventRecord(fork, s0)); CK(hipStreamWaitEvent(s1, fork, 0));
-                if (launch_conv(LA, s0) || launch_conv(LB, s1)) exit(1);
-                CK(hipEventRecord(join, s1)); CK(hipStreamWaitEvent(s0, join, 0));
-            };
-            for (int i = 0; i < 3; ++i) both();
-            CK(hipDeviceSynchronize());
-            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-            CK(hipEventRecord(e0, s0));
-            for (int i = 0; i < iters; ++i) both();
-            CK(hipEventRecord(e1, s0)); CK(hipEventSynchronize(e1));
-            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("conv %dx%d %d->%d taps %d CT%d PT%d occ2 %d as two interleaved half launches on two streams: %.1f us per pair\n", H, W, Cin, Cout, taps, CT, PT, (int)L.occ2, 1e3 * ms / iters);
-            return 0;
-        }
         const double us = time_us([&] { if (launch_conv(L, 0)) exit(1); }, iters);
 #ifdef AVC_ENC_PHASES
         {   // one more launch with s_memtime stamps per workgroup: where the time of a workgroup goes (cycles of the 100 MHz-independent shader counter)
