@@ -102,6 +102,7 @@ _SIGNATURES = {
     'avc_lbs_prepare': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'avc_calculate_lbs_bound': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_lbs_bound_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    'avc_lbs_skin_bound': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_skinning': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'avc_timing_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'avc_timing_read': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),

@@ -173,6 +173,8 @@ int near_flags(avc_ctx *ctx, const float *q, int64_t nq, const float *ref, int32
 int calculate_lbs(avc_ctx *ctx, const float *pts, int64_t n, const float *cano_v, const float *skin_w, int32_t nv, float *lbs, hipStream_t s);
 int lbs_prepare(avc_ctx *ctx, const float *cano_v, int32_t nv, hipStream_t s);
 int calculate_lbs_bound(avc_ctx *ctx, const float *pts, int64_t n, const float *skin_w, float *lbs, hipStream_t s);
+int lbs_skin_bound(avc_ctx *ctx, const float *pts, const float *nrm, int64_t n, const float *skin_w, const float *jm, float *lbs, float *po, float *no, float *mo,
+                   hipStream_t s);
 int lbs_bound_stats(avc_ctx *ctx, int64_t out[4]);
 void release_lbs_bound(avc_ctx *ctx);
 int skinning(const float *pts, const float *nrm, int64_t n, const float *lbs, const float *jm, float *po, float *no, float *mo, hipStream_t s);

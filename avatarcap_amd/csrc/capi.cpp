@@ -388,6 +388,16 @@ int avc_calculate_lbs_bound(avc_ctx *ctx, const float *pts, int64_t n, const flo
     return calculate_lbs_bound(ctx, pts, n, skin_w, lbs, (hipStream_t)stream);
 }
 
+int avc_lbs_skin_bound(avc_ctx *ctx, const float *pts, const float *nrm, int64_t n, const float *skin_w, const float *jm, float *lbs, float *po, float *no, float *mo,
+                       avc_stream stream)
+{
+    AVC_REQUIRE(ctx && n >= 0 && skin_w && jm, AVC_ERR_ARG, "avc_lbs_skin_bound: NULL argument");
+    AVC_REQUIRE(n == 0 || (pts && (po || mo || lbs)), AVC_ERR_ARG, "avc_lbs_skin_bound: no points, or nothing to write");
+    AVC_REQUIRE(!nrm || no, AVC_ERR_ARG, "avc_lbs_skin_bound: output missing for the normals");
+    AVC_HIP(hipSetDevice(ctx->device));
+    return lbs_skin_bound(ctx, pts, nrm, n, skin_w, jm, lbs, po, no, mo, (hipStream_t)stream);
+}
+
 int avc_lbs_bound_stats(avc_ctx *ctx, int64_t out[4])
 {
     AVC_REQUIRE(ctx && out, AVC_ERR_ARG, "avc_lbs_bound_stats: NULL argument");

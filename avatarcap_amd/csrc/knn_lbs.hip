@@ -502,6 +502,82 @@ __global__ __launch_bounds__(256) void skinning_kernel(const float *__restrict__
     }
 }
 
+// calculate_lbs + skinning + skinning_normal of main.py:385-389 in ONE launch (avc_lbs_skin_bound; lbs_skin_grid_kernel / lbs_skin_scan_kernel below): the blend weights of a vertex go from lbs_kernel's registers
+// straight into skinning_kernel's sums -- the same operations in the same order as the two kernels, so the same bits -- and the (n,24) weights, which the frame
+// loop never looks at, are written only on request: 112 B per vertex through HBM instead of 412 (lbs written once and read twice, points read twice).
+template <bool GRID>
+__device__ __forceinline__ void lbs_skin_body(const float *__restrict__ pts, const float *__restrict__ nrm, int64_t n, const float *__restrict__ cano_v,
+                                              const float *__restrict__ skin_w, int nv, const GridView &g, const CandView &cv, const float *__restrict__ jm,
+                                              float *__restrict__ lbs, float *__restrict__ po, float *__restrict__ no, float *__restrict__ mo)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ii = i < n ? i : n - 1;
+    float bd[4]; int bi[4];
+    knn_any<4, GRID>(cano_v, nv, g, pts[3 * ii], pts[3 * ii + 1], pts[3 * ii + 2], bd, bi, cv);
+    if (i >= n) return;
+    const float denom = (float)(2 * 0.05 * 0.05);                     // lbs_kernel, line for line
+    float w[4], sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { w[k] = expf(-bd[k] / denom); sum += w[k]; }
+    sum += 1e-16f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] /= sum;
+    float acc[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 *row = reinterpret_cast<const float4 *>(skin_w + (size_t)bi[k] * 24);
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+            const float4 v = row[jj];
+            acc[4 * jj + 0] += v.x * w[k]; acc[4 * jj + 1] += v.y * w[k]; acc[4 * jj + 2] += v.z * w[k]; acc[4 * jj + 3] += v.w * w[k];
+        }
+    }
+    if (lbs) {
+        float4 *out = reinterpret_cast<float4 *>(lbs + (size_t)i * 24);
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) out[jj] = make_float4(acc[4 * jj], acc[4 * jj + 1], acc[4 * jj + 2], acc[4 * jj + 3]);
+    }
+    float M[16];                                                      // skinning_kernel, line for line
+#pragma unroll
+    for (int e = 0; e < 16; ++e) M[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 24; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) M[e] += acc[j] * jm[j * 16 + e];           // wave-uniform addresses: the joint matrices come through scalar loads, sixteen SGPRs a row
+    if (mo) {
+        float4 *o = reinterpret_cast<float4 *>(mo + (size_t)i * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = make_float4(M[4 * r], M[4 * r + 1], M[4 * r + 2], M[4 * r + 3]);
+    }
+    if (po) {                                                         // (the point is read again rather than kept alive across the search)
+        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) po[3 * i + r] = M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z + M[4 * r + 3];
+    }
+    if (nrm) {
+        const float x = nrm[3 * i], y = nrm[3 * i + 1], z = nrm[3 * i + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) no[3 * i + r] = M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z;
+    }
+}
+// The search is a chain of dependent loads: it lives on waves in flight.  lbs_kernel fits 70 registers (seven waves per SIMD); the fused body's tail -- 24 blend
+// weights, 16 matrix sums, the skin-weight rows in flight -- would set the whole kernel's budget at 94 (five waves: 466 us against lbs_kernel's 319 on the dense frame's
+// 1.9 M vertices), so the grid form is held to seven waves (71 registers, three dwords spilled once in the tail: 311 us).  The exhaustive form is bound by its LDS tile.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void lbs_skin_grid_kernel(
+    const float *__restrict__ pts, const float *__restrict__ nrm, int64_t n, const float *__restrict__ cano_v, const float *__restrict__ skin_w, int nv, GridView g, CandView cv,
+    const float *__restrict__ jm, float *__restrict__ lbs, float *__restrict__ po, float *__restrict__ no, float *__restrict__ mo)
+{
+    lbs_skin_body<true>(pts, nrm, n, cano_v, skin_w, nv, g, cv, jm, lbs, po, no, mo);
+}
+__global__ __launch_bounds__(256) void lbs_skin_scan_kernel(
+    const float *__restrict__ pts, const float *__restrict__ nrm, int64_t n, const float *__restrict__ cano_v, const float *__restrict__ skin_w, int nv, GridView g, CandView cv,
+    const float *__restrict__ jm, float *__restrict__ lbs, float *__restrict__ po, float *__restrict__ no, float *__restrict__ mo)
+{
+    lbs_skin_body<false>(pts, nrm, n, cano_v, skin_w, nv, g, cv, jm, lbs, po, no, mo);
+}
+
 // near[i] = 0 when a reference point lies closer than sqrt(thr2) to query i, +inf otherwise -- the only thing the colour path wants of
 // knn_points(wpts, cano_smpl_vertices, K=1) (arch_avatar.py:208-209: near_flag = d2 < 0.08^2).  The same squared distance (cand_d2) against the
 // same threshold as a comparison of the K = 1 result gives, so the flags are the exact search's; but only the cells the ball touches are
@@ -768,6 +844,22 @@ int calculate_lbs_bound(avc_ctx *ctx, const float *pts, int64_t n, const float *
     const bool brute = ctx->opt.knn_search == 3 || !g.hdr;
     if (!brute) hipLaunchKernelGGL(lbs_kernel<true>, grid, block, 0, s, pts, n, b->ref, skin_w, b->nr, g, ctx->opt.knn_search == 0 ? b->cv : CandView{}, lbs);
     else hipLaunchKernelGGL(lbs_kernel<false>, grid, block, 0, s, pts, n, b->ref, skin_w, b->nr, g, CandView{}, lbs);
+    AVC_HIP(hipGetLastError());
+    return AVC_OK;
+}
+
+int lbs_skin_bound(avc_ctx *ctx, const float *pts, const float *nrm, int64_t n, const float *skin_w, const float *jm, float *lbs, float *po, float *no, float *mo,
+                   hipStream_t s)
+{
+    LbsBound *b = static_cast<LbsBound *>(ctx->lbs_bound);
+    AVC_REQUIRE(b && b->nr >= 4, AVC_ERR_STATE, "Canonical smpl vertices are invalid!");      // smpl_util.py:31 (avc_lbs_prepare was not called)
+    if (n == 0) return AVC_OK;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    GridView g = b->grid;
+    if (g.hdr) g.lane_box = ctx->opt.knn_search == 1 ? 0 : (ctx->opt.knn_search == 2 ? 0x7fffffff : LANE_BOX);
+    const bool brute = ctx->opt.knn_search == 3 || !g.hdr;
+    if (!brute) hipLaunchKernelGGL(lbs_skin_grid_kernel, grid, block, 0, s, pts, nrm, n, b->ref, skin_w, b->nr, g, ctx->opt.knn_search == 0 ? b->cv : CandView{}, jm, lbs, po, no, mo);
+    else hipLaunchKernelGGL(lbs_skin_scan_kernel, grid, block, 0, s, pts, nrm, n, b->ref, skin_w, b->nr, g, CandView{}, jm, lbs, po, no, mo);
     AVC_HIP(hipGetLastError());
     return AVC_OK;
 }

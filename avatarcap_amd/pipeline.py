@@ -63,7 +63,7 @@ class FramePipeline:
     """Holds the networks and the per-sequence constants; `avatar_frame` / `recon_frame` are steps
     1 and 3 of main.py's loop body."""
 
-    def __init__(self, network, dataset, recon_net=None):
+    def __init__(self, network, dataset, recon_net=None, lbs_reach_mm=None):
         from .network.arch_avatar import OccupancyNet
         self.network = network
         self.occ_net = OccupancyNet(network)
@@ -75,6 +75,16 @@ class FramePipeline:
         self.lookahead_on_side_stream = os.environ.get('AVC_LOOKAHEAD_SIDE', '1') == '1'     # the next frame's U-Net beside this frame's tail (avatar_frame)
         self._side = None
         smpl_util.set_smpl_skinning_weights(dataset.body['skin_weights'])
+        # How far from the body the bound vertices' candidate lists reach (csrc/knn_lbs.hip, avc_lbs_prepare) follows where a frame's SURFACE can lie: a
+        # band dataset's marching-cubes vertices stay inside the valid band (0.1 m of the body: 140 mm with the cell's diagonal); a dense dataset's can
+        # lie anywhere in the volume (the stress frame of bench.py: half of its 1.9 M vertices farther than 0.19 m, the farthest 0.8 m), and a lane
+        # without a list pays the grid search -- lists everywhere: 1.7 GB, 15 ms once per sequence, LBS 0.93 -> 0.31 ms per frame, same bits
+        # (tools/lbs_reach_dense.py).  `lbs_reach_mm` overrides.
+        if lbs_reach_mm is None:
+            lbs_reach_mm = 1000 if getattr(dataset, 'valid_mode', None) == 'dense' else 140
+        self.lbs_reach_mm = int(lbs_reach_mm)
+        if torch.device(config.device).type == 'cuda':
+            _lib.set_option('lbs_reach_mm', self.lbs_reach_mm, config.device)
         smpl_util.set_cano_smpl_vertices(dataset.cano_smpl_v)                 # main.py:335
 
     def _grid_items(self, items: dict):
@@ -140,9 +150,8 @@ class FramePipeline:
             res = {'cano_v': v, 'cano_vn': n, 'f': f, 'occ_volume': vol}
             if skin and v.shape[0] > 0:
                 with _stage('avc/lbs'):
-                    lbs = smpl_util.calculate_lbs(v[None])                       # :385
-                    live_v, mats = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'], True)     # :386
-                    live_n = smpl_util.skinning_normal(n[None], lbs, items['cano2live_jnt_mats'])          # :389 (einsum with vert_mats[:, :3, :3])
+                    # :385 calculate_lbs, :386 skinning(.., True), :389 skinning_normal (einsum with vert_mats[:, :3, :3]) -- one launch, same bits
+                    live_v, live_n, mats, _ = smpl_util.lbs_skinning(v[None], n[None], items['cano2live_jnt_mats'], return_pt_mats=True)
                 res.update({'live_v': live_v[0], 'live_vn': live_n[0], 'vert_mats': mats[0]})
         finally:
             if side_done is not None:
@@ -199,9 +208,8 @@ class FramePipeline:
         v, f, nrm = recon_util.recon_mesh_device(vol, self.vol_res, self.ds.cano_bounds, iso_value=config.iso_value)
         res = {'cano_v': v, 'cano_vn': nrm, 'f': f, 'occ_volume': vol}
         if skin and v.shape[0] > 0:
-            lbs = smpl_util.calculate_lbs(v[None])
-            live_v, mats = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'], True)
-            res.update({'live_v': live_v[0], 'live_vn': smpl_util.skinning_normal(nrm[None], lbs, items['cano2live_jnt_mats'])[0], 'vert_mats': mats[0]})
+            live_v, live_n, mats, _ = smpl_util.lbs_skinning(v[None], nrm[None], items['cano2live_jnt_mats'], return_pt_mats=True)
+            res.update({'live_v': live_v[0], 'live_vn': live_n[0], 'vert_mats': mats[0]})
         return res
 
     @torch.no_grad()
@@ -226,9 +234,8 @@ class FramePipeline:
         res = {'cano_v': v, 'cano_vn': n, 'f': f, 'occ_volume': vol}
         if v.shape[0] > 0:
             with _stage('avc/lbs'):
-                lbs = smpl_util.calculate_lbs(v[None])                       # :451
-                res['live_v'] = smpl_util.skinning(v[None], lbs, items['cano2live_jnt_mats'])[0]       # :452
-                res['live_vn'] = smpl_util.skinning_normal(n[None], lbs, items['cano2live_jnt_mats'])[0]   # :453
+                live_v, live_n, _, _ = smpl_util.lbs_skinning(v[None], n[None], items['cano2live_jnt_mats'])   # :451 calculate_lbs, :452 skinning, :453 skinning_normal
+                res['live_v'], res['live_vn'] = live_v[0], live_n[0]
         return res
 
     @torch.no_grad()

@@ -133,5 +133,34 @@ class SmplUtil:
         """(smpl_util.py:76-81)"""
         return self._skin(None, normals.contiguous(), lbs, cano2live_jnt_mats, False)[1]
 
+    def lbs_skinning(self, points, normals, jnt_mats, return_pt_mats=False, return_lbs=False):
+        """What main.py:385-389 does with a frame's vertices -- `lbs = calculate_lbs(points)`, `skinning(points, lbs, jnt_mats, True)`,
+        `skinning_normal(normals, lbs, jnt_mats)` -- as ONE launch on the bound vertices (avc_lbs_skin_bound): the same operations in the same order, the
+        same bits, without the (B,N,24) weights going through HBM three times.  -> (live_points, live_normals | None, pt_mats | None, lbs | None).
+        Anything the bound form does not serve (CPU tensors, batched vertices) is the three calls."""
+        if self.cano_smpl_vertices is None:
+            raise ValueError('Canonical smpl vertices are invalid!')       # smpl_util.py:30-31
+        v = self.cano_smpl_vertices
+        if not (points.is_cuda and v.device == points.device and v.dim() == 2 and v.shape[0] >= 4 and self.smpl_skinning_weights is not None):
+            lbs = self.calculate_lbs(points)
+            po, mo = self.skinning(points, lbs, jnt_mats, True)
+            no = self.skinning_normal(normals, lbs, jnt_mats) if normals is not None else None
+            return po, no, (mo if return_pt_mats else None), (lbs if return_lbs else None)
+        ctx = self._bind(points.device)
+        B, N, _ = points.shape
+        points = points.contiguous(); jnt_mats = jnt_mats.contiguous()
+        normals = normals.contiguous() if normals is not None else None
+        po = torch.empty_like(points)
+        no = torch.empty_like(normals) if normals is not None else None
+        mo = torch.empty((B, N, 4, 4), dtype=torch.float32, device=points.device) if return_pt_mats else None
+        lbs = torch.empty((B, N, 24), dtype=torch.float32, device=points.device) if return_lbs else None
+        for b in range(B):
+            _lib.check(_lib.lib().avc_lbs_skin_bound(
+                ctx, _lib.dev_ptr(points[b], name='points'), _lib.dev_ptr(normals[b], name='normals') if normals is not None else None, N,
+                _lib.dev_ptr(self.smpl_skinning_weights, name='skin_w'), _lib.dev_ptr(jnt_mats[b], name='jnt_mats'),
+                lbs[b].data_ptr() if lbs is not None else None, po[b].data_ptr(), no[b].data_ptr() if no is not None else None,
+                mo[b].data_ptr() if mo is not None else None, _lib.stream_ptr(points.device)))
+        return po, no, mo, lbs
+
 
 smpl_util = SmplUtil()

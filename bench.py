@@ -536,17 +536,16 @@ def main():
                 v1, n1, jm = out['cano_v'][None], out['cano_vn'][None], my[-1]['cano2live_jnt_mats']
 
                 def lbs_all():
-                    w = smpl_util.calculate_lbs(v1)
-                    smpl_util.skinning(v1, w, jm, True)
-                    smpl_util.skinning_normal(n1, w, jm)
+                    smpl_util.lbs_skinning(v1, n1, jm, return_pt_mats=True)      # what the frame runs (pipeline.avatar_frame)
                 t_lbs = timed(lbs_all)
-                mc_bytes, lbs_bytes = 4 * N + 24 * V + 12 * Fc, V * (12 + 96 + 24 + 12 + 12 + 64) + 83_000
+                # (the fused launch keeps a vertex's 24 blend weights in registers: points + normals in, points + normals + 4x4 out, the skin-weight table)
+                mc_bytes, lbs_bytes = 4 * N + 24 * V + 12 * Fc, V * (12 + 12 + 12 + 12 + 64) + 83_000 + 24 * 4 * 6890
                 def hbm(t, nbytes, **more):
                     return {'bound': 'hbm', 'ms': t * 1e3, 'algorithmic_bytes': nbytes, 'achieved': nbytes / t / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                             'frac': nbytes / t / 8e12, **more}
                 line['roofline_secondary'] = {
                     'marching cubes + normals (mesh.hip, 6 launches, one host wait at the end)': hbm(t_mc, mc_bytes),
-                    'KNN-4 LBS + skinning of points and normals (knn_lbs.hip)': hbm(
+                    'KNN-4 LBS + skinning of points and normals, one launch (knn_lbs.hip: lbs_skin_grid_kernel)': hbm(
                         t_lbs, lbs_bytes, note='the search is VALU-bound (DESIGN.md section 3): the HBM fraction is reported for completeness')}
             except Exception as e:       # informational only
                 line['roofline_secondary'] = {'error': repr(e)}

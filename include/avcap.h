@@ -358,6 +358,14 @@ int avc_skinning(avc_ctx *ctx, const float *pts_dev, const float *nrm_dev, int64
                  const float *lbs_dev, const float *jnt_mats_dev, float *pts_out_dev,
                  float *nrm_out_dev, float *mats_out_dev, avc_stream stream);
 
+/* main.py:385-389 in one launch: lbs = calculate_lbs(v) (smpl_util.py:24-39, against the vertices avc_lbs_prepare bound), live_v / vert_mats = skinning(v, lbs,
+ * jnt_mats, True) (:58-74), live_n = skinning_normal(n, lbs, jnt_mats) (:76-81).  The same operations in the same order as avc_calculate_lbs_bound followed by
+ * avc_skinning -- bit-identical outputs --, but a vertex's 24 blend weights stay in registers: lbs_out_dev (n,24) is written only when it is not NULL (the frame
+ * loop never reads it).  nrm_dev / nrm_out_dev, mats_out_dev (n,4,4), pts_out_dev and lbs_out_dev may be NULL (at least one output must not be).
+ * Before avc_lbs_prepare -> AVC_ERR_STATE as avc_calculate_lbs_bound. */
+int avc_lbs_skin_bound(avc_ctx *ctx, const float *pts_dev, const float *nrm_dev, int64_t n, const float *skin_w_dev, const float *jnt_mats_dev,
+                       float *lbs_out_dev, float *pts_out_dev, float *nrm_out_dev, float *mats_out_dev, avc_stream stream);
+
 /* ---- measurement hook ------------------------------------------------------------------------
  * Average device time (ms, HIP events on the launch stream) of the fused query kernel over the
  * launches since the last reset; used by bench.py for roofline.achieved.  which: 0 avatar, 1 recon. */
@@ -377,7 +385,8 @@ int avc_timing_read_cycles(avc_ctx *ctx, int which, double *avg_cycles_out, int6
  *   "knn_search"   0 (default: per wave) | 1 per-lane grid search | 2 cooperative grid search | 3 exhaustive scan -- all four return the same bits
  *                  (with 1, 2 or 3 avc_calculate_lbs_bound leaves its candidate lists alone and searches that way too)
  *   "lbs_reach_mm" 140 (default) | 0 .. 1000   read by avc_lbs_prepare: cells whose centre lies within this distance of its 4th nearest bound vertex
- *                  get a candidate list (0: no lists, avc_calculate_lbs_bound searches the grid); same bits whatever the value
+ *                  get a candidate list (0: no lists, avc_calculate_lbs_bound searches the grid); same bits whatever the value.  140 covers the valid band
+ *                  (where a frame's surface lies); 1000 covers a whole canonical volume (1.7 GB of lists, 15 ms once per sequence) for meshes that fill it
  *   "fusion_graph" 1 (default: the fusion iterations replay a hipGraph) | 0 plain launches
  *   "enc_graph"    1 (default: avc_hgfilter_forward replays a hipGraph) | 0 plain launches -- same kernels, same bits
  *   "enc_ksplit"   1 (default: a convolution that would run on fewer than half the CUs splits its input channels over several workgroups per

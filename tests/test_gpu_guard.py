@@ -79,6 +79,11 @@ def test_knn_lbs_skinning_stay_inside(nq, nr):
         _lib.check(L.avc_calculate_lbs_bound(ctx, q.ptr, nq, sw.ptr, lbs2.ptr, None))
         _ok(lbs2, q, ref, sw, finite=(lbs2,))
         assert torch.equal(lbs2.t, lbs.t)
+        # the fused launch (round 6: avc_lbs_skin_bound): the same four outputs, nothing written elsewhere
+        lbs3, po3, no3, mo3 = Guarded(nq * 24), Guarded(nq * 3), Guarded(nq * 3), Guarded(nq * 16)
+        _lib.check(L.avc_lbs_skin_bound(ctx, q.ptr, q.ptr, nq, sw.ptr, jm.ptr, lbs3.ptr, po3.ptr, no3.ptr, mo3.ptr, None))
+        _ok(lbs3, po3, no3, mo3, q, ref, sw, jm, finite=(lbs3, po3, no3, mo3))
+        assert torch.equal(lbs3.t, lbs.t) and torch.equal(po3.t, po.t) and torch.equal(no3.t, no.t) and torch.equal(mo3.t, mo.t)
 
 
 @pytest.mark.parametrize('N', [1, 1023, 1024, 1025, 70001])

@@ -248,6 +248,50 @@ def test_bound_lbs_equals_the_exhaustive_scan(body):
     assert not torch.equal(moved, want) and torch.equal(moved, su._lbs(_t(q[None]), su.cano_smpl_vertices))
 
 
+def test_fused_lbs_skinning_equals_the_three_calls(body):
+    """avc_lbs_skin_bound (round 6): calculate_lbs + skinning + skinning_normal of main.py:385-389 in one launch.  The same operations in the same order, so every
+    output must equal the three calls' bit for bit: on and around the body (candidate lists), far and outside points (grid search), the exhaustive scan and the
+    forced search paths, a ragged count, without normals / matrices, with the weights handed out; and whatever the reach of the lists (a dense dataset binds with
+    1000 mm, FramePipeline.__init__)."""
+    from avatarcap_amd.utils.smpl_util import SmplUtil
+    from avatarcap_amd.grid import generate_volume_points_np
+    rs = np.random.RandomState(12)
+    ref = body['cano_smpl_v'].copy()
+    surf = gi.surface_points(4321, 4000, body)
+    q = np.concatenate([surf, surf + 0.05 * rs.randn(*surf.shape).astype(np.float32), ref[:1000], rs.uniform(-3, 3, (2000, 3)).astype(np.float32),
+                        np.full((3, 3), 50.0, np.float32), generate_volume_points_np(syn.CANO_BOUNDS, (20, 20, 10))]).astype(np.float32)[:12345]
+    nrm = gi.unit_vectors(107, q.shape[0])
+    jm = _t(syn.random_pose_jnt_mats(gi.SEED_POSE)[None])
+    tq, tn = _t(q[None]), _t(nrm[None])
+    su = SmplUtil(body['skin_weights'])
+    try:
+        for reach in (140, 0, 1000):
+            _lib.set_option('lbs_reach_mm', reach)
+            su.set_cano_smpl_vertices(_t(ref))
+            for search in (0, 1, 2, 3):
+                _lib.set_option('knn_search', search)
+                lbs = su.calculate_lbs(tq)
+                live, mats = su.skinning(tq, lbs, jm, True)
+                ln = su.skinning_normal(tn, lbs, jm)
+                po, no, mo, lo = su.lbs_skinning(tq, tn, jm, return_pt_mats=True, return_lbs=True)
+                assert torch.equal(po, live) and torch.equal(no, ln) and torch.equal(mo, mats) and torch.equal(lo, lbs), (reach, search)
+            _lib.set_option('knn_search', 0)
+            po2, no2, mo2, lo2 = su.lbs_skinning(tq, None, jm)                # points only, nothing else written
+            assert no2 is None and mo2 is None and lo2 is None and torch.equal(po2, live)
+            if reach == 140:
+                want_lbs = lbs
+            else:
+                assert torch.equal(lbs, want_lbs), reach                      # same bits whatever the reach
+        assert float(lo[0, :4000].sum(1).min()) > 0.99
+        # an empty mesh
+        e = torch.zeros((1, 0, 3), device='cuda')
+        po, no, mo, _ = su.lbs_skinning(e, e, jm, return_pt_mats=True)
+        assert po.shape == (1, 0, 3) and no.shape == (1, 0, 3) and mo.shape == (1, 0, 4, 4)
+    finally:
+        _lib.set_option('knn_search', 0)
+        _lib.set_option('lbs_reach_mm', 140)
+
+
 def test_scatter_volume():
     from avatarcap_amd import _lib
     N = 100003
