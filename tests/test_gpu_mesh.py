@@ -58,6 +58,23 @@ def test_recon_mesh_matches_oracle(res, kind, iso):
         assert maxabs(n, on) < 1e-4
 
 
+def test_recon_mesh_fuzz_matches_oracle(monkeypatch):
+    """tests/tools/mc_fuzz_gpu.py, 250 cases: random thin / long / odd grid shapes around every tile edge, random iso values, noise, smooth fields, sparse volumes and
+    volumes of small integers / half-integers (every test of the case analysis ties, samples equal the iso value); vertices bit for bit, faces, numbering, and the same
+    exception type where the library raises.  (The round's campaign: 6,400 cases, 77 M vertices, no mismatch.)"""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location('mc_fuzz_gpu', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'mc_fuzz_gpu.py'))
+    mod = importlib.util.module_from_spec(spec)
+    dev, cfg = config.device, config.cfg
+    try:
+        spec.loader.exec_module(mod)
+        monkeypatch.setattr(sys, 'argv', ['mc_fuzz_gpu.py', '250', '77'])
+        assert mod.main() == 0
+    finally:
+        config.device, config.cfg = dev, cfg
+
+
 _MC_GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mc_golden.npz'))
 
 
