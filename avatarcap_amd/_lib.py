@@ -156,6 +156,9 @@ def ctx(device=None) -> int:
         h = C.c_void_p()
         check(lib().avc_ctx_create(int(device), C.byref(h)))
         _ctxs[device] = h.value
+        for kv in filter(None, os.environ.get('AVC_OPTIONS', '').split(',')):       # e.g. AVC_OPTIONS=enc_graph=0,enc_fork=0: avc_set_option on every new context (bisecting aid)
+            k, _, v = kv.partition('=')
+            check(lib().avc_set_option(h.value, k.strip().encode(), int(v)))
     return _ctxs[device]
 
 

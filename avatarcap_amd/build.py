@@ -15,12 +15,18 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libavcap_hip.so')
 SOURCES = ['fused_mlp.hip', 'conv_enc.hip', 'misc.hip', 'mesh.hip', 'raster.hip', 'fusion.hip', 'knn_lbs.hip', 'render.hip', 'pack.cpp', 'capi.cpp']
-HEADERS = ['avcap_internal.h', 'mlp_layout.h', 'mc_tables.h', os.path.join('..', '..', 'include', 'avcap.h')]
+HEADERS = ['avcap_internal.h', 'mlp_layout.h', 'mc_tables.h', 'store_settle.h', os.path.join('..', '..', 'include', 'avcap.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
+# gfx950 / ROCm 7.2: a VGPR written by a packed-f32 VALU instruction and read as the data of a multi-dword store an instruction later reached memory stale in
+# the wave's last 16 lanes when another kernel shared the CU (csrc/store_settle.h, profiles/r06_store_hazard.md).  hipcc forms those instructions by itself
+# (SLP-packing of adjacent scalar f32 operations); the element-wise translation units are built without them -- same IEEE operations, one per instruction --,
+# the two MFMA units (fused_mlp.hip: no packed producer near any wide store; conv_enc.hip: its element-wise kernels settle() their stores) keep their code.
+NOPK = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 # mesh / KNN kernels promise bit-exact agreement with the C oracle (built with -ffp-contract=off):
 # HIP's __fmul_rn/__fadd_rn are plain operators, so contraction has to be disabled per file.
-EXTRA = {'mesh.hip': ['-ffp-contract=off'], 'knn_lbs.hip': ['-ffp-contract=off'], 'raster.hip': ['-ffp-contract=off'], 'render.hip': ['-ffp-contract=off'],
+EXTRA = {'mesh.hip': ['-ffp-contract=off'] + NOPK, 'knn_lbs.hip': ['-ffp-contract=off'] + NOPK, 'raster.hip': ['-ffp-contract=off'] + NOPK, 'render.hip': ['-ffp-contract=off'] + NOPK,
+         'misc.hip': NOPK, 'fusion.hip': NOPK,
          # MFMA accumulators in VGPRs: the epilogue reads them without a v_accvgpr_read per value (-0.7 % launch time, tools/ablate_run.sh)
          'fused_mlp.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 

@@ -24,6 +24,7 @@
 //     double, into (mean, rstd) per group: deterministic, no atomics of any kind, no extra launch, nothing left to wait for at a launch's end.
 //   * avg_pool2d and bicubic-upsample + add are two small HBM-bound kernels that also leave statistics behind.
 //   * the whole encoder (~65 launches) is recorded once per input size as a hipGraph and replayed per frame.
+#include "store_settle.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -702,7 +703,8 @@ __device__ __forceinline__ void elt_body(const EltArgs &p, F &&value)
     float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     for (int pix = pix0 + sub; pix < pix1; pix += nsub) {
         const int oy = pix / p.W, ox = pix - oy * p.W;
-        const f32x4 v = value(oy, ox, c4);
+        f32x4 v = value(oy, ox, c4);
+        settle(v);                                       // store_settle.h: packed-f32 results as store data
         *reinterpret_cast<f32x4 *>(p.out + (size_t)pix * p.C + 4 * c4) = v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
@@ -827,7 +829,8 @@ __global__ __launch_bounds__(256) void upadd_tiled_kernel(const UpTiledArgs a)
             const f32x4 r = v0 * cx[0] + v1 * cx[1] + v2 * cx[2] + v3 * cx[3];
             acc = m == 0 ? r * cy[0] : acc + r * cy[m];
         }
-        const f32x4 v = up[i] + acc;
+        f32x4 v = up[i] + acc;
+        settle(v);
         *reinterpret_cast<f32x4 *>(p.out + ((size_t)oy * p.W + ox) * p.C + c0 + quad * 4) = v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
@@ -904,7 +907,9 @@ __global__ __launch_bounds__(256) void up2_kernel(const Up2Args p)
     };
     const f32x4 v00 = at(y0, x0), v01 = at(y0, x1), v10 = at(y1, x0), v11 = at(y1, x1);
     const float w00 = (1.0f - ly) * (1.0f - lx), w01 = (1.0f - ly) * lx, w10 = ly * (1.0f - lx), w11 = ly * lx;
-    *reinterpret_cast<f32x4 *>(p.out + pix * p.C + 4 * c4) = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+    f32x4 vo = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+    settle(vo);
+    *reinterpret_cast<f32x4 *>(p.out + pix * p.C + 4 * c4) = vo;
 }
 
 // =====================================================================================================================

@@ -14,6 +14,7 @@
 //   calculate_lbs  : KNN-4 + Gaussian weights + gather/blend of the 24-wide skin weights (:24-39), fused
 //   skinning       : per-point blend of the 24 joint 4x4s and its application to points / normals (:58-81)
 // All HBM/VALU-bound elementwise work; queries are read once, coalesced.
+#include "store_settle.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -488,17 +489,23 @@ __global__ __launch_bounds__(256) void skinning_kernel(const float *__restrict__
     if (mo) {
         float4 *o = reinterpret_cast<float4 *>(mo + (size_t)i * 16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = make_float4(M[4 * r], M[4 * r + 1], M[4 * r + 2], M[4 * r + 3]);
+        for (int r = 0; r < 4; ++r) { settle(M[4 * r], M[4 * r + 1], M[4 * r + 2], M[4 * r + 3]); o[r] = make_float4(M[4 * r], M[4 * r + 1], M[4 * r + 2], M[4 * r + 3]); }
     }
     if (pts) {   // live = M[:3,:3] p + M[:3,3]   (smpl_util.py:69)
         const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        float o[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) po[3 * i + r] = M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z + M[4 * r + 3];
+        for (int r = 0; r < 3; ++r) o[r] = M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z + M[4 * r + 3];
+        settle(o[0], o[1], o[2]);                // store_settle.h
+        po[3 * i] = o[0]; po[3 * i + 1] = o[1]; po[3 * i + 2] = o[2];
     }
     if (nrm) {   // live_normals = M[:3,:3] n, no renormalisation   (smpl_util.py:80)
         const float x = nrm[3 * i], y = nrm[3 * i + 1], z = nrm[3 * i + 2];
+        float o[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) no[3 * i + r] = M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z;
+        for (int r = 0; r < 3; ++r) o[r] = M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z;
+        settle(o[0], o[1], o[2]);
+        no[3 * i] = o[0]; no[3 * i + 1] = o[1]; no[3 * i + 2] = o[2];
     }
 }
 
@@ -549,23 +556,30 @@ __device__ __forceinline__ void lbs_skin_body(const float *__restrict__ pts, con
     if (mo) {
         float4 *o = reinterpret_cast<float4 *>(mo + (size_t)i * 16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = make_float4(M[4 * r], M[4 * r + 1], M[4 * r + 2], M[4 * r + 3]);
+        for (int r = 0; r < 4; ++r) { settle(M[4 * r], M[4 * r + 1], M[4 * r + 2], M[4 * r + 3]); o[r] = make_float4(M[4 * r], M[4 * r + 1], M[4 * r + 2], M[4 * r + 3]); }
     }
     if (po) {                                                         // (the point is read again rather than kept alive across the search)
         const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        float o[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) po[3 * i + r] = M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z + M[4 * r + 3];
+        for (int r = 0; r < 3; ++r) o[r] = M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z + M[4 * r + 3];
+        settle(o[0], o[1], o[2]);                                     // store_settle.h
+        po[3 * i] = o[0]; po[3 * i + 1] = o[1]; po[3 * i + 2] = o[2];
     }
     if (nrm) {
         const float x = nrm[3 * i], y = nrm[3 * i + 1], z = nrm[3 * i + 2];
+        float o[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) no[3 * i + r] = M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z;
+        for (int r = 0; r < 3; ++r) o[r] = M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z;
+        settle(o[0], o[1], o[2]);
+        no[3 * i] = o[0]; no[3 * i + 1] = o[1]; no[3 * i + 2] = o[2];
     }
 }
-// The search is a chain of dependent loads: it lives on waves in flight.  lbs_kernel fits 70 registers (seven waves per SIMD); the fused body's tail -- 24 blend
-// weights, 16 matrix sums, the skin-weight rows in flight -- would set the whole kernel's budget at 94 (five waves: 466 us against lbs_kernel's 319 on the dense frame's
-// 1.9 M vertices), so the grid form is held to seven waves (71 registers, three dwords spilled once in the tail: 311 us).  The exhaustive form is bound by its LDS tile.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void lbs_skin_grid_kernel(
+// The search is a chain of dependent loads: it lives on waves in flight.  lbs_kernel fits 76 registers (six waves per SIMD); the fused body's tail -- 24 blend
+// weights, 16 matrix sums, the skin-weight rows in flight -- would set the whole kernel's budget at 94 - 142 (3 - 5 waves: the search ran 1.5x slower than
+// lbs_kernel's on the dense frame's 1.9 M vertices), so the grid form is held to six waves (80 registers, four dwords spilled once in the tail).  The exhaustive
+// form is bound by its LDS tile.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void lbs_skin_grid_kernel(
     const float *__restrict__ pts, const float *__restrict__ nrm, int64_t n, const float *__restrict__ cano_v, const float *__restrict__ skin_w, int nv, GridView g, CandView cv,
     const float *__restrict__ jm, float *__restrict__ lbs, float *__restrict__ po, float *__restrict__ no, float *__restrict__ mo)
 {

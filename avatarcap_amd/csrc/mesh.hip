@@ -32,6 +32,7 @@
 // HBM-bound: the volume is read once (A1) + 3 B per cell of the crossed tiles + 24 B/vertex + 12 B/face written.
 // The 18 KB of look-up tables live in LDS.  Face / interior tests and the interpolation run in fp64 exactly as
 // the library's C code does (translation unit built with -ffp-contract=off).
+#include "store_settle.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -781,10 +782,12 @@ __global__ __launch_bounds__(256) void mc_eval_kernel(McArgs a, EmitArgs e, cons
 #pragma unroll
         for (int c = 0; c < 3; ++c)     // vertices = mc * voxel + b0 + 0.5 * voxel   (library: * spacing; recon_util.py:65), float32
             out[c] = __fadd_rn(__fadd_rn(__fmul_rn(vidx[c], e.vox[c]), e.b0[c]), __fmul_rn(0.5f, e.vox[c]));
+        settle(out[0], out[1], out[2]);                                      // store_settle.h
         verts[3 * id + 0] = out[0]; verts[3 * id + 1] = out[1]; verts[3 * id + 2] = out[2];
         if (normals) {
             float n[3];
             vertex_normal(a, e, vidx, n);
+            settle(n[0], n[1], n[2]);
             normals[3 * id + 0] = n[0]; normals[3 * id + 1] = n[1]; normals[3 * id + 2] = n[2];
         }
     }

@@ -141,7 +141,9 @@ class SmplUtil:
         if self.cano_smpl_vertices is None:
             raise ValueError('Canonical smpl vertices are invalid!')       # smpl_util.py:30-31
         v = self.cano_smpl_vertices
-        if not (points.is_cuda and v.device == points.device and v.dim() == 2 and v.shape[0] >= 4 and self.smpl_skinning_weights is not None):
+        import os
+        if os.environ.get('AVC_LBS_FUSED', '1') == '0' or not (     # AVC_LBS_FUSED=0: the three calls (A/B aid)
+            points.is_cuda and v.device == points.device and v.dim() == 2 and v.shape[0] >= 4 and self.smpl_skinning_weights is not None):
             lbs = self.calculate_lbs(points)
             po, mo = self.skinning(points, lbs, jnt_mats, True)
             no = self.skinning_normal(normals, lbs, jnt_mats) if normals is not None else None

@@ -1,5 +1,7 @@
 """End-to-end GPU parity of the frame pipeline and of the colour path,
 through the host mirror + C-ABI, against the reference goldens and the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -491,3 +493,15 @@ def test_mesh_exchange_on_rccl_side_stream_single_rank():
         assert len(bad) == 1 and bad[0].startswith('frame 2')
     finally:
         dist.destroy_process_group()
+
+
+def test_kernels_beside_the_lookahead_unet_keep_their_bits():
+    """tools/race_probe.py: marching cubes + normals and LBS + skinning on the main stream while the U-Net runs on a side stream (what
+    FramePipeline.avatar_frame does with the next frame's pose map).  Round 6 met 1 corrupted output in 6 here -- the x component of 16 consecutive vertices,
+    the last 16 lanes of a wave: a packed-f32 result read as store data an instruction later (csrc/store_settle.h) -- which the --sync-io loop of main.py
+    showed as files that differed from run to run.  Every output of 300 x 3 victim passes must equal the quiet run's bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'race_probe.py'), 'unet', '300'], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and ' 0 corrupted victim outputs' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
