@@ -56,7 +56,9 @@ def aggressor():
     return None
 
 
-ref = victim(); aggressor(); torch.cuda.synchronize()
+ref = victim(); aref = aggressor(); torch.cuda.synchronize()
+aref = aref.clone() if isinstance(aref, torch.Tensor) else (aref[-1].clone() if isinstance(aref, (list, tuple)) and len(aref) and isinstance(aref[-1], torch.Tensor) else None)
+abad = 0
 side = torch.cuda.Stream(dev)
 bad, t0 = 0, time.time()
 for it in range(iters):
@@ -64,10 +66,16 @@ for it in range(iters):
     if which != 'none':
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            aggressor()
+            aout = aggressor()
     outs = [victim() for _ in range(3)]
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize()
+    if which != 'none' and aref is not None:          # the aggressor is a victim too: its own output beside the main stream's kernels
+        ao = aout if isinstance(aout, torch.Tensor) else aout[-1]
+        if not torch.equal(ao, aref):
+            abad += 1
+            if abad <= 3:
+                print(f'iteration {it}: the {which} output differs from its quiet run in {int((ao != aref).sum())} values')
     for o in outs:
         for name, a, b in zip(('v', 'n', 'po', 'no', 'mo'), o, ref):
             if not torch.equal(a, b):
@@ -83,5 +91,5 @@ for it in range(iters):
                         print(f'    row {r_}: got x {a2[r_, 0].item():+.7f} want {b2[r_, 0].item():+.7f}; rows of the reference with that x: {same[:4]}; anywhere (row, col): {same_any}')
                 if bad <= 6:
                     print(f'iteration {it}: {name} differs in rows {rows[0].item()}..{rows[-1].item()} ({rows.numel()} rows; first row mod 64 = {rows[0].item() % 64}), columns {cols.tolist()}')
-print(f'aggressor {which} {sys.argv[3:]}: {bad} corrupted victim outputs in {iters} iterations x 3 ({time.time() - t0:.1f} s)')
-raise SystemExit(1 if bad else 0)
+print(f'aggressor {which} {sys.argv[3:]}: {bad} corrupted victim outputs in {iters} iterations x 3, {abad} corrupted aggressor outputs ({time.time() - t0:.1f} s)')
+raise SystemExit(1 if (bad or abad) else 0)
