@@ -549,6 +549,20 @@ def main():
                         t_lbs, lbs_bytes, note='the search is VALU-bound (DESIGN.md section 3): the HBM fraction is reported for completeness')}
             except Exception as e:       # informational only
                 line['roofline_secondary'] = {'error': repr(e)}
+            # ---- outside the timed region: the frame reproduces itself.  The timed loop runs the next frame's U-Net on a side stream beside this frame's
+            # marching cubes / LBS; round 6 found kernels that were bitwise deterministic alone and not beside it (profiles/r06_store_hazard.md).  One
+            # frame with the look-ahead running beside its tail against the same frame alone, every mesh tensor bit for bit.
+            try:
+                if len(my) >= 2:
+                    pipe._next_map = None
+                    busy = pipe.avatar_frame(my[0], next_items=my[1])
+                    torch.cuda.synchronize()
+                    pipe._next_map = None
+                    quiet = pipe.avatar_frame(my[0])
+                    torch.cuda.synchronize()
+                    line['frame_reproduced'] = all(torch.equal(busy[k_], quiet[k_]) for k_ in ('cano_v', 'cano_vn', 'f', 'live_v', 'live_vn', 'vert_mats'))
+            except Exception as e:       # informational only
+                line['frame_reproduced'] = repr(e)
         if world == 1 and not args.no_masked:
             try:
                 line['masked'] = masked_run(res, device, K, W)
