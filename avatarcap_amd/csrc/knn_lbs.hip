@@ -361,6 +361,7 @@ struct GridView { const GridHdr *hdr; const int *start; const float4 *sorted; in
 // knn_lane_ring1 (round 4: 317 us for the 190 k vertices of a band frame, three waves per SIMD waiting on memory).  Cells farther than the reach (avc_set_option "lbs_reach_mm", 140 by default) from
 // every vertex, and points outside the cells' box, have no list: their lanes go on with the grid search.
 struct CandView { const int *cstart; const float4 *cand; float ox, oy, oz, inv_h; int nx, ny, nz; };      // cstart == nullptr: no lists
+constexpr long long LIST_MAX_ENTRIES = 1ll << 28;             // 4 GiB of candidates: beyond it avc_lbs_prepare builds no lists (a body's 6890 vertices with lists over a whole volume: 1e8)
 constexpr float LIST_CELL = 0.02f, LIST_MARGIN = 0.16f;       // (the reach -- how far from the vertices cells still get a list -- is Options::lbs_reach_mm)
 
 template <int K>
@@ -667,24 +668,29 @@ __global__ __launch_bounds__(256) void cand_list_kernel(CandGrid cg, const float
     if (!FILL && c < ncell) count[c] = n;
 }
 
-// exclusive scan of count[0 .. n) in place into cstart[0 .. n] (one workgroup; once per sequence)
+// exclusive scan of count[0 .. n) in place into cstart[0 .. n] (one workgroup; once per sequence).  The sums are 64-bit: a[n + 2], a[n + 3] hold the exact total
+// (low, high word) whatever happens to the 32-bit offsets -- a degenerate vertex set (thousands of coincident points) lists every vertex in every cell, and
+// avc_lbs_prepare then does without lists instead of asking for the memory.
 __global__ __launch_bounds__(1024) void cand_scan_kernel(int *__restrict__ a, int n)
 {
-    __shared__ int part[1024];
+    __shared__ long long part[1024];
     const int per = (n + 1023) / 1024, lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
-    int sum = 0;
+    long long sum = 0;
     for (int i = lo; i < hi; ++i) sum += a[i];
     part[threadIdx.x] = sum;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
-        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        const long long v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
         __syncthreads();
         part[threadIdx.x] += v;
         __syncthreads();
     }
-    int run = part[threadIdx.x] - sum;
-    for (int i = lo; i < hi; ++i) { const int v = a[i]; a[i] = run; run += v; }
-    if (threadIdx.x == 1023) a[n] = part[1023];
+    long long run = part[threadIdx.x] - sum;
+    for (int i = lo; i < hi; ++i) { const int v = a[i]; a[i] = (int)run; run += v; }
+    if (threadIdx.x == 1023) {
+        const long long total = part[1023];
+        a[n] = (int)total; a[n + 2] = (int)(total & 0xffffffffll); a[n + 3] = (int)(total >> 32);
+    }
 }
 
 }  // namespace
@@ -829,10 +835,16 @@ int lbs_prepare(avc_ctx *ctx, const float *cano_v, int32_t nv, hipStream_t s)
     hipLaunchKernelGGL(cand_radius_kernel<4>, blocks, threads, 0, s, cg, b->ref, nv, b->grid, reach, radius);
     hipLaunchKernelGGL(cand_list_kernel<false>, blocks, threads, 0, s, cg, b->ref, nv, radius, cstart, (const int *)nullptr, (float4 *)nullptr);
     hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(1024), 0, s, cstart, ncell);
-    int total = 0;
-    AVC_HIP(hipMemcpyAsync(&total, cstart + ncell, sizeof(int), hipMemcpyDeviceToHost, s));
+    int tail[4] = {0, 0, 0, 0};
+    AVC_HIP(hipMemcpyAsync(tail, cstart + ncell, sizeof tail, hipMemcpyDeviceToHost, s));
     AVC_HIP(hipStreamSynchronize(s));
     AVC_HIP(hipGetLastError());
+    const long long total64 = (long long)(unsigned)tail[2] | ((long long)tail[3] << 32);
+    if (total64 > LIST_MAX_ENTRIES) {                     // a degenerate vertex set: every cell would list (nearly) every vertex -- the search serves, same results
+        b->ncand = 0; b->ncell = ncell;
+        return AVC_OK;
+    }
+    const int total = (int)total64;
     if (b->cand_cap < (size_t)total + 8) {
         if (b->cand) AVC_HIP(hipFree(b->cand));
         b->cand = nullptr; b->cand_cap = 0;

@@ -345,7 +345,8 @@ int avc_calculate_lbs(avc_ctx *ctx, const float *pts_dev, int64_t n, const float
  * |v - centre| <= d_4(centre) + cell diagonal).  avc_calculate_lbs_bound then reads one list per point instead of searching: bit-identical to
  * avc_calculate_lbs on the same vertices (same squared distances, same (distance, index) order; points without a list -- farther than that from the body,
  * outside the cells' box -- take the grid search), and without the per-call grid construction.  Host-synchronous (sizes its tables); a second call replaces
- * the first.  avc_calculate_lbs_bound before avc_lbs_prepare -> AVC_ERR_STATE ("Canonical smpl vertices are invalid!", smpl_util.py:31).
+ * the first.  A vertex set whose lists would exceed 2^28 entries (thousands of coincident vertices: every cell lists every vertex) gets none: the search serves.
+ * avc_calculate_lbs_bound before avc_lbs_prepare -> AVC_ERR_STATE ("Canonical smpl vertices are invalid!", smpl_util.py:31).
  * avc_lbs_bound_stats: out = {vertices bound, cells, list entries, 1 if lists exist}. */
 int avc_lbs_prepare(avc_ctx *ctx, const float *cano_v_dev, int32_t nv, avc_stream stream);
 int avc_calculate_lbs_bound(avc_ctx *ctx, const float *pts_dev, int64_t n, const float *skin_w_dev, float *lbs_out_dev, avc_stream stream);
