@@ -244,3 +244,23 @@ def test_hip_rasterisers_match_opengl():
     v, f, mv, fx, fy, cx, cy, W, H = sc.position_scene()
     pos = render_mesh_device(t(v), None, t(f), gl_perspective_projection_matrix(fx, fy, cx, cy, W, H) @ mv, W, H)
     _check_against_gl(pos.cpu().numpy(), _GL['position_mask'], _GL['position_lattice'], 3, 'position (HIP)')
+
+
+@pytest.mark.gpu
+def test_hip_rasterisers_fuzz_against_the_oracle(monkeypatch):
+    """tests/tools/raster_fuzz_gpu.py, 120 cases: random triangle soups (blobs, image-wide triangles, slivers, lattice vertices with edges through pixel centres and
+    coincident depths, zero-area and repeated triangles, shared vertices), random image sizes and pinhole cameras including ones inside the soup; the canonical front /
+    back views and the MVP view with and without attributes, every pixel bit for bit.  (The round's campaign: 1,200 cases, 56 M pixels, no mismatch.)"""
+    import importlib.util
+    import sys
+    import torch
+    from avatarcap_amd import config
+    spec = importlib.util.spec_from_file_location('raster_fuzz_gpu', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'raster_fuzz_gpu.py'))
+    mod = importlib.util.module_from_spec(spec)
+    dev, cfg = config.device, config.cfg
+    try:
+        spec.loader.exec_module(mod)
+        monkeypatch.setattr(sys, 'argv', ['raster_fuzz_gpu.py', '120', '3'])
+        assert mod.main() == 0
+    finally:
+        config.device, config.cfg = dev, cfg
