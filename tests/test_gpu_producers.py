@@ -189,6 +189,16 @@ def test_hgfilter_launch_by_launch(res):
     print(f'HGFilter {res}^2, HIP encoder vs stock torch ops launch by launch: worst {worst:.3e} (relative to max(1, |ref|max))')
 
 
+@pytest.mark.parametrize('hw', [(96, 160), (32, 224), (160, 96)])
+def test_hgfilter_launch_by_launch_on_other_image_shapes(hw):
+    """Non-square and narrow images (tools/enc_shapes_probe.py also ran 64 x 128 .. 480 x 512: worst launch 2.8e-6): the plan's tilings, halos and statistics
+    tables are sized per launch shape."""
+    hg = _hg()
+    x = _t(np.random.RandomState(sum(hw)).randn(1, 6, *hw).astype(np.float32))
+    worst = _walk_plan(hg, x)
+    print(f'HGFilter {hw[0]} x {hw[1]}, HIP encoder vs stock torch ops launch by launch: worst {worst:.3e}')
+
+
 def test_hgfilter_matches_reference(golden):
     """HGFilter.forward on the HIP encoder against goldens of the reference's own module on the CPU (64^2 and the real 512^2 input)."""
     hg = _hg()
