@@ -26,6 +26,7 @@
 //   * the whole encoder (~65 launches) is recorded once per input size as a hipGraph and replayed per frame.
 #include "store_settle.h"
 #include <hip/hip_runtime.h>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -1026,32 +1027,54 @@ static int pack_conv(Encoder *e, const avc_conv2d &c, int taps_expected, DevConv
     if (m > 0.0) { int ex; std::frexp(m, &ex); sw = 10 - ex; }      // largest |w| 2^sw in [2^9, 2^10): the lo halves stay normal fp16 numbers
     sw = std::max(-40, std::min(40, sw));
     d.wscale_inv = (float)std::ldexp(1.0, -sw);
-    // one stream per CT in {1, 2, 4} that divides the tile count: [CT == 1 | CT == 2 | CT == 4] back to back
+    // one stream per CT in {1, 2, 4} that divides the tile count: [CT == 1 | CT == 2 | CT == 4] back to back.  Every 2 KiB unit [hi | lo] is a function of its
+    // index alone: the units are filled by a few host threads (the U-Net's 10 M weights in three slice widths took 0.57 s of the first frame on one).
     const int ntile = c.cout / 32;
-    std::vector<uint8_t> stream;
+    const size_t units_per_ct = (size_t)ntile * nchunk * taps * 2;       // the same for every CT that divides ntile
     unsigned off[3] = {0, 0, 0};
+    size_t total = 0;
     for (int v = 0; v < 3; ++v) {
         const int CT = 1 << v;
-        off[v] = (unsigned)stream.size();
+        off[v] = (unsigned)total;
         if (ntile % CT || !(ct_mask & CT)) continue;
         d.ct_mask |= CT;
-        for (int slice = 0; slice < ntile / CT; ++slice)
-            for (int ch = 0; ch < nchunk; ++ch)
-                for (int t = 0; t < taps; ++t)
-                    for (int kk = 0; kk < 2; ++kk)
-                        for (int tl = 0; tl < CT; ++tl) {
-                            const size_t base = stream.size();
-                            stream.resize(base + 2048);
-                            _Float16 *hi = reinterpret_cast<_Float16 *>(stream.data() + base), *lo = hi + 512;
-                            for (int lane = 0; lane < 64; ++lane)
-                                for (int el = 0; el < 8; ++el) {
-                                    const int co = 32 * (slice * CT + tl) + (lane & 31), ci = 32 * ch + 16 * kk + 8 * (lane >> 5) + el;
-                                    const float w = std::ldexp(c.w[((size_t)co * c.cin + ci) * taps + t], sw);
-                                    const _Float16 hh = (_Float16)w;
-                                    hi[lane * 8 + el] = hh;
-                                    lo[lane * 8 + el] = (_Float16)(w - (float)hh);
-                                }
-                        }
+        total += units_per_ct * 2048;
+    }
+    AVC_REQUIRE(total < (1ull << 32), AVC_ERR_ARG, "avc_hgfilter_pack: %s: a weight stream of %zu bytes", name, total);
+    std::vector<uint8_t> stream(total);
+    const float scale = std::ldexp(1.0f, sw);                            // a power of two: w * scale is exact (|w| 2^sw < 2^10)
+    auto fill = [&](int v, size_t u0, size_t u1) {
+        const int CT = 1 << v;
+        for (size_t u = u0; u < u1; ++u) {
+            // u = ((((slice * nchunk + ch) * taps + t) * 2 + kk) * CT + tl
+            size_t r = u;
+            const int tl = (int)(r % CT); r /= CT;
+            const int kk = (int)(r % 2); r /= 2;
+            const int t = (int)(r % taps); r /= taps;
+            const int ch = (int)(r % nchunk); r /= nchunk;
+            const int slice = (int)r;
+            _Float16 *hi = reinterpret_cast<_Float16 *>(stream.data() + off[v] + u * 2048), *lo = hi + 512;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int el = 0; el < 8; ++el) {
+                    const int co = 32 * (slice * CT + tl) + (lane & 31), ci = 32 * ch + 16 * kk + 8 * (lane >> 5) + el;
+                    const float w = c.w[((size_t)co * c.cin + ci) * taps + t] * scale;
+                    const _Float16 hh = (_Float16)w;
+                    hi[lane * 8 + el] = hh;
+                    lo[lane * 8 + el] = (_Float16)(w - (float)hh);
+                }
+        }
+    };
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nthr = (int)std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 4), (size_t)16, units_per_ct / 64 + 1}));
+        for (int v = 0; v < 3; ++v) {
+            if (!(d.ct_mask & (1 << v))) continue;
+            if (nthr == 1) { fill(v, 0, units_per_ct); continue; }
+            std::vector<std::thread> pool;
+            for (int k = 0; k < nthr; ++k)
+                pool.emplace_back(fill, v, units_per_ct * k / nthr, units_per_ct * (k + 1) / nthr);
+            for (auto &th : pool) th.join();
+        }
     }
     d.wbytes = (unsigned)stream.size();
     uint8_t *dev = nullptr;
