@@ -28,7 +28,8 @@ NOPK = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 EXTRA = {'mesh.hip': ['-ffp-contract=off'] + NOPK, 'knn_lbs.hip': ['-ffp-contract=off'] + NOPK, 'raster.hip': ['-ffp-contract=off'] + NOPK, 'render.hip': ['-ffp-contract=off'] + NOPK,
          'misc.hip': NOPK, 'fusion.hip': NOPK,
          # MFMA accumulators in VGPRs: the epilogue reads them without a v_accvgpr_read per value (-0.7 % launch time, tools/ablate_run.sh)
-         'fused_mlp.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
+         # (fused_mlp.hip without packed f32 as well: hipcc's SLP-packed v_pk_*_f32 cost issue time beside the MFMAs -- same-box A/B of the dense launch -1.0 % shader cycles)
+         'fused_mlp.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'] + NOPK}
 
 
 ASAN_PLAIN = {'fused_mlp.hip'}      # translation units left uninstrumented in the --asan flavour (see build())
