@@ -29,7 +29,9 @@ EXTRA = {'mesh.hip': ['-ffp-contract=off'] + NOPK, 'knn_lbs.hip': ['-ffp-contrac
          'misc.hip': NOPK, 'fusion.hip': NOPK,
          # MFMA accumulators in VGPRs: the epilogue reads them without a v_accvgpr_read per value (-0.7 % launch time, tools/ablate_run.sh)
          # (fused_mlp.hip without packed f32 as well: hipcc's SLP-packed v_pk_*_f32 cost issue time beside the MFMAs -- same-box A/B of the dense launch -1.0 % shader cycles)
-         'fused_mlp.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'] + NOPK}
+         # -amdgpu-sched-strategy=max-ilp: what the scheduler does with the code between the pinned pieces; same bits, -1.1 % shader cycles per dense launch (tools/ab_flags.sh;
+         # max-memory-clause -0.4 %, no post-RA scheduler +2 %, -O2 the same)
+         'fused_mlp.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form', '-mllvm', '-amdgpu-sched-strategy=max-ilp'] + NOPK}
 
 
 ASAN_PLAIN = {'fused_mlp.hip'}      # translation units left uninstrumented in the --asan flavour (see build())
