@@ -673,24 +673,35 @@ __global__ __launch_bounds__(256) void cand_list_kernel(CandGrid cg, const float
 // avc_lbs_prepare then does without lists instead of asking for the memory.
 __global__ __launch_bounds__(1024) void cand_scan_kernel(int *__restrict__ a, int n)
 {
-    __shared__ long long part[1024];
-    const int per = (n + 1023) / 1024, lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
-    long long sum = 0;
-    for (int i = lo; i < hi; ++i) sum += a[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const long long v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    // batches of 16384 counts through LDS (coalesced in and out; a thread sums its 16 consecutive ones, the block scans the thread sums): 0.3 ms for the 3.4 M
+    // cells of a whole volume (a thread walking its own contiguous share of the array, uncoalesced, took 6 ms)
+    constexpr int PER = 16, BATCH = 1024 * PER;
+    __shared__ int buf[BATCH + BATCH / 16];                  // padded: a thread's 16 consecutive words start 17 words apart
+    __shared__ long long wsum[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    auto at = [](int i) { return i + (i >> 4); };
+    long long carry = 0;
+    for (int b0 = 0; b0 < n; b0 += BATCH) {
+        for (int j = 0; j < PER; ++j) { const int i = j * 1024 + threadIdx.x; buf[at(i)] = b0 + i < n ? a[b0 + i] : 0; }
         __syncthreads();
-        part[threadIdx.x] += v;
+        int v[PER]; long long sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { v[j] = buf[at(threadIdx.x * PER + j)]; sum += v[j]; }
+        long long incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { const long long t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        long long base = 0, all = 0;
+        for (int k = 0; k < 16; ++k) { if (k < w) base += wsum[k]; all += wsum[k]; }
+        long long run = carry + base + incl - sum;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { buf[at(threadIdx.x * PER + j)] = (int)run; run += v[j]; }
+        carry += all;
+        __syncthreads();
+        for (int j = 0; j < PER; ++j) { const int i = j * 1024 + threadIdx.x; if (b0 + i < n) a[b0 + i] = buf[at(i)]; }
         __syncthreads();
     }
-    long long run = part[threadIdx.x] - sum;
-    for (int i = lo; i < hi; ++i) { const int v = a[i]; a[i] = (int)run; run += v; }
-    if (threadIdx.x == 1023) {
-        const long long total = part[1023];
-        a[n] = (int)total; a[n + 2] = (int)(total & 0xffffffffll); a[n + 3] = (int)(total >> 32);
-    }
+    if (threadIdx.x == 0) { a[n] = (int)carry; a[n + 2] = (int)(carry & 0xffffffffll); a[n + 3] = (int)(carry >> 32); }
 }
 
 }  // namespace
