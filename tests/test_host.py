@@ -246,3 +246,19 @@ def test_tensor_watch_sees_what_the_packers_must_see():
         assert twin._weights_version() != net._weights_version() and twin._weights_version() == twin._weights_version()
     finally:
         config.cfg, config.device = old_cfg, old_dev
+
+
+def test_build_flags_keep_packed_f32_out_of_the_elementwise_units():
+    """profiles/r06_store_hazard.md: a packed-f32 VALU result read as store data an instruction later reached memory stale beside another kernel.  hipcc forms
+    those instructions by itself; the translation units whose kernels store what they have just computed are built without them (and fused_mlp.hip, where they cost
+    issue time beside the MFMAs).  conv_enc.hip keeps them (its element-wise kernels settle() their stores: csrc/store_settle.h)."""
+    from avatarcap_amd import build
+    nopk = ' '.join(build.NOPK)
+    assert '-packed-fp32-ops' in nopk
+    for unit in ('mesh.hip', 'knn_lbs.hip', 'raster.hip', 'render.hip', 'misc.hip', 'fusion.hip', 'fused_mlp.hip'):
+        assert nopk in ' '.join(build.EXTRA[unit]), unit
+    for unit in ('mesh.hip', 'knn_lbs.hip', 'raster.hip', 'render.hip'):          # bit-exact against the C oracles: no contraction
+        assert '-ffp-contract=off' in build.EXTRA[unit], unit
+    assert 'store_settle.h' in build.HEADERS
+    src = open(os.path.join(os.path.dirname(build.__file__), 'csrc', 'conv_enc.hip')).read()
+    assert src.count('settle(') >= 3 and '#include "store_settle.h"' in src
